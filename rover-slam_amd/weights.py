@@ -1,0 +1,137 @@
+"""Seeded synthetic weights + the RFEW container the C ABI loads (rfe_load_weights).
+
+The reference ships no weights in-tree (onnxmodel/*.onnx are missing, .MISSING_LARGE_BLOBS:4-5),
+so every test / bench in this repo runs on synthetic, seeded, architecture-shaped weights.
+Canonical blob layouts (float32, concatenated in this order):
+
+SuperPoint (1 300 865 floats): for each of conv1a conv1b conv2a conv2b conv3a conv3b conv4a conv4b
+  convPa convPb convDa convDb: weight [Cout,Cin,k,k] (PyTorch OIHW) then bias [Cout].
+  (layer names: reference include/SuperPoint.h:24-41)
+
+LightGlue: Wr [32,2]; 9 x { self: Wqkv [768,256] (rows 0..255 = q, 256..511 = k, 512..767 = v,
+  each head-major 4x64), bqkv, Wo [256,256], bo, W1 [512,512], b1, ln_g [512], ln_b [512],
+  W2 [256,512], b2;  cross: Wqk, bqk, Wv, bv, Wo, bo, W1, b1, ln_g, ln_b, W2, b2 };
+  final_proj W [256,256], b; matchability w [256], b [1].
+"""
+import struct
+import numpy as np
+
+SP_LAYERS = [  # name, cin, cout, k
+    ("conv1a", 1, 64, 3), ("conv1b", 64, 64, 3), ("conv2a", 64, 64, 3), ("conv2b", 64, 64, 3),
+    ("conv3a", 64, 128, 3), ("conv3b", 128, 128, 3), ("conv4a", 128, 128, 3), ("conv4b", 128, 128, 3),
+    ("convPa", 128, 256, 3), ("convPb", 256, 65, 1), ("convDa", 128, 256, 3), ("convDb", 256, 256, 1),
+]
+LG_LAYERS = 9
+
+
+def sp_manifest():
+    out, off = [], 0
+    for name, cin, cout, k in SP_LAYERS:
+        out.append((name + ".weight", off, (cout, cin, k, k)))
+        off += cout * cin * k * k
+        out.append((name + ".bias", off, (cout,)))
+        off += cout
+    return out, off
+
+
+def lg_manifest():
+    out, off = [], 0
+
+    def take(name, shape):
+        nonlocal off
+        out.append((name, off, shape))
+        off += int(np.prod(shape))
+
+    take("posenc.Wr", (32, 2))
+    for l in range(LG_LAYERS):
+        p = f"layers.{l}."
+        take(p + "self.Wqkv", (768, 256)); take(p + "self.bqkv", (768,))
+        take(p + "self.Wo", (256, 256)); take(p + "self.bo", (256,))
+        take(p + "self.W1", (512, 512)); take(p + "self.b1", (512,))
+        take(p + "self.ln_g", (512,)); take(p + "self.ln_b", (512,))
+        take(p + "self.W2", (256, 512)); take(p + "self.b2", (256,))
+        take(p + "cross.Wqk", (256, 256)); take(p + "cross.bqk", (256,))
+        take(p + "cross.Wv", (256, 256)); take(p + "cross.bv", (256,))
+        take(p + "cross.Wo", (256, 256)); take(p + "cross.bo", (256,))
+        take(p + "cross.W1", (512, 512)); take(p + "cross.b1", (512,))
+        take(p + "cross.ln_g", (512,)); take(p + "cross.ln_b", (512,))
+        take(p + "cross.W2", (256, 512)); take(p + "cross.b2", (256,))
+    take("final_proj.W", (256, 256)); take("final_proj.b", (256,))
+    take("matchability.w", (256,)); take("matchability.b", (1,))
+    return out, off
+
+
+SP_COUNT = sp_manifest()[1]
+LG_COUNT = lg_manifest()[1]
+
+
+def make_superpoint(seed=7, dustbin_bias=0.0, logit_gain=4.0):
+    """He-normal convs, biases U[-0.05,0.05].  `logit_gain` widens the 65-way logits so the score
+    map is not near-uniform; `dustbin_bias` > 0 pushes mass into channel 64 (fewer keypoints)."""
+    rng = np.random.default_rng(seed)
+    man, n = sp_manifest()
+    blob = np.empty(n, np.float32)
+    for name, off, shape in man:
+        cnt = int(np.prod(shape))
+        if name.endswith(".weight"):
+            fan_in = shape[1] * shape[2] * shape[3]
+            w = rng.standard_normal(cnt).astype(np.float32) * np.float32(np.sqrt(2.0 / fan_in))
+            if name.startswith("convPb"):
+                w *= np.float32(logit_gain)
+            blob[off:off + cnt] = w
+        else:
+            b = rng.uniform(-0.05, 0.05, cnt).astype(np.float32)
+            if name.startswith("convPb"):
+                b[64] += np.float32(dustbin_bias)
+            blob[off:off + cnt] = b
+    return blob
+
+
+def make_lightglue(seed=11, proj_gain=6.0):
+    rng = np.random.default_rng(seed)
+    man, n = lg_manifest()
+    blob = np.empty(n, np.float32)
+    for name, off, shape in man:
+        cnt = int(np.prod(shape))
+        leaf = name.split(".")[-1]
+        if leaf == "Wr":
+            v = rng.standard_normal(cnt) * 3.0
+        elif leaf == "ln_g":
+            v = 1.0 + 0.1 * rng.standard_normal(cnt)
+        elif leaf in ("ln_b",) or leaf.startswith("b"):
+            v = rng.uniform(-0.05, 0.05, cnt)
+        elif leaf == "w":  # matchability
+            v = rng.standard_normal(cnt) / np.sqrt(256.0)
+        else:
+            fan_in = shape[-1]
+            g = 1.0
+            if leaf == "W2":
+                g = 0.5      # keep the residual stream tame over 18 blocks
+            if name.startswith("final_proj"):
+                g = proj_gain
+            v = rng.standard_normal(cnt) * (g / np.sqrt(fan_in))
+        blob[off:off + cnt] = v.astype(np.float32)
+    if name.endswith("matchability.b"):
+        blob[-1] = np.float32(2.0)
+    return blob
+
+
+_MAGIC = b"RFEW"
+
+
+def save(path, blob, kind):
+    """kind: 1 = SuperPoint, 2 = LightGlue."""
+    blob = np.ascontiguousarray(blob, np.float32)
+    with open(path, "wb") as f:
+        f.write(_MAGIC + struct.pack("<IIQ", 1, kind, blob.size))
+        f.write(blob.tobytes())
+
+
+def load(path):
+    with open(path, "rb") as f:
+        head = f.read(20)
+        assert head[:4] == _MAGIC, "not an RFEW file"
+        ver, kind, cnt = struct.unpack("<IIQ", head[4:])
+        blob = np.frombuffer(f.read(cnt * 4), np.float32).copy()
+    assert blob.size == cnt
+    return blob, kind
