@@ -1,0 +1,147 @@
+/*
+ * rover_fe.h -- C ABI of librover_fe.so: MI355X-native SuperPoint extractor + LightGlue matcher.
+ *
+ * This is the drop-in boundary for Rover-SLAM's learned front end.  Each entry point names the
+ * reference interface it replaces (paths relative to the reference checkout):
+ *
+ *   rfe_init / rfe_destroy        SuperPointOnnxRunner::InitOrtEnv   src/Extractors/superpoint_onnx.cc:4-66
+ *                                 LightGlueDecoupleOnnxRunner::InitOrtEnv  src/Matchers/lightglue_onnx.cpp:4-98
+ *   rfe_load_weights              the two model paths: src/Extractors/SPextractor.cc:93 (superpoint.onnx),
+ *                                 src/Matchers/lightglue_onnx.cpp:38 (lightglue_sim.onnx)
+ *   rfe_extract_u8                NormalizeImage (src/Matchers/transform.cpp:3-17) +
+ *                                 SuperPointOnnxRunner::Extractor_Inference (superpoint_onnx.cc:88-162,
+ *                                 Session::Run at :133-136) + the tensor unpacking half of
+ *                                 Extractor_PostProcess (superpoint_onnx.cc:165-255)
+ *   rfe_match                     LightGlueDecoupleOnnxRunner::Matcher_Inference
+ *                                 (lightglue_onnx.cpp:162-240, Session::Run at :210-214); inputs are the
+ *                                 already normalised keypoints of Matcher_PreProcess (:140-159)
+ *   rfe_match_fused               rfe_match + Matcher_PostProcess_fused (lightglue_onnx.cpp:396-482):
+ *                                 fills vnMatches12 exactly like SPmatcher::MatchingPoints_onnx
+ *                                 (src/Matchers/SPmatcher.cc:359-542)
+ *   rfe_extract_match_stream      batched-frames mode (BASELINE config 4): extract B frames and match
+ *                                 frame i with frame i+1, everything device resident
+ *
+ * Conventions: plain pointers and sizes only.  Functions return RFE_OK (0) or a negative
+ * rfe_status; nothing throws across the boundary; rfe_last_error() gives the message
+ * (the reference prints to std::cerr and returns EXIT_FAILURE, superpoint_onnx.cc:59-65).
+ * A ctx is single-caller (not re-entrant); several ctxs may be used concurrently from different
+ * threads (the reference gives each SPextractor / SPmatcher its own ORT session,
+ * src/Tracking.cc:645-651, :70).  "_dev" variants take DEVICE pointers and are asynchronous on
+ * the ctx stream; the plain variants take HOST pointers and return after the results are copied.
+ *
+ * There is no CPU fallback: every entry point fails with RFE_ERR_NO_DEVICE if no gfx950 GPU
+ * can be opened.
+ */
+#ifndef ROVER_FE_H
+#define ROVER_FE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rfe_ctx rfe_ctx;
+
+typedef enum {
+    RFE_OK = 0,
+    RFE_ERR_INVALID = -1,    /* bad argument */
+    RFE_ERR_NO_DEVICE = -2,  /* no HIP device / wrong arch */
+    RFE_ERR_HIP = -3,        /* a HIP runtime call failed */
+    RFE_ERR_IO = -4,         /* weight file problem */
+    RFE_ERR_NO_WEIGHTS = -5, /* model used before weights were set */
+    RFE_ERR_OOM = -6
+} rfe_status;
+
+#define RFE_DESC_DIM 256
+#define RFE_KIND_SUPERPOINT 1
+#define RFE_KIND_LIGHTGLUE 2
+
+/* ---- lifetime ---- */
+int rfe_init(int device, rfe_ctx** out);
+void rfe_destroy(rfe_ctx* ctx);
+const char* rfe_last_error(rfe_ctx* ctx); /* ctx may be NULL: last error of a failed rfe_init */
+const char* rfe_version(void);
+
+/* ---- weights: RFEW container files, or host blobs in the canonical layout ---- */
+int rfe_load_weights(rfe_ctx* ctx, const char* sp_path, const char* lg_path); /* either may be NULL */
+int rfe_set_weights(rfe_ctx* ctx, int kind, const float* blob, int64_t count);
+int64_t rfe_weight_count(int kind);
+
+/* ---- stream / sync / device memory helpers (so a pure-C caller needs no HIP headers) ---- */
+int rfe_set_stream(rfe_ctx* ctx, void* hip_stream); /* NULL -> ctx's own stream */
+int rfe_synchronize(rfe_ctx* ctx);
+int rfe_malloc(rfe_ctx* ctx, size_t bytes, void** dev_ptr);
+int rfe_free(rfe_ctx* ctx, void* dev_ptr);
+int rfe_memcpy_h2d(rfe_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int rfe_memcpy_d2h(rfe_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+
+/* ---- SuperPoint ----
+ * img:   u8 grayscale, B frames of H x W, row pitch `stride` bytes, frame pitch stride*H
+ *        (H, W multiples of 8; the reference asserts CV_8UC1, SPextractor.cc:525)
+ * Kmax:  capacity per frame (the export-time max_num_keypoints of the reference graph)
+ * thr:   detection threshold (0.0005 in the LightGlue-ONNX SuperPoint export)
+ * n:     [B]            number of keypoints per frame
+ * kxy:   [B,Kmax,2] i32 (x,y) integer pixel coordinates; rows >= n[b] are zero
+ * score: [B,Kmax]
+ * desc:  [B,Kmax,256]   L2-normalised descriptors
+ * Order: score-descending (ties: row-major pixel index ascending) when more than Kmax candidates
+ * pass the threshold, row-major otherwise. */
+int rfe_extract_u8(rfe_ctx* ctx, const uint8_t* img, int H, int W, int stride, int B, int Kmax,
+                   float thr, int32_t* n, int32_t* kxy, float* score, float* desc);
+int rfe_extract_u8_dev(rfe_ctx* ctx, const uint8_t* img_dev, int H, int W, int stride, int B,
+                       int Kmax, float thr, int32_t* n_dev, int32_t* kxy_dev, float* score_dev,
+                       float* desc_dev);
+
+/* ---- LightGlue ----
+ * P pairs.  k0n/k1n: normalised keypoints [P,Mmax,2] / [P,Nmax,2]; d0/d1: [P,Mmax,256] /
+ * [P,Nmax,256]; m/n: [P] valid counts.  filter_thr: in-graph match filter (0.1).
+ * S: [P] number of matches; pairs: [P,min(Mmax,Nmax),2] (i,j) with i ascending; ms: scores. */
+int rfe_match(rfe_ctx* ctx, const float* k0n, const float* k1n, const float* d0, const float* d1,
+              const int32_t* m, const int32_t* n, int P, int Mmax, int Nmax, float filter_thr,
+              int32_t* S, int32_t* pairs, float* ms);
+int rfe_match_dev(rfe_ctx* ctx, const float* k0n, const float* k1n, const float* d0,
+                  const float* d1, const int32_t* m, const int32_t* n, int P, int Mmax, int Nmax,
+                  float filter_thr, int32_t* S, int32_t* pairs, float* ms);
+
+/* One pair, pixel keypoints in, vnMatches12 out (length M, -1 = unmatched); returns the number
+ * of accepted matches (>= 0) or a negative rfe_status.  (rows, cols) is the image size used by
+ * NormalizeKeypoints; pass 300,400 to reproduce the hard-coded quirk of three of the reference's
+ * four overloads (SPmatcher.cc:360-361,376-377,414-415). */
+int rfe_match_fused(rfe_ctx* ctx, const float* kpts0_xy, int M, const float* kpts1_xy, int N,
+                    const float* desc0, const float* desc1, int rows, int cols, float filter_thr,
+                    float match_thresh, int32_t* vnMatches12);
+
+/* ---- batched stream (device resident): extract B frames, match (i, i+1) for i < B-1 ----
+ * Outputs as in rfe_extract_u8_dev, plus S:[B-1], pairs:[B-1,Kmax,2], ms:[B-1,Kmax]
+ * (any match output pointer may be NULL to skip the copy-out of that array). */
+int rfe_extract_match_stream_dev(rfe_ctx* ctx, const uint8_t* img_dev, int H, int W, int stride,
+                                 int B, int Kmax, float thr, float filter_thr, int32_t* n_dev,
+                                 int32_t* kxy_dev, float* score_dev, float* desc_dev,
+                                 int32_t* S_dev, int32_t* pairs_dev, float* ms_dev);
+
+/* ---- per-stage timing (hipEvent on the ctx stream), for bench.py's roofline object ----
+ * Enable, run, then read back: names is a ';'-separated list of stage names, ms / calls the
+ * accumulated time and launch count per stage since the last reset. */
+int rfe_profile_enable(rfe_ctx* ctx, int on);
+int rfe_profile_reset(rfe_ctx* ctx);
+int rfe_profile_read(rfe_ctx* ctx, char* names, size_t names_cap, double* ms, int64_t* calls, int cap);
+
+/* ---- kernel-level test hooks (device pointers, synchronous): used only by tests/ ----
+ * NHWC activations, canonical weight layouts as in the oracle. */
+int rfe_k_conv3x3(rfe_ctx* ctx, const float* in_dev, int B, int H, int W, int Cin,
+                  const float* w_oihw_host, const float* bias_host, int Cout, int relu, int pool,
+                  float* out_dev);
+int rfe_k_linear(rfe_ctx* ctx, const float* a_dev, int M, int K, const float* w_nk_host,
+                 const float* bias_host, int N, int relu, float* out_dev);
+int rfe_k_scoremap(rfe_ctx* ctx, const uint8_t* img_dev, int H, int W, int stride, int B,
+                   float* scoremap_dev /*[B,H,W] pre-NMS*/, float* nms_dev /*[B,H,W] post-NMS+border*/,
+                   float* descmap_dev /*[B,H/8,W/8,256]*/);
+int rfe_k_lightglue_taps(rfe_ctx* ctx, const float* k0n, const float* k1n, const float* d0,
+                         const float* d1, int M, int N, float* x0_dev, float* x1_dev,
+                         float* scores_dev /*[M,N]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROVER_FE_H */

@@ -1,0 +1,205 @@
+"""ctypes binding of librover_fe.so (include/rover_fe.h).  The HIP library is the product's only
+compute path: importing this module raises ImportError when the library has not been built, and
+`Context()` raises RuntimeError when no gfx950 device can be opened -- there is no CPU fallback."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librover_fe.so")
+
+KIND_SUPERPOINT, KIND_LIGHTGLUE = 1, 2
+
+EXPORTS = [
+    "rfe_init", "rfe_destroy", "rfe_last_error", "rfe_version", "rfe_load_weights", "rfe_set_weights",
+    "rfe_weight_count", "rfe_set_stream", "rfe_synchronize", "rfe_malloc", "rfe_free", "rfe_memcpy_h2d",
+    "rfe_memcpy_d2h", "rfe_extract_u8", "rfe_extract_u8_dev", "rfe_match", "rfe_match_dev", "rfe_match_fused",
+    "rfe_extract_match_stream_dev", "rfe_profile_enable", "rfe_profile_reset", "rfe_profile_read",
+    "rfe_k_conv3x3", "rfe_k_linear", "rfe_k_scoremap", "rfe_k_lightglue_taps",
+]
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(rover-slam_amd/csrc/Makefile). There is no CPU fallback.")
+
+lib = C.CDLL(LIB_PATH)
+
+_vp, _fp, _ip, _u8p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p  # raw addresses (host or device)
+lib.rfe_init.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+lib.rfe_destroy.argtypes = [C.c_void_p]
+lib.rfe_destroy.restype = None
+lib.rfe_last_error.argtypes = [C.c_void_p]
+lib.rfe_last_error.restype = C.c_char_p
+lib.rfe_version.restype = C.c_char_p
+lib.rfe_load_weights.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+lib.rfe_set_weights.argtypes = [C.c_void_p, C.c_int, _fp, C.c_int64]
+lib.rfe_weight_count.argtypes = [C.c_int]
+lib.rfe_weight_count.restype = C.c_int64
+lib.rfe_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+lib.rfe_synchronize.argtypes = [C.c_void_p]
+lib.rfe_malloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+lib.rfe_free.argtypes = [C.c_void_p, C.c_void_p]
+lib.rfe_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+lib.rfe_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+_ext = [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _ip, _ip, _fp, _fp]
+lib.rfe_extract_u8.argtypes = _ext
+lib.rfe_extract_u8_dev.argtypes = _ext
+_mt = [C.c_void_p, _fp, _fp, _fp, _fp, _ip, _ip, C.c_int, C.c_int, C.c_int, C.c_float, _ip, _ip, _fp]
+lib.rfe_match.argtypes = _mt
+lib.rfe_match_dev.argtypes = _mt
+lib.rfe_match_fused.argtypes = [C.c_void_p, _fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_float,
+                                C.c_float, _ip]
+lib.rfe_extract_match_stream_dev.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                             C.c_float, _ip, _ip, _fp, _fp, _ip, _ip, _fp]
+lib.rfe_profile_enable.argtypes = [C.c_void_p, C.c_int]
+lib.rfe_profile_reset.argtypes = [C.c_void_p]
+lib.rfe_profile_read.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
+lib.rfe_k_conv3x3.argtypes = [C.c_void_p, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]
+lib.rfe_k_linear.argtypes = [C.c_void_p, _fp, C.c_int, C.c_int, _fp, _fp, C.c_int, C.c_int, _fp]
+lib.rfe_k_scoremap.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]
+lib.rfe_k_lightglue_taps.argtypes = [C.c_void_p, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]
+
+
+class RfeError(RuntimeError):
+    pass
+
+
+def _addr(a):
+    """address of a numpy array (host) / int (device pointer) / object with data_ptr() (torch)."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return a
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return a.ctypes.data
+    if hasattr(a, "data_ptr"):
+        return a.data_ptr()
+    raise TypeError(type(a))
+
+
+class DevBuf:
+    """Device allocation owned by a Context (rfe_malloc / rfe_free)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = C.c_void_p()
+        ctx._chk(lib.rfe_malloc(ctx.h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.ctx._chk(lib.rfe_memcpy_h2d(self.ctx.h, self.ptr, arr.ctypes.data, arr.nbytes))
+        return self
+
+    def download(self, shape, dtype):
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        self.ctx._chk(lib.rfe_memcpy_d2h(self.ctx.h, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib.rfe_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+
+class Context:
+    """One rfe_ctx (own HIP stream + workspaces).  Single caller, like one ORT session of the reference."""
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        rc = lib.rfe_init(device, C.byref(h))
+        if rc != 0:
+            raise RfeError(f"rfe_init failed ({rc}): {lib.rfe_last_error(None).decode()}")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib.rfe_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise RfeError(f"librover_fe error {rc}: {lib.rfe_last_error(self.h).decode()}")
+        return rc
+
+    # ---- weights
+    def set_weights(self, kind, blob):
+        blob = np.ascontiguousarray(blob, np.float32)
+        self._chk(lib.rfe_set_weights(self.h, kind, blob.ctypes.data, blob.size))
+
+    def load_weights(self, sp_path=None, lg_path=None):
+        self._chk(lib.rfe_load_weights(self.h, sp_path.encode() if sp_path else None, lg_path.encode() if lg_path else None))
+
+    def set_stream(self, stream_ptr):
+        self._chk(lib.rfe_set_stream(self.h, stream_ptr))
+
+    def synchronize(self):
+        self._chk(lib.rfe_synchronize(self.h))
+
+    def alloc(self, nbytes):
+        return DevBuf(self, nbytes)
+
+    # ---- host-buffer entry points
+    def extract(self, img_u8, kmax=1024, thr=0.0005):
+        """img_u8: [B,H,W] or [H,W] uint8 (host).  Returns n[B], kxy[B,Kmax,2], score[B,Kmax], desc[B,Kmax,256]."""
+        img = np.ascontiguousarray(img_u8, np.uint8)
+        if img.ndim == 2:
+            img = img[None]
+        B, H, W = img.shape
+        n = np.zeros((B,), np.int32)
+        kxy = np.zeros((B, kmax, 2), np.int32)
+        score = np.zeros((B, kmax), np.float32)
+        desc = np.zeros((B, kmax, 256), np.float32)
+        self._chk(lib.rfe_extract_u8(self.h, img.ctypes.data, H, W, W, B, kmax, thr, n.ctypes.data, kxy.ctypes.data,
+                                     score.ctypes.data, desc.ctypes.data))
+        return n, kxy, score, desc
+
+    def match(self, k0n, k1n, d0, d1, m, n, filter_thr=0.1):
+        """Batched pairs, host arrays: k0n [P,Mmax,2], d0 [P,Mmax,256], m [P] ...  Returns S[P], pairs, ms."""
+        k0n = np.ascontiguousarray(k0n, np.float32); k1n = np.ascontiguousarray(k1n, np.float32)
+        d0 = np.ascontiguousarray(d0, np.float32); d1 = np.ascontiguousarray(d1, np.float32)
+        m = np.ascontiguousarray(m, np.int32); n = np.ascontiguousarray(n, np.int32)
+        P, Mmax = k0n.shape[0], k0n.shape[1]
+        Nmax = k1n.shape[1]
+        cap = min(Mmax, Nmax)
+        S = np.zeros((P,), np.int32)
+        pairs = np.zeros((P, cap, 2), np.int32)
+        ms = np.zeros((P, cap), np.float32)
+        self._chk(lib.rfe_match(self.h, k0n.ctypes.data, k1n.ctypes.data, d0.ctypes.data, d1.ctypes.data, m.ctypes.data,
+                                n.ctypes.data, P, Mmax, Nmax, filter_thr, S.ctypes.data, pairs.ctypes.data, ms.ctypes.data))
+        return S, pairs, ms
+
+    def match_fused(self, kpts0, kpts1, desc0, desc1, rows, cols, filter_thr=0.1, match_thresh=0.0):
+        kpts0 = np.ascontiguousarray(kpts0, np.float32).reshape(-1, 2)
+        kpts1 = np.ascontiguousarray(kpts1, np.float32).reshape(-1, 2)
+        desc0 = np.ascontiguousarray(desc0, np.float32); desc1 = np.ascontiguousarray(desc1, np.float32)
+        M, N = kpts0.shape[0], kpts1.shape[0]
+        vn = np.full((max(M, 1),), -1, np.int32)
+        size = self._chk(lib.rfe_match_fused(self.h, kpts0.ctypes.data, M, kpts1.ctypes.data, N, desc0.ctypes.data,
+                                             desc1.ctypes.data, rows, cols, filter_thr, match_thresh, vn.ctypes.data))
+        return size, vn[:M]
+
+    # ---- profiling
+    def profile(self, on=True):
+        self._chk(lib.rfe_profile_enable(self.h, int(on)))
+
+    def profile_reset(self):
+        self._chk(lib.rfe_profile_reset(self.h))
+
+    def profile_read(self):
+        names = C.create_string_buffer(4096)
+        ms = (C.c_double * 64)()
+        calls = (C.c_int64 * 64)()
+        k = self._chk(lib.rfe_profile_read(self.h, names, 4096, ms, calls, 64))
+        nm = names.value.decode().split(";") if k else []
+        return {nm[i]: (ms[i], calls[i]) for i in range(k)}

@@ -1,0 +1,392 @@
+// lg_kernels.hip -- LightGlue on CDNA4: positional encoding, rotary, fused (flash-style) attention
+// on the fp32 matrix cores, LayerNorm+GELU, and the dual-softmax assignment with mutual filtering.
+// Replaces the body of lightglue_sim.onnx, which the reference executes through
+// Ort::Session::Run (src/Matchers/lightglue_onnx.cpp:210-214); output contract matches0 [S,2] /
+// mscores0 [S] as consumed by Matcher_PostProcess_fused (lightglue_onnx.cpp:404-409).
+// fp32 throughout (descriptor tolerance 1e-4 of the north star rules out bf16 operands).
+#include "rfe_internal.h"
+
+namespace rfe {
+
+// ---------------------------------------------------------------- posenc: theta = Wr . p ; cos/sin
+__global__ void lg_posenc_kernel(const float* __restrict__ kn, const float* __restrict__ wr, int rows,
+                                 float* __restrict__ cs, float* __restrict__ sn) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= rows * 32) return;
+    const int i = gid >> 5, f = gid & 31;
+    const float th = fmaf(wr[2 * f + 1], kn[2 * i + 1], wr[2 * f] * kn[2 * i]);
+    cs[gid] = cosf(th);
+    sn[gid] = sinf(th);
+}
+void launch_lg_posenc(hipStream_t s, const float* kn, const float* wr, int rows, float* cs, float* sn) {
+    hipLaunchKernelGGL(lg_posenc_kernel, dim3((rows * 32 + 255) / 256), dim3(256), 0, s, kn, wr, rows, cs, sn);
+}
+
+// qkv [rows,768] -> q,k (rotary applied, pairs (2f,2f+1) per head) and v, each [rows,256]
+__global__ void lg_rope_split_kernel(const float* __restrict__ qkv, const float* __restrict__ cs,
+                                     const float* __restrict__ sn, int rows, float* __restrict__ q,
+                                     float* __restrict__ k, float* __restrict__ v) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (row, channel pair)
+    if (gid >= rows * 128) return;
+    const int i = gid >> 7, c2 = gid & 127;                 // c2: pair index 0..127 ; freq = c2 & 31
+    const float c = cs[i * 32 + (c2 & 31)], s = sn[i * 32 + (c2 & 31)];
+    const float2 qq = *reinterpret_cast<const float2*>(qkv + (size_t)i * 768 + 2 * c2);
+    const float2 kk = *reinterpret_cast<const float2*>(qkv + (size_t)i * 768 + 256 + 2 * c2);
+    const float2 vv = *reinterpret_cast<const float2*>(qkv + (size_t)i * 768 + 512 + 2 * c2);
+    *reinterpret_cast<float2*>(q + (size_t)i * 256 + 2 * c2) = make_float2(qq.x * c - qq.y * s, qq.y * c + qq.x * s);
+    *reinterpret_cast<float2*>(k + (size_t)i * 256 + 2 * c2) = make_float2(kk.x * c - kk.y * s, kk.y * c + kk.x * s);
+    *reinterpret_cast<float2*>(v + (size_t)i * 256 + 2 * c2) = vv;
+}
+void launch_lg_rope_split(hipStream_t s, const float* qkv, const float* cs, const float* sn, int rows, float* q,
+                          float* k, float* v) {
+    hipLaunchKernelGGL(lg_rope_split_kernel, dim3((rows * 128 + 255) / 256), dim3(256), 0, s, qkv, cs, sn, rows, q, k, v);
+}
+
+// ---------------------------------------------------------------- fused attention
+// softmax(Q K^T / 8) V per (sequence, head), online softmax, never materialising the L x L matrix.
+// Workgroup = 4 waves = 128 queries of one head; wave = 32 queries.  Per 64-key tile staged in LDS:
+//   S^T = K . Q^T   (A = K tile rows from LDS, B = Q fragment held in 32 VGPRs)  -> lane = one query,
+//         16 keys in registers: the softmax row reduction is in-lane + one xor-32 shuffle;
+//   O^T += V^T . P^T  where the B operand of k-step r IS accumulator register r of S^T (the key
+//         order of the reduction is permuted to the D-layout order, so P never moves).
+// 64 MFMA (32x32x2 f32) per 32x32 tile, no wasted FLOPs: 4*L*L*64 per head.
+constexpr int AT_Q = 128, AT_K = 64, AT_LDK = 65;
+
+__global__ __launch_bounds__(256, 2) void lg_attention_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, float* __restrict__ out,
+    int Lq, int Lk, const int* __restrict__ qlen, const int* __restrict__ klen, const int* __restrict__ kv_map) {
+    __shared__ float Ks[AT_K * AT_LDK];
+    __shared__ float Vs[AT_K * 64];
+    const int seq = blockIdx.z, head = blockIdx.y, qb = blockIdx.x;
+    const int kvseq = kv_map ? kv_map[seq] : seq;
+    const int nq = qlen ? qlen[seq] : Lq;
+    const int nk = klen ? klen[kvseq] : Lk;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (qb * AT_Q >= nq) {  // whole block is padding: keep the padded context rows defined (zero)
+        for (int e = tid; e < AT_Q * 64; e += 256) {
+            const int row = qb * AT_Q + (e >> 6);
+            if (row < Lq) out[((size_t)seq * Lq + row) * 256 + head * 64 + (e & 63)] = 0.f;
+        }
+        return;
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int qrow = qb * AT_Q + wave * 32 + j;  // this lane's query (may be >= nq: computed, not stored)
+    const float* qp = q + ((size_t)seq * Lq + (qrow < Lq ? qrow : Lq - 1)) * 256 + head * 64 + h;
+    float qreg[32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) qreg[s] = qp[2 * s];
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const float* kbase = k + (size_t)kvseq * Lk * 256 + head * 64;
+    const float* vbase = v + (size_t)kvseq * Lk * 256 + head * 64;
+    for (int k0 = 0; k0 < nk; k0 += AT_K) {
+        __syncthreads();
+        // stage K,V tile: 64 keys x 64 dims each; thread -> (key = tid/4 [+0], 16 dims)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int key = (tid >> 4) + 16 * it, dq = tid & 15;
+            float4 kv4 = make_float4(0.f, 0.f, 0.f, 0.f), vv4 = kv4;
+            if (k0 + key < nk) {
+                kv4 = *reinterpret_cast<const float4*>(kbase + (size_t)(k0 + key) * 256 + dq * 4);
+                vv4 = *reinterpret_cast<const float4*>(vbase + (size_t)(k0 + key) * 256 + dq * 4);
+            }
+            float* dk = Ks + key * AT_LDK + dq * 4;
+            dk[0] = kv4.x; dk[1] = kv4.y; dk[2] = kv4.z; dk[3] = kv4.w;
+            *reinterpret_cast<float4*>(Vs + key * 64 + dq * 4) = vv4;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < AT_K / 32; ++sub) {
+            if (k0 + sub * 32 >= nk) break;
+            // ---- S^T[key][query] = sum_d K[key][d] * Q[query][d]
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+            const float* ka = Ks + (sub * 32 + j) * AT_LDK + h;
+#pragma unroll
+            for (int s = 0; s < 32; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[2 * s], qreg[s], st, 0, 0, 0);
+            // ---- online softmax over this lane's 16 keys (+ the other half-wave's 16)
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                st[r] = key < nk ? st[r] * 0.125f : -INFINITY;
+                mx = fmaxf(mx, st[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = expf(m_run - m_new);  // m_run = -inf on the first tile -> 0
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[r] = expf(st[r] - m_new); ps += st[r]; }
+            ps += __shfl_xor(ps, 32);
+            l_run = l_run * alpha + ps;
+            m_run = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            // ---- O^T[d][query] += sum_key V[key][d] * P[key][query]; k-step r uses key(r,h)
+            const float* va = Vs + (sub * 32 + 4 * h) * 64 + j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kr = (r & 3) + 8 * (r >> 2);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[kr * 64], st[r], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[kr * 64 + 32], st[r], o1, 0, 0, 0);
+            }
+        }
+    }
+    if (qrow < Lq) {
+        const float inv = (qrow < nq && l_run > 0.f) ? 1.0f / l_run : 0.f;  // padded rows -> 0
+        float* op = out + ((size_t)seq * Lq + qrow) * 256 + head * 64;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = (r & 3) + 8 * (r >> 2) + 4 * h;
+            op[d] = o0[r] * inv;
+            op[d + 32] = o1[r] * inv;
+        }
+    }
+}
+
+void launch_lg_attention(hipStream_t s, const float* q, const float* k, const float* v, float* out, int nseq, int Lq,
+                         int Lk, const int* qlen, const int* klen, const int* kv_map) {
+    dim3 grid((Lq + AT_Q - 1) / AT_Q, 4, nseq);
+    hipLaunchKernelGGL(lg_attention_kernel, grid, dim3(256), 0, s, q, k, v, out, Lq, Lk, qlen, klen, kv_map);
+}
+
+// ---------------------------------------------------------------- LayerNorm(512) + GELU(erf), in place
+__global__ __launch_bounds__(256) void lg_ln_gelu_kernel(float* __restrict__ hbuf, const float* __restrict__ g,
+                                                         const float* __restrict__ b, int64_t rows) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float4* p = reinterpret_cast<float4*>(hbuf + row * 512) + lane * 2;
+    float4 a = p[0], c = p[1];
+    float sum = ((a.x + a.y) + (a.z + a.w)) + ((c.x + c.y) + (c.z + c.w));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    const float mean = sum * (1.0f / 512.0f);
+    float x[8] = {a.x - mean, a.y - mean, a.z - mean, a.w - mean, c.x - mean, c.y - mean, c.z - mean, c.w - mean};
+    float var = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) var = fmaf(x[e], x[e], var);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) var += __shfl_xor(var, off);
+    const float rs = 1.0f / sqrtf(var * (1.0f / 512.0f) + 1e-5f);
+    const float4 g0 = reinterpret_cast<const float4*>(g)[lane * 2], g1 = reinterpret_cast<const float4*>(g)[lane * 2 + 1];
+    const float4 b0 = reinterpret_cast<const float4*>(b)[lane * 2], b1 = reinterpret_cast<const float4*>(b)[lane * 2 + 1];
+    const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float vv = x[e] * rs * gg[e] + bb[e];
+        x[e] = 0.5f * vv * (1.0f + erff(vv * 0.70710678118654752f));
+    }
+    p[0] = make_float4(x[0], x[1], x[2], x[3]);
+    p[1] = make_float4(x[4], x[5], x[6], x[7]);
+}
+void launch_lg_ln_gelu(hipStream_t s, float* h, const float* g, const float* b, int64_t rows) {
+    hipLaunchKernelGGL(lg_ln_gelu_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, h, g, b, rows);
+}
+
+// z[row] = x[row] . w + b   (matchability head, 256 -> 1)
+__global__ __launch_bounds__(256) void lg_matchability_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ b, int64_t rows,
+                                                              float* __restrict__ z) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float4 a = reinterpret_cast<const float4*>(x + row * 256)[lane];
+    const float4 ww = reinterpret_cast<const float4*>(w)[lane];
+    float s = fmaf(a.w, ww.w, fmaf(a.z, ww.z, fmaf(a.y, ww.y, a.x * ww.x)));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) z[row] = s + b[0];
+}
+void launch_lg_matchability(hipStream_t s, const float* x, const float* w, const float* b, int64_t rows, float* z) {
+    hipLaunchKernelGGL(lg_matchability_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, w, b, rows, z);
+}
+
+// ---------------------------------------------------------------- assignment
+__device__ __forceinline__ float logsigmoid_(float z) { return z >= 0.f ? -log1pf(expf(-z)) : z - log1pf(expf(z)); }
+
+// row log-sum-exp of sim[p][i][0..n) : one wave per row
+__global__ __launch_bounds__(256) void lg_rowlse_kernel(const float* __restrict__ sim, int L, const int* __restrict__ m,
+                                                        const int* __restrict__ n, float* __restrict__ rowlse) {
+    const int p = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= m[p]) return;
+    const int nn = n[p];
+    const float* r = sim + ((size_t)p * L + i) * L;
+    float mx = -INFINITY;
+    for (int jj = lane; jj < nn; jj += 64) mx = fmaxf(mx, r[jj]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float s = 0.f;
+    for (int jj = lane; jj < nn; jj += 64) s += expf(r[jj] - mx);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) rowlse[(size_t)p * L + i] = mx + logf(s);
+}
+
+// column log-sum-exp: block = 32 columns x 8 row groups
+__global__ __launch_bounds__(256) void lg_collse_kernel(const float* __restrict__ sim, int L, const int* __restrict__ m,
+                                                        const int* __restrict__ n, float* __restrict__ collse) {
+    __shared__ float red[8][33];
+    const int p = blockIdx.y, c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int jj = blockIdx.x * 32 + c;
+    const int mm = m[p], nn = n[p];
+    const float* base = sim + (size_t)p * L * L;
+    float mx = -INFINITY;
+    if (jj < nn) for (int i = rg; i < mm; i += 8) mx = fmaxf(mx, base[(size_t)i * L + jj]);
+    red[rg][c] = mx;
+    __syncthreads();
+    float gm = red[0][c];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) gm = fmaxf(gm, red[g][c]);
+    __syncthreads();
+    float s = 0.f;
+    if (jj < nn) for (int i = rg; i < mm; i += 8) s += expf(base[(size_t)i * L + jj] - gm);
+    red[rg][c] = s;
+    __syncthreads();
+    if (rg == 0 && jj < nn) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += red[g][c];
+        collse[(size_t)p * L + jj] = gm + logf(t);
+    }
+}
+
+__device__ __forceinline__ float lg_score(float sv, float lr, float lc, float l0, float l1) {
+    return ((sv - lr) + (sv - lc)) + (l0 + l1);
+}
+
+// row argmax (first maximum) + optional dump of the score matrix: one wave per row
+__global__ __launch_bounds__(256) void lg_rowarg_kernel(const float* __restrict__ sim, const float* __restrict__ z0,
+                                                        const float* __restrict__ z1, const float* __restrict__ rowlse,
+                                                        const float* __restrict__ collse, int L, const int* __restrict__ m,
+                                                        const int* __restrict__ n, int32_t* __restrict__ a0,
+                                                        float* __restrict__ mx0, float* __restrict__ scores_opt) {
+    const int p = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= m[p]) return;
+    const int nn = n[p];
+    const float* r = sim + ((size_t)p * L + i) * L;
+    const float lr = rowlse[(size_t)p * L + i], l0 = logsigmoid_(z0[(size_t)p * L + i]);
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int jj = lane; jj < nn; jj += 64) {
+        const float sc = lg_score(r[jj], lr, collse[(size_t)p * L + jj], l0, logsigmoid_(z1[(size_t)p * L + jj]));
+        if (scores_opt) scores_opt[((size_t)p * L + i) * L + jj] = sc;
+        if (sc > best) { best = sc; bi = jj; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ob = __shfl_xor(best, off); const int oi = __shfl_xor(bi, off);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { a0[(size_t)p * L + i] = bi == 0x7fffffff ? 0 : bi; mx0[(size_t)p * L + i] = best; }
+}
+
+__global__ __launch_bounds__(256) void lg_colarg_kernel(const float* __restrict__ sim, const float* __restrict__ z0,
+                                                        const float* __restrict__ z1, const float* __restrict__ rowlse,
+                                                        const float* __restrict__ collse, int L, const int* __restrict__ m,
+                                                        const int* __restrict__ n, int32_t* __restrict__ a1) {
+    __shared__ float rb[8][33];
+    __shared__ int ri[8][33];
+    const int p = blockIdx.y, c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int jj = blockIdx.x * 32 + c;
+    const int mm = m[p], nn = n[p];
+    const float* base = sim + (size_t)p * L * L;
+    float best = -INFINITY; int bi = 0x7fffffff;
+    if (jj < nn) {
+        const float lc = collse[(size_t)p * L + jj], l1 = logsigmoid_(z1[(size_t)p * L + jj]);
+        for (int i = rg; i < mm; i += 8) {
+            const float sc = lg_score(base[(size_t)i * L + jj], rowlse[(size_t)p * L + i], lc,
+                                      logsigmoid_(z0[(size_t)p * L + i]), l1);
+            if (sc > best) { best = sc; bi = i; }
+        }
+    }
+    rb[rg][c] = best; ri[rg][c] = bi;
+    __syncthreads();
+    if (rg == 0 && jj < nn) {
+#pragma unroll
+        for (int g = 1; g < 8; ++g) {
+            const float ob = rb[g][c]; const int oi = ri[g][c];
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        a1[(size_t)p * L + jj] = bi == 0x7fffffff ? 0 : bi;
+    }
+}
+
+// mutual check + exp + threshold + ordered compaction: one workgroup per pair
+__global__ __launch_bounds__(256) void lg_mutual_kernel(const int32_t* __restrict__ a0, const float* __restrict__ mx0,
+                                                        const int32_t* __restrict__ a1, int L, int cap,
+                                                        const int* __restrict__ m, const int* __restrict__ n, float thr,
+                                                        int32_t* __restrict__ S, int32_t* __restrict__ pairs,
+                                                        float* __restrict__ ms) {
+    __shared__ int wave_tot[4];
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int mm = m[p], nn = n[p];
+    int count = 0;
+    for (int base = 0; base < mm; base += 256) {
+        const int i = base + tid;
+        bool ok = false; int jbest = 0; float e = 0.f;
+        if (i < mm && nn > 0) {
+            jbest = a0[(size_t)p * L + i];
+            e = expf(mx0[(size_t)p * L + i]);
+            ok = (a1[(size_t)p * L + jbest] == i) && (e > thr);
+        }
+        const unsigned long long bal = __ballot(ok);
+        if (lane == 0) wave_tot[wv] = __popcll(bal);
+        __syncthreads();
+        int off = 0, tot = 0;
+        for (int w = 0; w < 4; ++w) { if (w < wv) off += wave_tot[w]; tot += wave_tot[w]; }
+        __syncthreads();
+        if (ok) {
+            const int pos = count + off + __popcll(bal & ((1ull << lane) - 1ull));
+            if (pos < cap) {
+                pairs[((size_t)p * cap + pos) * 2] = i; pairs[((size_t)p * cap + pos) * 2 + 1] = jbest;
+                ms[(size_t)p * cap + pos] = e;
+            }
+        }
+        count += tot;
+    }
+    if (tid == 0) S[p] = count < cap ? count : cap;
+}
+
+void launch_lg_assign(hipStream_t s, const float* sim, const float* z0, const float* z1, int P, int L, int cap,
+                      const int* m, const int* n, float thr, float* scores_opt, float* rowlse, float* collse,
+                      int32_t* a0, float* mx0, int32_t* a1, int32_t* S, int32_t* pairs, float* ms) {
+    hipLaunchKernelGGL(lg_rowlse_kernel, dim3((L + 3) / 4, P), dim3(256), 0, s, sim, L, m, n, rowlse);
+    hipLaunchKernelGGL(lg_collse_kernel, dim3((L + 31) / 32, P), dim3(256), 0, s, sim, L, m, n, collse);
+    hipLaunchKernelGGL(lg_rowarg_kernel, dim3((L + 3) / 4, P), dim3(256), 0, s, sim, z0, z1, rowlse, collse, L, m, n, a0, mx0, scores_opt);
+    hipLaunchKernelGGL(lg_colarg_kernel, dim3((L + 31) / 32, P), dim3(256), 0, s, sim, z0, z1, rowlse, collse, L, m, n, a1);
+    hipLaunchKernelGGL(lg_mutual_kernel, dim3(P), dim3(256), 0, s, a0, mx0, a1, L, cap, m, n, thr, S, pairs, ms);
+}
+
+// ---------------------------------------------------------------- small helpers
+__global__ void copy_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+void launch_copy_f32(hipStream_t s, const float* src, float* dst, int64_t n) {
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(copy_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, n);
+}
+
+// NormalizeKeypoints (reference src/Matchers/transform.cpp:19-32) on integer pixel keypoints
+__global__ void normalize_kpts_kernel(const int32_t* __restrict__ kxy, int64_t n, float sx, float sy, float scale,
+                                      float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[2 * i] = ((float)kxy[2 * i] - sx) / scale;
+    out[2 * i + 1] = ((float)kxy[2 * i + 1] - sy) / scale;
+}
+void launch_normalize_kpts(hipStream_t s, const int32_t* kxy, int64_t n, int rows, int cols, float* out) {
+    const float sx = (float)cols / 2, sy = (float)rows / 2, scale = (float)(rows > cols ? rows : cols) / 2;
+    hipLaunchKernelGGL(normalize_kpts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, kxy, n, sx, sy, scale, out);
+}
+
+}  // namespace rfe

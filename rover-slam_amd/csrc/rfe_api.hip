@@ -1,0 +1,704 @@
+// rfe_api.hip -- the C ABI of librover_fe.so (see include/rover_fe.h for the reference interface
+// each entry point replaces).  Host-side orchestration only: weight packing, workspaces, the two
+// kernel pipelines (SuperPoint, LightGlue) and the batched stream mode.  No CPU compute path.
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <mutex>
+#include "rfe_internal.h"
+
+using namespace rfe;
+
+static std::string g_init_error;
+static std::mutex g_mu;
+
+namespace rfe {
+
+int fail(rfe_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    else { std::lock_guard<std::mutex> l(g_mu); g_init_error = msg; }
+    return code;
+}
+
+int ensure_ws(rfe_ctx* c, void** p, size_t* cur, size_t need) {
+    if (need <= *cur) return RFE_OK;
+    if (*p) { RFE_HIP(c, hipStreamSynchronize(c->stream)); RFE_HIP(c, hipFree(*p)); *p = nullptr; *cur = 0; }
+    need = (need + ((size_t)1 << 20)) & ~(((size_t)1 << 20) - 1);
+    hipError_t e = hipMalloc(p, need);
+    if (e != hipSuccess) return fail(c, RFE_ERR_OOM, std::string("hipMalloc workspace: ") + hipGetErrorString(e));
+    *cur = need;
+    return RFE_OK;
+}
+
+ProfScope::ProfScope(rfe_ctx* ctx, const char* name) : c(ctx), idx(-1) {
+    if (!c->prof) return;
+    for (size_t i = 0; i < c->stages.size(); ++i) if (c->stages[i].name == name) idx = (int)i;
+    if (idx < 0) { c->stages.push_back(Stage{name, 0, 0}); idx = (int)c->stages.size() - 1; }
+    auto get = [&]() { hipEvent_t e; if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); } else hipEventCreate(&e); return e; };
+    e0 = get(); e1 = get();
+    hipEventRecord(e0, c->stream);
+}
+ProfScope::~ProfScope() {
+    if (idx < 0) return;
+    hipEventRecord(e1, c->stream);
+    c->pending.push_back({idx, {e0, e1}});
+}
+void prof_collect(rfe_ctx* c) {
+    for (auto& p : c->pending) {
+        float ms = 0.f;
+        hipEventSynchronize(p.second.second);
+        hipEventElapsedTime(&ms, p.second.first, p.second.second);
+        c->stages[p.first].ms += ms; c->stages[p.first].calls += 1;
+        c->ev_pool.push_back(p.second.first); c->ev_pool.push_back(p.second.second);
+    }
+    c->pending.clear();
+}
+
+// bump allocator over a workspace
+struct Bump {
+    char* base; size_t off = 0;
+    explicit Bump(void* b) : base((char*)b) {}
+    template <typename T> T* take(size_t n) { T* p = (T*)(base + off); off += (n * sizeof(T) + 255) & ~(size_t)255; return p; }
+};
+static size_t al(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+
+}  // namespace rfe
+
+// =====================================================================================
+// lifetime
+// =====================================================================================
+extern "C" const char* rfe_version(void) { return "rover-fe 0.1 (gfx950)"; }
+
+extern "C" const char* rfe_last_error(rfe_ctx* ctx) {
+    if (ctx) return ctx->err.c_str();
+    return g_init_error.c_str();
+}
+
+extern "C" int rfe_init(int device, rfe_ctx** out) {
+    if (!out) return fail(nullptr, RFE_ERR_INVALID, "rfe_init: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, RFE_ERR_NO_DEVICE, "rfe_init: no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(nullptr, RFE_ERR_INVALID, "rfe_init: device index out of range");
+    if ((e = hipSetDevice(device)) != hipSuccess)
+        return fail(nullptr, RFE_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess)
+        return fail(nullptr, RFE_ERR_HIP, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, RFE_ERR_NO_DEVICE, std::string("rfe_init: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+    rfe_ctx* c = new rfe_ctx();
+    c->device = device;
+    if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) {
+        delete c;
+        return fail(nullptr, RFE_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return RFE_OK;
+}
+
+extern "C" void rfe_destroy(rfe_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    for (auto e : c->ev_pool) hipEventDestroy(e);
+    auto fr = [](void* p) { if (p) hipFree(p); };
+    fr(c->sp.conv1a_w);
+    for (int l = 0; l < 12; ++l) { fr(c->sp.packed[l]); fr(c->sp.bias[l]); }
+    fr(c->lg.blob);
+    fr(c->ws_sp); fr(c->ws_lg); fr(c->ws_io); fr(c->ws_tmp);
+    hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+extern "C" int rfe_set_stream(rfe_ctx* c, void* s) {
+    if (!c) return RFE_ERR_INVALID;
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return RFE_OK;
+}
+extern "C" int rfe_synchronize(rfe_ctx* c) {
+    if (!c) return RFE_ERR_INVALID;
+    RFE_HIP(c, hipSetDevice(c->device));
+    RFE_HIP(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    return RFE_OK;
+}
+extern "C" int rfe_malloc(rfe_ctx* c, size_t bytes, void** p) {
+    if (!c || !p) return RFE_ERR_INVALID;
+    RFE_HIP(c, hipSetDevice(c->device));
+    hipError_t e = hipMalloc(p, bytes ? bytes : 1);
+    if (e != hipSuccess) return fail(c, RFE_ERR_OOM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return RFE_OK;
+}
+extern "C" int rfe_free(rfe_ctx* c, void* p) {
+    if (!c) return RFE_ERR_INVALID;
+    RFE_HIP(c, hipSetDevice(c->device));
+    RFE_HIP(c, hipFree(p));
+    return RFE_OK;
+}
+extern "C" int rfe_memcpy_h2d(rfe_ctx* c, void* d, const void* s, size_t n) {
+    if (!c) return RFE_ERR_INVALID;
+    RFE_HIP(c, hipSetDevice(c->device));
+    RFE_HIP(c, hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, c->stream));
+    RFE_HIP(c, hipStreamSynchronize(c->stream));
+    return RFE_OK;
+}
+extern "C" int rfe_memcpy_d2h(rfe_ctx* c, void* d, const void* s, size_t n) {
+    if (!c) return RFE_ERR_INVALID;
+    RFE_HIP(c, hipSetDevice(c->device));
+    RFE_HIP(c, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, c->stream));
+    RFE_HIP(c, hipStreamSynchronize(c->stream));
+    return RFE_OK;
+}
+
+// =====================================================================================
+// weights
+// =====================================================================================
+extern "C" int64_t rfe_weight_count(int kind) {
+    return kind == RFE_KIND_SUPERPOINT ? SP_COUNT : kind == RFE_KIND_LIGHTGLUE ? LG_COUNT : -1;
+}
+
+static int upload(rfe_ctx* c, float** dst, const float* src, size_t n) {
+    if (*dst) { RFE_HIP(c, hipFree(*dst)); *dst = nullptr; }
+    RFE_HIP(c, hipMalloc((void**)dst, n * sizeof(float)));
+    RFE_HIP(c, hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyHostToDevice));
+    return RFE_OK;
+}
+
+static int set_sp(rfe_ctx* c, const float* blob) {
+    size_t off = 0;
+    for (int l = 0; l < 12; ++l) {
+        const SpLayer& L = kSpLayers[l];
+        const float* w = blob + off;
+        const size_t wn = (size_t)L.cout * L.cin * L.k * L.k;
+        const float* b = w + wn;
+        off += wn + L.cout;
+        int rc;
+        if (l == L_1A) {
+            std::vector<float> t(9 * 64);
+            for (int co = 0; co < 64; ++co) for (int k = 0; k < 9; ++k) t[k * 64 + co] = w[co * 9 + k];
+            if ((rc = upload(c, &c->sp.conv1a_w, t.data(), t.size()))) return rc;
+        } else if (L.k == 3) {
+            std::vector<float> t;
+            pack_conv3x3_weights(w, L.cin, L.cout, t);
+            if ((rc = upload(c, &c->sp.packed[l], t.data(), t.size()))) return rc;
+        } else {
+            if ((rc = upload(c, &c->sp.packed[l], w, wn))) return rc;  // [N][K] as-is
+        }
+        if ((rc = upload(c, &c->sp.bias[l], b, L.cout))) return rc;
+    }
+    c->has_sp = true;
+    return RFE_OK;
+}
+
+static int set_lg(rfe_ctx* c, const float* blob) {
+    int rc = upload(c, &c->lg.blob, blob, (size_t)LG_COUNT);
+    if (rc) return rc;
+    float* p = c->lg.blob;
+    auto take = [&](size_t n) { float* r = p; p += n; return r; };
+    LgWeightsDev& W = c->lg;
+    W.wr = take(64);
+    for (int l = 0; l < LG_LAYERS; ++l) {
+        LgLayerDev& L = W.L[l];
+        L.wqkv = take(768 * 256); L.bqkv = take(768); L.wo = take(256 * 256); L.bo = take(256);
+        L.w1 = take(512 * 512); L.b1 = take(512); L.lng = take(512); L.lnb = take(512);
+        L.w2 = take(256 * 512); L.b2 = take(256);
+        L.cwqk = take(256 * 256); L.cbqk = take(256); L.cwv = take(256 * 256); L.cbv = take(256);
+        L.cwo = take(256 * 256); L.cbo = take(256);
+        L.cw1 = take(512 * 512); L.cb1 = take(512); L.clng = take(512); L.clnb = take(512);
+        L.cw2 = take(256 * 512); L.cb2 = take(256);
+    }
+    W.wp = take(256 * 256); W.bp = take(256); W.wm = take(256); W.bm = take(1);
+    if (p - c->lg.blob != LG_COUNT) return fail(c, RFE_ERR_INVALID, "internal: LightGlue blob layout mismatch");
+    c->has_lg = true;
+    return RFE_OK;
+}
+
+extern "C" int rfe_set_weights(rfe_ctx* c, int kind, const float* blob, int64_t count) {
+    if (!c || !blob) return fail(c, RFE_ERR_INVALID, "rfe_set_weights: null argument");
+    RFE_HIP(c, hipSetDevice(c->device));
+    if (count != rfe_weight_count(kind)) return fail(c, RFE_ERR_INVALID, "rfe_set_weights: wrong float count for this model kind");
+    RFE_HIP(c, hipStreamSynchronize(c->stream));
+    return kind == RFE_KIND_SUPERPOINT ? set_sp(c, blob) : set_lg(c, blob);
+}
+
+static int load_rfew(rfe_ctx* c, const char* path, int want_kind) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(c, RFE_ERR_IO, std::string("cannot open weight file ") + path);
+    unsigned char head[20];
+    if (fread(head, 1, 20, f) != 20 || memcmp(head, "RFEW", 4) != 0) { fclose(f); return fail(c, RFE_ERR_IO, std::string("not an RFEW file: ") + path); }
+    uint32_t ver, kind; uint64_t cnt;
+    memcpy(&ver, head + 4, 4); memcpy(&kind, head + 8, 4); memcpy(&cnt, head + 12, 8);
+    if (ver != 1 || (int)kind != want_kind || (int64_t)cnt != rfe_weight_count(want_kind)) { fclose(f); return fail(c, RFE_ERR_IO, std::string("RFEW header mismatch in ") + path); }
+    std::vector<float> blob(cnt);
+    size_t got = fread(blob.data(), sizeof(float), cnt, f);
+    fclose(f);
+    if (got != cnt) return fail(c, RFE_ERR_IO, std::string("short read on ") + path);
+    return rfe_set_weights(c, want_kind, blob.data(), (int64_t)cnt);
+}
+
+extern "C" int rfe_load_weights(rfe_ctx* c, const char* sp_path, const char* lg_path) {
+    if (!c) return RFE_ERR_INVALID;
+    int rc;
+    if (sp_path && (rc = load_rfew(c, sp_path, RFE_KIND_SUPERPOINT))) return rc;
+    if (lg_path && (rc = load_rfew(c, lg_path, RFE_KIND_LIGHTGLUE))) return rc;
+    return RFE_OK;
+}
+
+// =====================================================================================
+// SuperPoint pipeline
+// =====================================================================================
+namespace {
+
+struct SpBuffers {
+    float *a1, *p1, *a2, *p2, *a3, *p3, *a4, *f4, *pa, *logits, *da, *dmap, *smap, *nmap, *ss;
+    uint8_t *mask, *supp;
+    float* cand_score; int32_t* cand_idx;
+};
+
+size_t sp_ws_bytes(int B, int H, int W) {
+    const size_t hw = (size_t)B * H * W, cells = hw / 64;
+    size_t t = 0;
+    t += al(hw * 64 * 4);          // a1
+    t += al(hw / 4 * 64 * 4) * 2;  // p1, a2
+    t += al(hw / 16 * 64 * 4);     // p2
+    t += al(hw / 16 * 128 * 4);    // a3
+    t += al(cells * 128 * 4) * 3;  // p3, a4, f4
+    t += al(cells * 256 * 4) * 3;  // pa, da, dmap
+    t += al(cells * 65 * 4);       // logits
+    t += al(hw * 4) * 3;           // smap, nmap, ss
+    t += al(hw) * 2;               // mask, supp
+    t += al(hw * 4) * 2;           // cand
+    return t + 4096;
+}
+
+void sp_carve(void* ws, int B, int H, int W, SpBuffers& b) {
+    const size_t hw = (size_t)B * H * W, cells = hw / 64;
+    Bump a(ws);
+    b.a1 = a.take<float>(hw * 64); b.p1 = a.take<float>(hw / 4 * 64); b.a2 = a.take<float>(hw / 4 * 64);
+    b.p2 = a.take<float>(hw / 16 * 64); b.a3 = a.take<float>(hw / 16 * 128);
+    b.p3 = a.take<float>(cells * 128); b.a4 = a.take<float>(cells * 128); b.f4 = a.take<float>(cells * 128);
+    b.pa = a.take<float>(cells * 256); b.da = a.take<float>(cells * 256); b.dmap = a.take<float>(cells * 256);
+    b.logits = a.take<float>(cells * 65);
+    b.smap = a.take<float>(hw); b.nmap = a.take<float>(hw); b.ss = a.take<float>(hw);
+    b.mask = a.take<uint8_t>(hw); b.supp = a.take<uint8_t>(hw);
+    b.cand_score = a.take<float>(hw); b.cand_idx = a.take<int32_t>(hw);
+}
+
+GemmArgs gemm_plain(const float* A, int lda, const float* Bw, int ldb, const float* bias, float* C, int ldc, int M, int N, int K) {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.lda = lda; g.B = Bw; g.ldb = ldb; g.bias = bias; g.C = C; g.ldc = ldc;
+    g.M = M; g.N = N; g.K = K; g.alpha = 1.0f; g.batch = 1;
+    return g;
+}
+
+int sp_check(rfe_ctx* c, int H, int W, int B, int Kmax) {
+    if (!c) return RFE_ERR_INVALID;
+    if (!c->has_sp) return fail(c, RFE_ERR_NO_WEIGHTS, "SuperPoint weights not loaded (rfe_load_weights / rfe_set_weights)");
+    if (H <= 0 || W <= 0 || (H % 8) || (W % 8) || B <= 0) return fail(c, RFE_ERR_INVALID, "extract: H and W must be positive multiples of 8, B > 0");
+    if (Kmax <= 0 || Kmax > 4096) return fail(c, RFE_ERR_INVALID, "extract: Kmax must be in 1..4096");
+    return RFE_OK;
+}
+
+// backbone + heads up to the NMS'ed score map and the normalised descriptor map
+int sp_forward_maps(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, int B, SpBuffers& b) {
+    int rc = ensure_ws(c, &c->ws_sp, &c->ws_sp_bytes, sp_ws_bytes(B, H, W));
+    if (rc) return rc;
+    sp_carve(c->ws_sp, B, H, W, b);
+    hipStream_t s = c->stream;
+    const SpWeightsDev& w = c->sp;
+    const int Hc = H / 8, Wc = W / 8, cells = B * Hc * Wc;
+    { ProfScope p(c, "conv1a"); launch_conv1a_u8(s, img, stride, B, H, W, w.conv1a_w, w.bias[L_1A], b.a1); }
+    { ProfScope p(c, "conv1b"); launch_conv3x3(s, b.a1, B, H, W, 64, w.packed[L_1B], w.bias[L_1B], 64, true, true, b.p1, L_1B); }
+    { ProfScope p(c, "conv2a"); launch_conv3x3(s, b.p1, B, H / 2, W / 2, 64, w.packed[L_2A], w.bias[L_2A], 64, true, false, b.a2, L_2A); }
+    { ProfScope p(c, "conv2b"); launch_conv3x3(s, b.a2, B, H / 2, W / 2, 64, w.packed[L_2B], w.bias[L_2B], 64, true, true, b.p2, L_2B); }
+    { ProfScope p(c, "conv3a"); launch_conv3x3(s, b.p2, B, H / 4, W / 4, 64, w.packed[L_3A], w.bias[L_3A], 128, true, false, b.a3, L_3A); }
+    { ProfScope p(c, "conv3b"); launch_conv3x3(s, b.a3, B, H / 4, W / 4, 128, w.packed[L_3B], w.bias[L_3B], 128, true, true, b.p3, L_3B); }
+    { ProfScope p(c, "conv4a"); launch_conv3x3(s, b.p3, B, Hc, Wc, 128, w.packed[L_4A], w.bias[L_4A], 128, true, false, b.a4, L_4A); }
+    { ProfScope p(c, "conv4b"); launch_conv3x3(s, b.a4, B, Hc, Wc, 128, w.packed[L_4B], w.bias[L_4B], 128, true, false, b.f4, L_4B); }
+    { ProfScope p(c, "convPa"); launch_conv3x3(s, b.f4, B, Hc, Wc, 128, w.packed[L_PA], w.bias[L_PA], 256, true, false, b.pa, L_PA); }
+    { ProfScope p(c, "convDa"); launch_conv3x3(s, b.f4, B, Hc, Wc, 128, w.packed[L_DA], w.bias[L_DA], 256, true, false, b.da, L_DA); }
+    { ProfScope p(c, "head_gemm");
+      launch_gemm_nt(s, gemm_plain(b.pa, 256, w.packed[L_PB], 256, w.bias[L_PB], b.logits, 65, cells, 65, 256));
+      launch_gemm_nt(s, gemm_plain(b.da, 256, w.packed[L_DB], 256, w.bias[L_DB], b.dmap, 256, cells, 256, 256)); }
+    { ProfScope p(c, "sp_post");
+      launch_softmax65_d2s(s, b.logits, 65, B, Hc, Wc, b.smap);
+      launch_nms(s, b.smap, B, H, W, 4, b.ss, b.mask, b.supp, b.nmap);
+      launch_descmap_norm(s, b.dmap, cells); }
+    RFE_HIP(c, hipGetLastError());
+    return RFE_OK;
+}
+
+int sp_forward(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, int B, int Kmax, float thr,
+               int32_t* n, int32_t* kxy, float* score, float* desc) {
+    SpBuffers b;
+    int rc = sp_forward_maps(c, img, H, W, stride, B, b);
+    if (rc) return rc;
+    { ProfScope p(c, "sp_select");
+      launch_select(c->stream, b.nmap, B, H, W, Kmax, thr, b.cand_score, b.cand_idx, n, kxy, score);
+      launch_desc_sample(c->stream, b.dmap, B, H / 8, W / 8, H, W, n, kxy, Kmax, desc); }
+    RFE_HIP(c, hipGetLastError());
+    return RFE_OK;
+}
+
+}  // namespace
+
+extern "C" int rfe_extract_u8_dev(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, int B, int Kmax,
+                                  float thr, int32_t* n, int32_t* kxy, float* score, float* desc) {
+    int rc = sp_check(c, H, W, B, Kmax);
+    if (rc) return rc;
+    if (!img || !n || !kxy || !score || !desc || stride < W) return fail(c, RFE_ERR_INVALID, "extract: null pointer or stride < W");
+    RFE_HIP(c, hipSetDevice(c->device));
+    return sp_forward(c, img, H, W, stride, B, Kmax, thr, n, kxy, score, desc);
+}
+
+extern "C" int rfe_extract_u8(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, int B, int Kmax, float thr,
+                              int32_t* n, int32_t* kxy, float* score, float* desc) {
+    int rc = sp_check(c, H, W, B, Kmax);
+    if (rc) return rc;
+    if (!img || !n || !kxy || !score || !desc || stride < W) return fail(c, RFE_ERR_INVALID, "extract: null pointer or stride < W");
+    RFE_HIP(c, hipSetDevice(c->device));
+    const size_t ib = al((size_t)B * H * stride), nb = al((size_t)B * 4), kb = al((size_t)B * Kmax * 8),
+                 sb = al((size_t)B * Kmax * 4), db = al((size_t)B * Kmax * 1024);
+    if ((rc = ensure_ws(c, &c->ws_io, &c->ws_io_bytes, ib + nb + kb + sb + db))) return rc;
+    char* p = (char*)c->ws_io;
+    uint8_t* d_img = (uint8_t*)p; int32_t* d_n = (int32_t*)(p + ib); int32_t* d_k = (int32_t*)(p + ib + nb);
+    float* d_s = (float*)(p + ib + nb + kb); float* d_d = (float*)(p + ib + nb + kb + sb);
+    RFE_HIP(c, hipMemcpyAsync(d_img, img, (size_t)B * H * stride, hipMemcpyHostToDevice, c->stream));
+    if ((rc = sp_forward(c, d_img, H, W, stride, B, Kmax, thr, d_n, d_k, d_s, d_d))) return rc;
+    RFE_HIP(c, hipMemcpyAsync(n, d_n, (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
+    RFE_HIP(c, hipMemcpyAsync(kxy, d_k, (size_t)B * Kmax * 8, hipMemcpyDeviceToHost, c->stream));
+    RFE_HIP(c, hipMemcpyAsync(score, d_s, (size_t)B * Kmax * 4, hipMemcpyDeviceToHost, c->stream));
+    RFE_HIP(c, hipMemcpyAsync(desc, d_d, (size_t)B * Kmax * 1024, hipMemcpyDeviceToHost, c->stream));
+    RFE_HIP(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    return RFE_OK;
+}
+
+// =====================================================================================
+// LightGlue pipeline.  Token layout: side-major sequences, seq = side*P + pair, each padded to L.
+// =====================================================================================
+namespace {
+
+struct LgBuffers {
+    float *x, *kn, *cs, *sn, *qkv, *q, *k, *v, *ctx, *msg, *h, *md, *z, *sim, *rowlse, *collse, *mx0;
+    int32_t *a0, *a1, *lens, *kvmap;
+};
+
+size_t lg_ws_bytes(int P, int L) {
+    const size_t rows = (size_t)2 * P * L;
+    size_t t = 0;
+    t += al(rows * 256 * 4) * 7;  // x q k v ctx msg md
+    t += al(rows * 2 * 4) + al(rows * 32 * 4) * 2 + al(rows * 768 * 4) + al(rows * 512 * 4) + al(rows * 4);
+    t += al((size_t)P * L * L * 4);
+    t += al((size_t)P * L * 4) * 5;
+    t += al((size_t)2 * P * 4) * 2;
+    return t + 4096;
+}
+void lg_carve(void* ws, int P, int L, LgBuffers& b) {
+    const size_t rows = (size_t)2 * P * L;
+    Bump a(ws);
+    b.x = a.take<float>(rows * 256); b.q = a.take<float>(rows * 256); b.k = a.take<float>(rows * 256);
+    b.v = a.take<float>(rows * 256); b.ctx = a.take<float>(rows * 256); b.msg = a.take<float>(rows * 256);
+    b.md = a.take<float>(rows * 256);
+    b.kn = a.take<float>(rows * 2); b.cs = a.take<float>(rows * 32); b.sn = a.take<float>(rows * 32);
+    b.qkv = a.take<float>(rows * 768); b.h = a.take<float>(rows * 512); b.z = a.take<float>(rows);
+    b.sim = a.take<float>((size_t)P * L * L);
+    b.rowlse = a.take<float>((size_t)P * L); b.collse = a.take<float>((size_t)P * L); b.mx0 = a.take<float>((size_t)P * L);
+    b.a0 = a.take<int32_t>((size_t)P * L); b.a1 = a.take<int32_t>((size_t)P * L);
+    b.lens = a.take<int32_t>((size_t)2 * P); b.kvmap = a.take<int32_t>((size_t)2 * P);
+}
+
+// x + ffn([x | msg]) in place on b.x
+void lg_ffn(rfe_ctx* c, LgBuffers& b, int rows, const float* w1, const float* b1, const float* g, const float* be,
+            const float* w2, const float* b2) {
+    hipStream_t s = c->stream;
+    { ProfScope p(c, "lg_gemm");
+      GemmArgs a = gemm_plain(b.x, 256, w1, 512, b1, b.h, 512, rows, 512, 512);
+      a.A2 = b.msg; a.lda2 = 256; a.K1 = 256;
+      launch_gemm_nt(s, a); }
+    { ProfScope p(c, "lg_ln_gelu"); launch_lg_ln_gelu(s, b.h, g, be, rows); }
+    { ProfScope p(c, "lg_gemm");
+      GemmArgs a = gemm_plain(b.h, 512, w2, 512, b2, b.x, 256, rows, 256, 512);
+      a.R = b.x; a.ldr = 256;
+      launch_gemm_nt(s, a); }
+}
+
+// runs the 9 layers + assignment on already staged b.x / b.kn / b.lens / b.kvmap
+int lg_forward(rfe_ctx* c, LgBuffers& b, int P, int L, float thr, int cap, int32_t* S, int32_t* pairs, float* ms,
+               float* scores_opt) {
+    hipStream_t s = c->stream;
+    const LgWeightsDev& W = c->lg;
+    const int rows = 2 * P * L, nseq = 2 * P;
+    { ProfScope p(c, "lg_misc"); launch_lg_posenc(s, b.kn, W.wr, rows, b.cs, b.sn); }
+    for (int l = 0; l < LG_LAYERS; ++l) {
+        const LgLayerDev& Lw = W.L[l];
+        // ---- self block
+        { ProfScope p(c, "lg_gemm"); launch_gemm_nt(s, gemm_plain(b.x, 256, Lw.wqkv, 256, Lw.bqkv, b.qkv, 768, rows, 768, 256)); }
+        { ProfScope p(c, "lg_misc"); launch_lg_rope_split(s, b.qkv, b.cs, b.sn, rows, b.q, b.k, b.v); }
+        { ProfScope p(c, "lg_attention"); launch_lg_attention(s, b.q, b.k, b.v, b.ctx, nseq, L, L, b.lens, b.lens, nullptr); }
+        { ProfScope p(c, "lg_gemm"); launch_gemm_nt(s, gemm_plain(b.ctx, 256, Lw.wo, 256, Lw.bo, b.msg, 256, rows, 256, 256)); }
+        lg_ffn(c, b, rows, Lw.w1, Lw.b1, Lw.lng, Lw.lnb, Lw.w2, Lw.b2);
+        // ---- cross block
+        { ProfScope p(c, "lg_gemm");
+          launch_gemm_nt(s, gemm_plain(b.x, 256, Lw.cwqk, 256, Lw.cbqk, b.q, 256, rows, 256, 256));
+          launch_gemm_nt(s, gemm_plain(b.x, 256, Lw.cwv, 256, Lw.cbv, b.v, 256, rows, 256, 256)); }
+        { ProfScope p(c, "lg_attention"); launch_lg_attention(s, b.q, b.q, b.v, b.ctx, nseq, L, L, b.lens, b.lens, b.kvmap); }
+        { ProfScope p(c, "lg_gemm"); launch_gemm_nt(s, gemm_plain(b.ctx, 256, Lw.cwo, 256, Lw.cbo, b.msg, 256, rows, 256, 256)); }
+        lg_ffn(c, b, rows, Lw.cw1, Lw.cb1, Lw.clng, Lw.clnb, Lw.cw2, Lw.cb2);
+    }
+    // ---- assignment
+    { ProfScope p(c, "lg_gemm");
+      GemmArgs a = gemm_plain(b.x, 256, W.wp, 256, W.bp, b.md, 256, rows, 256, 256);
+      a.alpha = 0.25f;  // / 256^(1/4)
+      launch_gemm_nt(s, a);
+      GemmArgs g = gemm_plain(b.md, 256, b.md + (size_t)P * L * 256, 256, nullptr, b.sim, L, L, L, 256);
+      g.batch = P; g.sA = (long long)L * 256; g.sB = (long long)L * 256; g.sC = (long long)L * L;
+      g.m_valid = b.lens;
+      launch_gemm_nt(s, g); }
+    { ProfScope p(c, "lg_assign");
+      launch_lg_matchability(s, b.x, W.wm, W.bm, rows, b.z);
+      launch_lg_assign(s, b.sim, b.z, b.z + (size_t)P * L, P, L, cap, b.lens, b.lens + P, thr, scores_opt, b.rowlse,
+                       b.collse, b.a0, b.mx0, b.a1, S, pairs, ms); }
+    RFE_HIP(c, hipGetLastError());
+    return RFE_OK;
+}
+
+__global__ void lg_setup_kernel(const int32_t* m, const int32_t* n, int P, int Mmax, int Nmax, int32_t* lens, int32_t* kvmap) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * P) return;
+    int v = i < P ? m[i] : n[i - P];
+    const int cap = i < P ? Mmax : Nmax;
+    v = v < 0 ? 0 : (v > cap ? cap : v);
+    lens[i] = v;
+    kvmap[i] = i < P ? i + P : i - P;
+}
+
+// stage device inputs [P,Mmax,*]/[P,Nmax,*] into the padded side-major token layout
+int lg_stage(rfe_ctx* c, LgBuffers& b, const float* k0n, const float* k1n, const float* d0, const float* d1,
+             const int32_t* m, const int32_t* n, int P, int Mmax, int Nmax, int L) {
+    hipStream_t s = c->stream;
+    const size_t rows = (size_t)2 * P * L;
+    if (Mmax != L || Nmax != L) {
+        RFE_HIP(c, hipMemsetAsync(b.x, 0, rows * 256 * 4, s));
+        RFE_HIP(c, hipMemsetAsync(b.kn, 0, rows * 2 * 4, s));
+    }
+    RFE_HIP(c, hipMemcpy2DAsync(b.x, (size_t)L * 1024, d0, (size_t)Mmax * 1024, (size_t)Mmax * 1024, P, hipMemcpyDeviceToDevice, s));
+    RFE_HIP(c, hipMemcpy2DAsync(b.x + (size_t)P * L * 256, (size_t)L * 1024, d1, (size_t)Nmax * 1024, (size_t)Nmax * 1024, P, hipMemcpyDeviceToDevice, s));
+    RFE_HIP(c, hipMemcpy2DAsync(b.kn, (size_t)L * 8, k0n, (size_t)Mmax * 8, (size_t)Mmax * 8, P, hipMemcpyDeviceToDevice, s));
+    RFE_HIP(c, hipMemcpy2DAsync(b.kn + (size_t)P * L * 2, (size_t)L * 8, k1n, (size_t)Nmax * 8, (size_t)Nmax * 8, P, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(lg_setup_kernel, dim3((2 * P + 255) / 256), dim3(256), 0, s, m, n, P, Mmax, Nmax, b.lens, b.kvmap);
+    return RFE_OK;
+}
+
+int lg_check(rfe_ctx* c, int P, int Mmax, int Nmax) {
+    if (!c) return RFE_ERR_INVALID;
+    if (!c->has_lg) return fail(c, RFE_ERR_NO_WEIGHTS, "LightGlue weights not loaded (rfe_load_weights / rfe_set_weights)");
+    if (P <= 0 || Mmax <= 0 || Nmax <= 0 || Mmax > 4096 || Nmax > 4096) return fail(c, RFE_ERR_INVALID, "match: P > 0 and 1 <= Mmax,Nmax <= 4096 required");
+    return RFE_OK;
+}
+
+}  // namespace
+
+extern "C" int rfe_match_dev(rfe_ctx* c, const float* k0n, const float* k1n, const float* d0, const float* d1,
+                             const int32_t* m, const int32_t* n, int P, int Mmax, int Nmax, float thr, int32_t* S,
+                             int32_t* pairs, float* ms) {
+    int rc = lg_check(c, P, Mmax, Nmax);
+    if (rc) return rc;
+    if (!k0n || !k1n || !d0 || !d1 || !m || !n || !S || !pairs || !ms) return fail(c, RFE_ERR_INVALID, "match: null pointer");
+    RFE_HIP(c, hipSetDevice(c->device));
+    const int L = ((std::max(Mmax, Nmax) + 3) / 4) * 4;
+    if ((rc = ensure_ws(c, &c->ws_lg, &c->ws_lg_bytes, lg_ws_bytes(P, L)))) return rc;
+    LgBuffers b;
+    lg_carve(c->ws_lg, P, L, b);
+    if ((rc = lg_stage(c, b, k0n, k1n, d0, d1, m, n, P, Mmax, Nmax, L))) return rc;
+    return lg_forward(c, b, P, L, thr, std::min(Mmax, Nmax), S, pairs, ms, nullptr);
+}
+
+extern "C" int rfe_match(rfe_ctx* c, const float* k0n, const float* k1n, const float* d0, const float* d1,
+                         const int32_t* m, const int32_t* n, int P, int Mmax, int Nmax, float thr, int32_t* S,
+                         int32_t* pairs, float* ms) {
+    int rc = lg_check(c, P, Mmax, Nmax);
+    if (rc) return rc;
+    if (!k0n || !k1n || !d0 || !d1 || !m || !n || !S || !pairs || !ms) return fail(c, RFE_ERR_INVALID, "match: null pointer");
+    RFE_HIP(c, hipSetDevice(c->device));
+    const int cap = std::min(Mmax, Nmax);
+    const size_t bk0 = al((size_t)P * Mmax * 8), bk1 = al((size_t)P * Nmax * 8), bd0 = al((size_t)P * Mmax * 1024),
+                 bd1 = al((size_t)P * Nmax * 1024), bi = al((size_t)P * 4), bp = al((size_t)P * cap * 8), bs = al((size_t)P * cap * 4);
+    if ((rc = ensure_ws(c, &c->ws_io, &c->ws_io_bytes, bk0 + bk1 + bd0 + bd1 + 3 * bi + bp + bs))) return rc;
+    char* p = (char*)c->ws_io;
+    float* dk0 = (float*)p; p += bk0; float* dk1 = (float*)p; p += bk1; float* dd0 = (float*)p; p += bd0; float* dd1 = (float*)p; p += bd1;
+    int32_t* dm = (int32_t*)p; p += bi; int32_t* dn = (int32_t*)p; p += bi; int32_t* dS = (int32_t*)p; p += bi;
+    int32_t* dp = (int32_t*)p; p += bp; float* dms = (float*)p;
+    hipStream_t s = c->stream;
+    RFE_HIP(c, hipMemcpyAsync(dk0, k0n, (size_t)P * Mmax * 8, hipMemcpyHostToDevice, s));
+    RFE_HIP(c, hipMemcpyAsync(dk1, k1n, (size_t)P * Nmax * 8, hipMemcpyHostToDevice, s));
+    RFE_HIP(c, hipMemcpyAsync(dd0, d0, (size_t)P * Mmax * 1024, hipMemcpyHostToDevice, s));
+    RFE_HIP(c, hipMemcpyAsync(dd1, d1, (size_t)P * Nmax * 1024, hipMemcpyHostToDevice, s));
+    RFE_HIP(c, hipMemcpyAsync(dm, m, (size_t)P * 4, hipMemcpyHostToDevice, s));
+    RFE_HIP(c, hipMemcpyAsync(dn, n, (size_t)P * 4, hipMemcpyHostToDevice, s));
+    if ((rc = rfe_match_dev(c, dk0, dk1, dd0, dd1, dm, dn, P, Mmax, Nmax, thr, dS, dp, dms))) return rc;
+    RFE_HIP(c, hipMemcpyAsync(S, dS, (size_t)P * 4, hipMemcpyDeviceToHost, s));
+    RFE_HIP(c, hipMemcpyAsync(pairs, dp, (size_t)P * cap * 8, hipMemcpyDeviceToHost, s));
+    RFE_HIP(c, hipMemcpyAsync(ms, dms, (size_t)P * cap * 4, hipMemcpyDeviceToHost, s));
+    RFE_HIP(c, hipStreamSynchronize(s));
+    prof_collect(c);
+    return RFE_OK;
+}
+
+extern "C" int rfe_match_fused(rfe_ctx* c, const float* kp0, int M, const float* kp1, int N, const float* desc0,
+                               const float* desc1, int rows, int cols, float filter_thr, float match_thresh,
+                               int32_t* vnMatches12) {
+    if (!c) return RFE_ERR_INVALID;
+    if (M < 0 || N < 0 || !vnMatches12) return fail(c, RFE_ERR_INVALID, "match_fused: bad argument");
+    for (int i = 0; i < M; ++i) vnMatches12[i] = -1;   // vnMatches12.resize(M, -1): SPmatcher.cc:375,413,460
+    if (M == 0 || N == 0) return 0;
+    // NormalizeKeypoints, reference src/Matchers/transform.cpp:19-32
+    std::vector<float> k0((size_t)M * 2), k1((size_t)N * 2);
+    const float sx = (float)cols / 2, sy = (float)rows / 2, scale = (float)std::max(cols, rows) / 2;
+    for (int i = 0; i < M; ++i) { k0[2 * i] = (kp0[2 * i] - sx) / scale; k0[2 * i + 1] = (kp0[2 * i + 1] - sy) / scale; }
+    for (int i = 0; i < N; ++i) { k1[2 * i] = (kp1[2 * i] - sx) / scale; k1[2 * i + 1] = (kp1[2 * i + 1] - sy) / scale; }
+    const int cap = std::min(M, N);
+    std::vector<int32_t> pairs((size_t)cap * 2);
+    std::vector<float> ms(cap);
+    int32_t S = 0, m = M, n = N;
+    int rc = rfe_match(c, k0.data(), k1.data(), desc0, desc1, &m, &n, 1, M, N, filter_thr, &S, pairs.data(), ms.data());
+    if (rc) return rc;
+    // Matcher_PostProcess_fused, reference src/Matchers/lightglue_onnx.cpp:437-453
+    int size = 0;
+    for (int i = 0; i < S; ++i)
+        if (ms[i] > match_thresh) { ++size; vnMatches12[pairs[2 * i]] = pairs[2 * i + 1]; }
+    return size;
+}
+
+// =====================================================================================
+// batched stream: extract B frames, match (i, i+1)
+// =====================================================================================
+extern "C" int rfe_extract_match_stream_dev(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, int B, int Kmax,
+                                            float thr, float filter_thr, int32_t* n, int32_t* kxy, float* score,
+                                            float* desc, int32_t* S, int32_t* pairs, float* ms) {
+    int rc = rfe_extract_u8_dev(c, img, H, W, stride, B, Kmax, thr, n, kxy, score, desc);
+    if (rc || B < 2) return rc;
+    if ((rc = lg_check(c, B - 1, Kmax, Kmax))) return rc;
+    if (!S || !pairs || !ms) return fail(c, RFE_ERR_INVALID, "stream: null match output");
+    const int P = B - 1, L = ((Kmax + 3) / 4) * 4;
+    if ((rc = ensure_ws(c, &c->ws_lg, &c->ws_lg_bytes, lg_ws_bytes(P, L) + al((size_t)B * Kmax * 8)))) return rc;
+    LgBuffers b;
+    lg_carve(c->ws_lg, P, L, b);
+    float* kn_all = (float*)((char*)c->ws_lg + lg_ws_bytes(P, L) - 4096 + 256);
+    { ProfScope p(c, "lg_misc");
+      launch_normalize_kpts(c->stream, kxy, (int64_t)B * Kmax, H, W, kn_all);
+      if ((rc = lg_stage(c, b, kn_all, kn_all + (size_t)Kmax * 2, desc, desc + (size_t)Kmax * 256, n, n + 1, P, Kmax, Kmax, L))) return rc; }
+    return lg_forward(c, b, P, L, filter_thr, Kmax, S, pairs, ms, nullptr);
+}
+
+// =====================================================================================
+// profiling
+// =====================================================================================
+extern "C" int rfe_profile_enable(rfe_ctx* c, int on) { if (!c) return RFE_ERR_INVALID; c->prof = on != 0; return RFE_OK; }
+extern "C" int rfe_profile_reset(rfe_ctx* c) {
+    if (!c) return RFE_ERR_INVALID;
+    hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    c->stages.clear();
+    return RFE_OK;
+}
+extern "C" int rfe_profile_read(rfe_ctx* c, char* names, size_t names_cap, double* ms, int64_t* calls, int cap) {
+    if (!c) return RFE_ERR_INVALID;
+    hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    std::string all;
+    int k = 0;
+    for (auto& st : c->stages) {
+        if (k >= cap) break;
+        if (k) all += ";";
+        all += st.name; ms[k] = st.ms; calls[k] = st.calls; ++k;
+    }
+    if (names && names_cap) { strncpy(names, all.c_str(), names_cap - 1); names[names_cap - 1] = 0; }
+    return k;
+}
+
+// =====================================================================================
+// kernel-level test hooks
+// =====================================================================================
+extern "C" int rfe_k_conv3x3(rfe_ctx* c, const float* in, int B, int H, int W, int Cin, const float* w, const float* bias,
+                             int Cout, int relu, int pool, float* out) {
+    if (!c) return RFE_ERR_INVALID;
+    if ((Cin != 16 && Cin != 32 && Cin != 64 && Cin != 128) || (Cout % 64)) return fail(c, RFE_ERR_INVALID, "k_conv3x3: Cin in {16,32,64,128}, Cout % 64 == 0");
+    RFE_HIP(c, hipSetDevice(c->device));
+    std::vector<float> packed;
+    pack_conv3x3_weights(w, Cin, Cout, packed);
+    int rc = ensure_ws(c, &c->ws_tmp, &c->ws_tmp_bytes, al(packed.size() * 4) + al((size_t)Cout * 4));
+    if (rc) return rc;
+    float* dw = (float*)c->ws_tmp; float* db = (float*)((char*)c->ws_tmp + al(packed.size() * 4));
+    RFE_HIP(c, hipMemcpyAsync(dw, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, c->stream));
+    RFE_HIP(c, hipMemcpyAsync(db, bias, (size_t)Cout * 4, hipMemcpyHostToDevice, c->stream));
+    launch_conv3x3(c->stream, in, B, H, W, Cin, dw, db, Cout, relu != 0, pool != 0, out, 0);
+    RFE_HIP(c, hipGetLastError());
+    RFE_HIP(c, hipStreamSynchronize(c->stream));
+    return RFE_OK;
+}
+
+extern "C" int rfe_k_linear(rfe_ctx* c, const float* a, int M, int K, const float* w, const float* bias, int N, int relu,
+                            float* out) {
+    if (!c) return RFE_ERR_INVALID;
+    if (K % 32) return fail(c, RFE_ERR_INVALID, "k_linear: K % 32 == 0 required");
+    RFE_HIP(c, hipSetDevice(c->device));
+    int rc = ensure_ws(c, &c->ws_tmp, &c->ws_tmp_bytes, al((size_t)N * K * 4) + al((size_t)N * 4));
+    if (rc) return rc;
+    float* dw = (float*)c->ws_tmp; float* db = (float*)((char*)c->ws_tmp + al((size_t)N * K * 4));
+    RFE_HIP(c, hipMemcpyAsync(dw, w, (size_t)N * K * 4, hipMemcpyHostToDevice, c->stream));
+    if (bias) RFE_HIP(c, hipMemcpyAsync(db, bias, (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
+    GemmArgs g = gemm_plain(a, K, dw, K, bias ? db : nullptr, out, N, M, N, K);
+    g.relu = relu;
+    launch_gemm_nt(c->stream, g);
+    RFE_HIP(c, hipGetLastError());
+    RFE_HIP(c, hipStreamSynchronize(c->stream));
+    return RFE_OK;
+}
+
+extern "C" int rfe_k_scoremap(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, int B, float* scoremap,
+                              float* nms, float* descmap) {
+    int rc = sp_check(c, H, W, B, 1);
+    if (rc) return rc;
+    RFE_HIP(c, hipSetDevice(c->device));
+    SpBuffers b;
+    if ((rc = sp_forward_maps(c, img, H, W, stride, B, b))) return rc;
+    const size_t hw = (size_t)B * H * W;
+    if (scoremap) RFE_HIP(c, hipMemcpyAsync(scoremap, b.smap, hw * 4, hipMemcpyDeviceToDevice, c->stream));
+    if (nms) RFE_HIP(c, hipMemcpyAsync(nms, b.nmap, hw * 4, hipMemcpyDeviceToDevice, c->stream));
+    if (descmap) RFE_HIP(c, hipMemcpyAsync(descmap, b.dmap, hw / 64 * 256 * 4, hipMemcpyDeviceToDevice, c->stream));
+    RFE_HIP(c, hipStreamSynchronize(c->stream));
+    return RFE_OK;
+}
+
+extern "C" int rfe_k_lightglue_taps(rfe_ctx* c, const float* k0n, const float* k1n, const float* d0, const float* d1,
+                                    int M, int N, float* x0, float* x1, float* scores) {
+    int rc = lg_check(c, 1, M, N);
+    if (rc) return rc;
+    RFE_HIP(c, hipSetDevice(c->device));
+    const int L = ((std::max(M, N) + 3) / 4) * 4, cap = std::min(M, N);
+    const size_t extra = al((size_t)L * L * 4) + al(64) * 3 + al((size_t)cap * 8) + al((size_t)cap * 4);
+    if ((rc = ensure_ws(c, &c->ws_lg, &c->ws_lg_bytes, lg_ws_bytes(1, L) + extra))) return rc;
+    LgBuffers b;
+    lg_carve(c->ws_lg, 1, L, b);
+    char* p = (char*)c->ws_lg + lg_ws_bytes(1, L) - 4096 + 256;
+    float* sc = (float*)p; p += al((size_t)L * L * 4);
+    int32_t* dm = (int32_t*)p; p += al(64); int32_t* dn = (int32_t*)p; p += al(64); int32_t* dS = (int32_t*)p; p += al(64);
+    int32_t* dp = (int32_t*)p; p += al((size_t)cap * 8); float* dms = (float*)p;
+    RFE_HIP(c, hipMemcpyAsync(dm, &M, 4, hipMemcpyHostToDevice, c->stream));
+    RFE_HIP(c, hipMemcpyAsync(dn, &N, 4, hipMemcpyHostToDevice, c->stream));
+    RFE_HIP(c, hipStreamSynchronize(c->stream));
+    if ((rc = lg_stage(c, b, k0n, k1n, d0, d1, dm, dn, 1, M, N, L))) return rc;
+    if ((rc = lg_forward(c, b, 1, L, 0.1f, cap, dS, dp, dms, scores ? sc : nullptr))) return rc;
+    if (x0) RFE_HIP(c, hipMemcpyAsync(x0, b.x, (size_t)M * 1024, hipMemcpyDeviceToDevice, c->stream));
+    if (x1) RFE_HIP(c, hipMemcpyAsync(x1, b.x + (size_t)L * 256, (size_t)N * 1024, hipMemcpyDeviceToDevice, c->stream));
+    if (scores) RFE_HIP(c, hipMemcpy2DAsync(scores, (size_t)N * 4, sc, (size_t)L * 4, (size_t)N * 4, M, hipMemcpyDeviceToDevice, c->stream));
+    RFE_HIP(c, hipStreamSynchronize(c->stream));
+    return RFE_OK;
+}

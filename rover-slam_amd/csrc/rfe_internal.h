@@ -1,0 +1,143 @@
+// rfe_internal.h -- shared declarations of librover_fe.so (HIP, gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/rover_fe.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace rfe {
+
+// ---------------------------------------------------------------- SuperPoint layer table
+// names follow the reference's dead libtorch header include/SuperPoint.h:24-41
+struct SpLayer { int cin, cout, k; };
+static const SpLayer kSpLayers[12] = {
+    {1, 64, 3}, {64, 64, 3}, {64, 64, 3}, {64, 64, 3}, {64, 128, 3}, {128, 128, 3},
+    {128, 128, 3}, {128, 128, 3}, {128, 256, 3}, {256, 65, 1}, {128, 256, 3}, {256, 256, 1}};
+enum { L_1A, L_1B, L_2A, L_2B, L_3A, L_3B, L_4A, L_4B, L_PA, L_PB, L_DA, L_DB };
+
+constexpr int LG_LAYERS = 9;
+constexpr int64_t SP_COUNT = 1300865;
+constexpr int64_t LG_COUNT = 11321153;
+
+// conv3x3 implicit-GEMM tiling (see sp_conv.hip)
+constexpr int CONV_CK = 16;   // input channels per LDS chunk
+constexpr int CONV_NT = 64;   // output channels per workgroup
+
+// device-side packed SuperPoint weights
+struct SpWeightsDev {
+    float* conv1a_w = nullptr;           // [9][64]   (kappa-major)
+    float* packed[12] = {nullptr};       // 3x3 layers: [Cout/64][Cin/16][144][64]; 1x1: [N][K] as-is
+    float* bias[12] = {nullptr};
+};
+
+struct LgLayerDev {
+    float *wqkv, *bqkv, *wo, *bo, *w1, *b1, *lng, *lnb, *w2, *b2;
+    float *cwqk, *cbqk, *cwv, *cbv, *cwo, *cbo, *cw1, *cb1, *clng, *clnb, *cw2, *cb2;
+};
+struct LgWeightsDev {
+    float* blob = nullptr;  // whole canonical blob on device; pointers below index into it
+    float* wr;
+    LgLayerDev L[LG_LAYERS];
+    float *wp, *bp, *wm, *bm;
+};
+
+// ---------------------------------------------------------------- profiling
+struct Stage { std::string name; double ms = 0; int64_t calls = 0; };
+
+struct GemmArgs {
+    const float* A; int lda;          // rows of A, K-contiguous
+    const float* A2; int lda2; int K1; // optional second A source for k >= K1 (concat [x | msg])
+    const float* B; int ldb;          // B[n][k], K-contiguous (PyTorch Linear weight layout)
+    const float* bias;                // [N] or null
+    const float* R; int ldr;          // optional residual added after alpha/relu
+    float* C; int ldc;
+    int M, N, K;
+    float alpha; int relu;
+    long long sA, sA2, sB, sC, sR;    // batch strides (grid.z)
+    const int* m_valid;               // optional per-batch valid row count (rows >= m_valid skipped)
+    int batch;
+};
+
+}  // namespace rfe
+
+struct rfe_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool has_sp = false, has_lg = false;
+    rfe::SpWeightsDev sp;
+    rfe::LgWeightsDev lg;
+    // grow-only workspaces
+    void* ws_sp = nullptr; size_t ws_sp_bytes = 0;
+    void* ws_lg = nullptr; size_t ws_lg_bytes = 0;
+    void* ws_io = nullptr; size_t ws_io_bytes = 0;   // staging for host-pointer entry points
+    void* ws_tmp = nullptr; size_t ws_tmp_bytes = 0; // test hooks
+    // profiling
+    bool prof = false;
+    std::vector<rfe::Stage> stages;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+namespace rfe {
+
+int fail(rfe_ctx* c, int code, const std::string& msg);
+#define RFE_HIP(ctx, call)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return rfe::fail((ctx), RFE_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// profiling scope: records two events around a stage when ctx->prof is on
+struct ProfScope {
+    rfe_ctx* c; int idx; hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(rfe_ctx* ctx, const char* name);
+    ~ProfScope();
+};
+void prof_collect(rfe_ctx* c);
+
+int ensure_ws(rfe_ctx* c, void** p, size_t* cur, size_t need);
+
+// ---------------------------------------------------------------- kernel launchers
+// sp_conv.hip
+void pack_conv3x3_weights(const float* w_oihw, int cin, int cout, std::vector<float>& out);
+size_t packed_conv3x3_count(int cin, int cout);
+void launch_conv1a_u8(hipStream_t s, const uint8_t* img, int stride, int B, int H, int W,
+                      const float* w9x64, const float* bias, float* out);
+void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin,
+                    const float* wpacked, const float* bias, int cout, bool relu, bool pool, float* out,
+                    int tag = 0);
+// gemm.hip
+void launch_gemm_nt(hipStream_t s, const GemmArgs& g);
+// sp_post.hip
+void launch_softmax65_d2s(hipStream_t s, const float* logits, int ld, int B, int Hc, int Wc, float* score);
+void launch_nms(hipStream_t s, const float* score, int B, int H, int W, int border, float* tmp_ss,
+                uint8_t* tmp_mask, uint8_t* tmp_supp, float* out);
+void launch_select(hipStream_t s, const float* nms, int B, int H, int W, int Kmax, float thr,
+                   float* cand_score, int32_t* cand_idx, int32_t* n_out, int32_t* kxy, float* score);
+void launch_descmap_norm(hipStream_t s, float* dmap, int64_t cells);
+void launch_desc_sample(hipStream_t s, const float* dmap, int B, int Hc, int Wc, int H, int W,
+                        const int32_t* n, const int32_t* kxy, int Kmax, float* desc);
+// lg_kernels.hip
+void launch_lg_posenc(hipStream_t s, const float* kn, const float* wr, int rows, float* cs, float* sn);
+void launch_lg_rope_split(hipStream_t s, const float* qkv, const float* cs, const float* sn, int rows,
+                          float* q, float* k, float* v);
+void launch_lg_attention(hipStream_t s, const float* q, const float* k, const float* v, float* out,
+                         int nseq, int Lq, int Lk, const int* qlen, const int* klen,
+                         const int* kv_map /*seq -> kv seq index, or null = identity*/);
+void launch_lg_ln_gelu(hipStream_t s, float* h, const float* g, const float* b, int64_t rows);
+void launch_lg_assign(hipStream_t s, const float* sim, const float* z0, const float* z1, int P, int L,
+                      int cap, const int* m, const int* n, float thr, float* scores_opt, float* rowlse,
+                      float* collse, int32_t* a0, float* mx0, int32_t* a1, int32_t* S, int32_t* pairs,
+                      float* ms);
+void launch_lg_matchability(hipStream_t s, const float* x, const float* w, const float* b, int64_t rows, float* z);
+void launch_copy_f32(hipStream_t s, const float* src, float* dst, int64_t n);
+void launch_normalize_kpts(hipStream_t s, const int32_t* kxy, int64_t n, int rows, int cols, float* out);
+
+}  // namespace rfe

@@ -1,0 +1,236 @@
+// sp_conv.hip -- SuperPoint 3x3 convolutions on CDNA4 (gfx950).
+//
+// Replaces the conv nodes of the reference's superpoint.onnx (executed by ONNXRuntime at
+// src/Extractors/superpoint_onnx.cc:133-136).  Layout: NHWC fp32 activations.
+//
+// conv3x3_mfma_kernel: implicit GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact f32:
+// the accumulate is bit-for-bit an fmaf chain in k order).  Per workgroup (256 threads, 4 waves):
+//   output tile 8 rows x 32 cols x 64 output channels; wave w owns rows 2w,2w+1 (two 32-pixel
+//   M-blocks) x two 32-channel N-blocks -> 4 accumulators of 16 VGPRs.
+//   The K loop runs over chunks of 16 input channels: the haloed input tile is staged into LDS
+//   channel-planar ([ci][10][34]) so that the 32 lanes of an A-fragment read 32 consecutive words
+//   (bank-conflict free), the weight chunk ([144][64]) is a linear copy of a pre-packed blob.
+//   Canonical reduction order kappa = ci*9 + ky*3 + kx ascending, accumulator initialised with the
+//   bias -- identical to oracle/rfe_oracle.c:rfo_conv3x3, so results are bit-exact.
+//   Epilogue: ReLU, optional fused 2x2/2 max-pool (all four taps of a window live in one lane:
+//   D rows (r, r+1) of the two M-blocks), coalesced 128-B stores.
+// Roofline: compute bound on the fp32 MFMA peak (157.3 TFLOP/s); algorithmic 2*9*Cin*Cout FLOP/px.
+#include "rfe_internal.h"
+
+namespace rfe {
+
+constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 2;
+constexpr int TWS = IW;            // LDS row stride (words)
+constexpr int PLANE = IH * TWS;    // 340 words per input-channel plane
+constexpr int CK = CONV_CK;
+constexpr int KCH = CK * 9;        // 144 kappa per chunk
+constexpr int NT = CONV_NT;
+
+size_t packed_conv3x3_count(int cin, int cout) { return (size_t)cout * cin * 9; }
+
+// [Cout/64][Cin/16][144][64] : element (ct, ch, kl, j) = w[ct*64+j][ch*16 + kl/9][(kl%9)/3][kl%3]
+void pack_conv3x3_weights(const float* w, int cin, int cout, std::vector<float>& out) {
+    out.assign(packed_conv3x3_count(cin, cout), 0.f);
+    const int nch = cin / CK, nct = cout / NT;
+    for (int ct = 0; ct < nct; ++ct)
+        for (int ch = 0; ch < nch; ++ch)
+            for (int kl = 0; kl < KCH; ++kl)
+                for (int j = 0; j < NT; ++j) {
+                    int co = ct * NT + j, ci = ch * CK + kl / 9, tap = kl % 9;
+                    out[(((size_t)ct * nch + ch) * KCH + kl) * NT + j] = w[((size_t)co * cin + ci) * 9 + tap];
+                }
+}
+
+// TAG only gives each SuperPoint layer its own kernel symbol (per-layer rows in rocprofv3 --stats)
+template <int CIN, bool POOL, bool RELU, int TAG>
+__global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
+    const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
+    float* __restrict__ out, int H, int W, int COUT) {
+    __shared__ __attribute__((aligned(16))) float lds[CK * PLANE + KCH * NT];
+    float* lds_in = lds;
+    float* lds_w = lds + CK * PLANE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, h = lane >> 5;
+    const int nct = COUT / NT;
+    const int b = blockIdx.z / nct, ct = blockIdx.z % nct;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int co0 = ct * NT;
+
+    f32x16 acc[2][2];
+    {
+        const float b0 = bias[co0 + col], b1 = bias[co0 + 32 + col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][0][r] = b0; acc[1][0][r] = b0; acc[0][1][r] = b1; acc[1][1][r] = b1; }
+    }
+
+    // per-lane A offsets for the 9 k-steps of an 18-kappa period (two input channels)
+    int aoff[9];
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+        const int k0 = 2 * s, k1 = 2 * s + 1;
+        const int o0 = (k0 / 9) * PLANE + ((k0 % 9) / 3) * TWS + (k0 % 9) % 3;
+        const int o1 = (k1 / 9) * PLANE + ((k1 % 9) / 3) * TWS + (k1 % 9) % 3;
+        aoff[s] = (h ? o1 : o0) + (2 * wave) * TWS + col;
+    }
+    const int boff = h * NT + col;
+
+    const float* in_b = in + (size_t)b * H * W * CIN;
+    const float* wp_ct = wp + (size_t)ct * (CIN / CK) * KCH * NT;
+
+    for (int ch = 0; ch < CIN / CK; ++ch) {
+        __syncthreads();
+        // ---- stage input tile: NHWC global -> channel-planar LDS (zero padding materialised)
+        for (int idx = tid; idx < IH * IW * (CK / 4); idx += 256) {
+            const int cq = idx % (CK / 4), pix = idx / (CK / 4);
+            const int py = pix / IW, px = pix % IW;
+            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+                v = *reinterpret_cast<const float4*>(in_b + ((size_t)gy * W + gx) * CIN + ch * CK + cq * 4);
+            float* d = lds_in + (cq * 4) * PLANE + py * TWS + px;
+            d[0] = v.x; d[PLANE] = v.y; d[2 * PLANE] = v.z; d[3 * PLANE] = v.w;
+        }
+        // ---- stage weight chunk (linear 36 KB copy)
+        {
+            const float4* src = reinterpret_cast<const float4*>(wp_ct + (size_t)ch * KCH * NT);
+            float4* dst = reinterpret_cast<float4*>(lds_w);
+#pragma unroll
+            for (int it = 0; it < KCH * NT / 4 / 256; ++it) dst[it * 256 + tid] = src[it * 256 + tid];
+        }
+        __syncthreads();
+        // ---- 72 k-steps x 4 MFMA
+#pragma unroll 1
+        for (int cp = 0; cp < CK / 2; ++cp) {
+            const float* ap = lds_in + cp * 2 * PLANE;
+            const float* bp = lds_w + cp * 18 * NT + boff;
+#pragma unroll
+            for (int s = 0; s < 9; ++s) {
+                const float a0 = ap[aoff[s]], a1 = ap[aoff[s] + TWS];
+                const float b0 = bp[2 * s * NT], b1 = bp[2 * s * NT + 32];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue.  D layout: lane holds channel (lane&31), pixel column (r&3)+8*(r>>2)+4*h
+    if (!POOL) {
+        float* out_b = out + (size_t)b * H * W * COUT;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const int y = y0 + 2 * wave + mb;
+            if (y >= H) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (x >= W) continue;
+                float v0 = acc[mb][0][r], v1 = acc[mb][1][r];
+                if (RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                float* o = out_b + ((size_t)y * W + x) * COUT + co0 + col;
+                o[0] = v0; o[32] = v1;
+            }
+        }
+    } else {
+        const int Ho = H >> 1, Wo = W >> 1;
+        float* out_b = out + (size_t)b * Ho * Wo * COUT;
+        const int yo = (y0 >> 1) + wave;
+        if (yo < Ho) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const int xo = (x0 >> 1) + ((r & 3) >> 1) + 4 * (r >> 2) + 2 * h;
+                if (xo >= Wo) continue;
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    float v = fmaxf(fmaxf(acc[0][nb][r], acc[0][nb][r + 1]), fmaxf(acc[1][nb][r], acc[1][nb][r + 1]));
+                    if (RELU) v = fmaxf(v, 0.f);
+                    out_b[((size_t)yo * Wo + xo) * COUT + co0 + nb * 32 + col] = v;
+                }
+            }
+        }
+    }
+}
+
+#define RFE_CONV_LAUNCH(CIN, POOL, RELU, TAG) \
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, POOL, RELU, TAG>), grid, dim3(256), 0, s, in, wp, bias, out, H, W, cout)
+
+// tag: SuperPoint layer id (L_1B .. L_DA) for the production path, 0 for the generic test hook
+void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin, const float* wp,
+                    const float* bias, int cout, bool relu, bool pool, float* out, int tag) {
+    dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B * (cout / NT));
+    switch (tag) {
+        case L_1B: RFE_CONV_LAUNCH(64, true, true, L_1B); return;
+        case L_2A: RFE_CONV_LAUNCH(64, false, true, L_2A); return;
+        case L_2B: RFE_CONV_LAUNCH(64, true, true, L_2B); return;
+        case L_3A: RFE_CONV_LAUNCH(64, false, true, L_3A); return;
+        case L_3B: RFE_CONV_LAUNCH(128, true, true, L_3B); return;
+        case L_4A: RFE_CONV_LAUNCH(128, false, true, L_4A); return;
+        case L_4B: RFE_CONV_LAUNCH(128, false, true, L_4B); return;
+        case L_PA: RFE_CONV_LAUNCH(128, false, true, L_PA); return;
+        case L_DA: RFE_CONV_LAUNCH(128, false, true, L_DA); return;
+        default: break;
+    }
+    // generic (kernel-level test hook): any Cin in {16,32,64,128}, any relu/pool combination
+#define RFE_CONV_GEN(CIN)                                                    \
+    do {                                                                     \
+        if (pool && relu) RFE_CONV_LAUNCH(CIN, true, true, 0);               \
+        else if (relu) RFE_CONV_LAUNCH(CIN, false, true, 0);                 \
+        else if (pool) RFE_CONV_LAUNCH(CIN, true, false, 0);                 \
+        else RFE_CONV_LAUNCH(CIN, false, false, 0);                          \
+    } while (0)
+    if (cin == 64) RFE_CONV_GEN(64);
+    else if (cin == 128) RFE_CONV_GEN(128);
+    else if (cin == 16) RFE_CONV_GEN(16);
+    else if (cin == 32) RFE_CONV_GEN(32);
+}
+
+// ------------------------------------------------------------------------------------------
+// conv1a: u8 image -> (x * 1/255) -> conv3x3 1->64 + bias + ReLU, NHWC out.  HBM bound (writes
+// 256 B per pixel).  16 lanes per pixel, 4 output channels per lane: a wave stores 1 KB contiguous.
+// NormalizeImage (reference src/Matchers/transform.cpp:11) is fused here.
+__global__ __launch_bounds__(256) void conv1a_u8_kernel(const uint8_t* __restrict__ img, int stride,
+                                                        int H, int W, const float* __restrict__ w9x64,
+                                                        const float* __restrict__ bias,
+                                                        float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int cg = threadIdx.x & 15;  // channel group: channels 4cg..4cg+3
+    float wr[9][4], br[4];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wr[k][e] = w9x64[k * 64 + cg * 4 + e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) br[e] = bias[cg * 4 + e];
+    const uint8_t* im = img + (size_t)b * stride * H;
+    float* ob = out + (size_t)b * H * W * 64;
+    const int npix = H * W;
+    for (int p = blockIdx.x * 16 + (threadIdx.x >> 4); p < npix; p += gridDim.x * 16) {
+        const int y = p / W, x = p % W;
+        float a[4] = {br[0], br[1], br[2], br[3]};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int gy = y + ky - 1, gx = x + kx - 1;
+                float v = 0.f;
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = (float)im[(size_t)gy * stride + gx] * 0.003921568859368563f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = fmaf(v, wr[ky * 3 + kx][e], a[e]);
+            }
+        float4 o = make_float4(fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(a[2], 0.f), fmaxf(a[3], 0.f));
+        *reinterpret_cast<float4*>(ob + (size_t)p * 64 + cg * 4) = o;
+    }
+}
+
+void launch_conv1a_u8(hipStream_t s, const uint8_t* img, int stride, int B, int H, int W,
+                      const float* w9x64, const float* bias, float* out) {
+    int blocks = (H * W + 15) / 16;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv1a_u8_kernel, dim3(blocks, B), dim3(256), 0, s, img, stride, H, W, w9x64, bias, out);
+}
+
+}  // namespace rfe

@@ -1,0 +1,347 @@
+// sp_post.hip -- the non-GEMM tail of SuperPoint: softmax(65)+depth-to-space, simple_nms(r=4),
+// border/threshold/top-k selection, descriptor-map L2 normalisation and bilinear descriptor sampling.
+// In the reference all of this is inside superpoint.onnx (Ort::Session::Run,
+// src/Extractors/superpoint_onnx.cc:133-136); outputs follow the tensor contract read by
+// Extractor_PostProcess (superpoint_onnx.cc:169-181): keypoints (x,y), scores, descriptors[.,256].
+// All kernels here are HBM/latency bound (a few MB per frame); arithmetic orders are the canonical
+// ones of oracle/rfe_oracle.c so that scores / keypoints / descriptors are bit-exact.
+#include "rfe_internal.h"
+
+namespace rfe {
+
+// ---------------------------------------------------------------- canonical expf (== rfo_expf)
+__device__ __forceinline__ float rfe_expf(float x) {
+    x = fmaxf(x, -87.0f);
+    x = fminf(x, 88.0f);
+    const float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500E-4f;
+    p = fmaf(p, r, 1.3981999507E-3f);
+    p = fmaf(p, r, 8.3334519073E-3f);
+    p = fmaf(p, r, 4.1665795894E-2f);
+    p = fmaf(p, r, 1.6666665459E-1f);
+    p = fmaf(p, r, 5.0000001201E-1f);
+    const float r2 = r * r;
+    const float y = fmaf(p, r2, r) + 1.0f;
+    return y * __uint_as_float((uint32_t)((int)n + 127) << 23);
+}
+
+// one thread per 8x8 cell: 65-way softmax in index order, drop dustbin, scatter to the H x W map
+__global__ __launch_bounds__(256) void softmax65_d2s_kernel(const float* __restrict__ logits, int ld,
+                                                            int cells_total, int Hc, int Wc,
+                                                            float* __restrict__ score) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= cells_total) return;
+    const int b = gid / (Hc * Wc), cell = gid % (Hc * Wc);
+    const float* l = logits + (size_t)gid * ld;
+    float e[65];
+    float m = l[0];
+#pragma unroll
+    for (int c = 0; c < 65; ++c) { e[c] = l[c]; m = fmaxf(m, e[c]); }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 65; ++c) { e[c] = rfe_expf(e[c] - m); s = s + e[c]; }
+    const int W = Wc * 8;
+    const int cy = cell / Wc, cx = cell % Wc;
+    float* o = score + (size_t)b * Hc * 8 * W + (size_t)(cy * 8) * W + cx * 8;
+#pragma unroll
+    for (int dy = 0; dy < 8; ++dy) {
+        float4 v0 = make_float4(e[dy * 8] / s, e[dy * 8 + 1] / s, e[dy * 8 + 2] / s, e[dy * 8 + 3] / s);
+        float4 v1 = make_float4(e[dy * 8 + 4] / s, e[dy * 8 + 5] / s, e[dy * 8 + 6] / s, e[dy * 8 + 7] / s);
+        *reinterpret_cast<float4*>(o + (size_t)dy * W) = v0;
+        *reinterpret_cast<float4*>(o + (size_t)dy * W + 4) = v1;
+    }
+}
+
+void launch_softmax65_d2s(hipStream_t s, const float* logits, int ld, int B, int Hc, int Wc, float* score) {
+    const int total = B * Hc * Wc;
+    hipLaunchKernelGGL(softmax65_d2s_kernel, dim3((total + 255) / 256), dim3(256), 0, s, logits, ld, total, Hc, Wc, score);
+}
+
+// ---------------------------------------------------------------- simple_nms (radius 4)
+// published recurrence (SuperPoint / LightGlue):  max_mask = s == mp(s);
+//   2x { supp = mp(max_mask) > 0; ss = supp ? 0 : s; new = ss == mp(ss); max_mask |= new & ~supp }
+//   out = max_mask ? s : 0   then the 4-px border is set to -1.
+constexpr int NR = 4, NTH = 32, NTW = 64, NIH = NTH + 2 * NR, NIW = NTW + 2 * NR;
+
+template <typename LoadFn>
+__device__ __forceinline__ void tile_maxpool9(LoadFn load, int y0, int x0, int H, int W, float* t0, float* t1) {
+    for (int idx = threadIdx.x; idx < NIH * NIW; idx += 256) {
+        const int py = idx / NIW, px = idx % NIW;
+        const int gy = y0 - NR + py, gx = x0 - NR + px;
+        t0[idx] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? load(gy, gx) : -INFINITY;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < NIH * NTW; idx += 256) {
+        const int py = idx / NTW, px = idx % NTW;
+        const float* r = t0 + py * NIW + px;
+        float m = r[0];
+#pragma unroll
+        for (int d = 1; d <= 2 * NR; ++d) m = fmaxf(m, r[d]);
+        t1[idx] = m;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ float tile_colmax(const float* t1, int py, int px) {
+    const float* c = t1 + py * NTW + px;
+    float m = c[0];
+#pragma unroll
+    for (int d = 1; d <= 2 * NR; ++d) m = fmaxf(m, c[d * NTW]);
+    return m;
+}
+
+// MODE 0: mask = (s == mp(s))
+// MODE 1: supp = mp(mask) > 0 ; ss = supp ? 0 : s
+// MODE 2: mask |= (ss == mp(ss)) & ~supp ; FINAL: out = mask ? s : 0, border -> -1
+template <int MODE, bool FINAL>
+__global__ __launch_bounds__(256) void nms_pass_kernel(const float* __restrict__ s, float* __restrict__ ss,
+                                                       uint8_t* __restrict__ mask, uint8_t* __restrict__ supp,
+                                                       float* __restrict__ out, int H, int W, int border) {
+    __shared__ float t0[NIH * NIW];
+    __shared__ float t1[NIH * NTW];
+    const size_t fo = (size_t)blockIdx.z * H * W;
+    const int y0 = blockIdx.y * NTH, x0 = blockIdx.x * NTW;
+    if (MODE == 0) tile_maxpool9([&](int y, int x) { return s[fo + (size_t)y * W + x]; }, y0, x0, H, W, t0, t1);
+    if (MODE == 1) tile_maxpool9([&](int y, int x) { return mask[fo + (size_t)y * W + x] ? 1.f : 0.f; }, y0, x0, H, W, t0, t1);
+    if (MODE == 2) tile_maxpool9([&](int y, int x) { return ss[fo + (size_t)y * W + x]; }, y0, x0, H, W, t0, t1);
+    for (int idx = threadIdx.x; idx < NTH * NTW; idx += 256) {
+        const int py = idx / NTW, px = idx % NTW;
+        const int y = y0 + py, x = x0 + px;
+        if (y >= H || x >= W) continue;
+        const float m = tile_colmax(t1, py, px);
+        const size_t o = fo + (size_t)y * W + x;
+        if (MODE == 0) {
+            mask[o] = (s[o] == m) ? 1 : 0;
+        } else if (MODE == 1) {
+            const bool sp = m > 0.f;
+            supp[o] = sp ? 1 : 0;
+            ss[o] = sp ? 0.f : s[o];
+        } else {
+            const float c = t0[(py + NR) * NIW + px + NR];  // ss at this pixel
+            bool mk = mask[o] != 0;
+            if (c == m && !supp[o]) mk = true;
+            if (FINAL) {
+                float v = mk ? s[o] : 0.f;
+                if (y < border || y >= H - border || x < border || x >= W - border) v = -1.f;
+                out[o] = v;
+            } else {
+                mask[o] = mk ? 1 : 0;
+            }
+        }
+    }
+}
+
+void launch_nms(hipStream_t st, const float* score, int B, int H, int W, int border, float* tmp_ss,
+                uint8_t* tmp_mask, uint8_t* tmp_supp, float* out) {
+    dim3 grid((W + NTW - 1) / NTW, (H + NTH - 1) / NTH, B), blk(256);
+    hipLaunchKernelGGL((nms_pass_kernel<0, false>), grid, blk, 0, st, score, tmp_ss, tmp_mask, tmp_supp, out, H, W, border);
+    hipLaunchKernelGGL((nms_pass_kernel<1, false>), grid, blk, 0, st, score, tmp_ss, tmp_mask, tmp_supp, out, H, W, border);
+    hipLaunchKernelGGL((nms_pass_kernel<2, false>), grid, blk, 0, st, score, tmp_ss, tmp_mask, tmp_supp, out, H, W, border);
+    hipLaunchKernelGGL((nms_pass_kernel<1, false>), grid, blk, 0, st, score, tmp_ss, tmp_mask, tmp_supp, out, H, W, border);
+    hipLaunchKernelGGL((nms_pass_kernel<2, true>), grid, blk, 0, st, score, tmp_ss, tmp_mask, tmp_supp, out, H, W, border);
+}
+
+// ---------------------------------------------------------------- threshold + top-k selection
+// One 1024-thread workgroup per frame.  (1) ordered (row-major) compaction of pixels with
+// nms > thr; (2) if more than Kmax candidates: 4-pass radix select on the score bits for the
+// Kmax-th largest score, ties resolved by ascending pixel index (candidate order), then a bitonic
+// sort of the selected 64-bit keys (score bits << 32 | ~index) in LDS -> score-descending output.
+constexpr int SEL_T = 1024;
+
+__device__ __forceinline__ int block_excl_scan_flag(bool flag, int* wave_tot /*[16]*/, int& total) {
+    const unsigned long long bal = __ballot(flag);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane_prefix = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wv] = __popcll(bal);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SEL_T / 64; ++w) { const int c = wave_tot[w]; if (w < wv) off += c; tot += c; }
+    __syncthreads();
+    total = tot;
+    return off + lane_prefix;
+}
+
+__global__ __launch_bounds__(SEL_T) void select_kernel(const float* __restrict__ nms, int H, int W, int Kmax,
+                                                       int P2, float thr, float* __restrict__ cand_score,
+                                                       int32_t* __restrict__ cand_idx, int32_t* __restrict__ n_out,
+                                                       int32_t* __restrict__ kxy, float* __restrict__ score) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);  // [P2]
+    __shared__ int wave_tot[SEL_T / 64];
+    __shared__ int hist[256];
+    __shared__ unsigned int sh_prefix;
+    __shared__ int sh_remaining;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int HW = H * W;
+    const float* s = nms + (size_t)b * HW;
+    float* cs = cand_score + (size_t)b * HW;
+    int32_t* ci = cand_idx + (size_t)b * HW;
+
+    int count = 0;
+    for (int base = 0; base < HW; base += SEL_T) {
+        const int p = base + tid;
+        const float v = p < HW ? s[p] : -1.f;
+        const bool f = v > thr;
+        int tot;
+        const int pos = count + block_excl_scan_flag(f, wave_tot, tot);
+        if (f) { cs[pos] = v; ci[pos] = p; }
+        count += tot;
+    }
+    __syncthreads();  // candidate list visible to the whole workgroup (global writes by this WG)
+    __threadfence_block();
+
+    int32_t* okxy = kxy + (size_t)b * Kmax * 2;
+    float* osc = score + (size_t)b * Kmax;
+    if (count <= Kmax) {
+        if (tid == 0) n_out[b] = count;
+        for (int k = tid; k < Kmax; k += SEL_T) {
+            if (k < count) {
+                const int idx = ci[k];
+                okxy[2 * k] = idx % W; okxy[2 * k + 1] = idx / W; osc[k] = cs[k];
+            } else {
+                okxy[2 * k] = 0; okxy[2 * k + 1] = 0; osc[k] = 0.f;
+            }
+        }
+        return;
+    }
+    // ---- radix select: Kmax-th largest score (scores are positive floats: bit pattern is monotonic)
+    if (tid == 0) { sh_prefix = 0u; sh_remaining = Kmax; }
+    __syncthreads();
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const unsigned int prefix = sh_prefix;
+        const unsigned int pmask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (int k = tid; k < count; k += SEL_T) {
+            const unsigned int bits = __float_as_uint(cs[k]);
+            if ((bits & pmask) == prefix) atomicAdd(&hist[(bits >> shift) & 255], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int rem = sh_remaining, bin = 255;
+            for (; bin > 0; --bin) { if (hist[bin] >= rem) break; rem -= hist[bin]; }
+            sh_prefix = prefix | ((unsigned int)bin << shift);
+            sh_remaining = rem;
+        }
+        __syncthreads();
+    }
+    const unsigned int T = sh_prefix;
+    const int r_eq = sh_remaining;  // how many candidates with score == T are taken (lowest index first)
+    for (int k = tid; k < P2; k += SEL_T) keys[k] = 0ull;
+    __syncthreads();
+    int eq_seen = 0, sel_seen = 0;
+    for (int base = 0; base < count; base += SEL_T) {
+        const int k = base + tid;
+        const unsigned int bits = k < count ? __float_as_uint(cs[k]) : 0u;
+        const bool gt = k < count && bits > T;
+        const bool eq = k < count && bits == T;
+        int tot_eq;
+        const int eq_rank = eq_seen + block_excl_scan_flag(eq, wave_tot, tot_eq);
+        const bool sel = gt || (eq && eq_rank < r_eq);
+        int tot_sel;
+        const int pos = sel_seen + block_excl_scan_flag(sel, wave_tot, tot_sel);
+        if (sel) keys[pos] = ((unsigned long long)bits << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)ci[k]);
+        eq_seen += tot_eq; sel_seen += tot_sel;
+    }
+    __syncthreads();
+    // ---- bitonic sort, descending
+    for (int kk = 2; kk <= P2; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < P2; t += SEL_T) {
+                const int ixj = t ^ j;
+                if (ixj > t) {
+                    const unsigned long long a = keys[t], c = keys[ixj];
+                    const bool desc = (t & kk) == 0;
+                    if (desc ? (a < c) : (a > c)) { keys[t] = c; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    if (tid == 0) n_out[b] = Kmax;
+    for (int k = tid; k < Kmax; k += SEL_T) {
+        const unsigned long long key = keys[k];
+        const int idx = (int)(0xFFFFFFFFu - (unsigned int)(key & 0xFFFFFFFFull));
+        okxy[2 * k] = idx % W; okxy[2 * k + 1] = idx / W;
+        osc[k] = __uint_as_float((unsigned int)(key >> 32));
+    }
+}
+
+void launch_select(hipStream_t s, const float* nms, int B, int H, int W, int Kmax, float thr, float* cand_score,
+                   int32_t* cand_idx, int32_t* n_out, int32_t* kxy, float* score) {
+    int P2 = 1;
+    while (P2 < Kmax) P2 <<= 1;
+    hipLaunchKernelGGL(select_kernel, dim3(B), dim3(SEL_T), (size_t)P2 * 8, s, nms, H, W, Kmax, P2, thr,
+                       cand_score, cand_idx, n_out, kxy, score);
+}
+
+// ---------------------------------------------------------------- 256-d L2 normalisation
+// canonical tree (== rfo_sumsq256): lane l owns channels 4l..4l+3, then xor butterfly 32..1
+__device__ __forceinline__ float wave_sumsq256(float4 v) {
+    float p = v.x * v.x;
+    p = fmaf(v.y, v.y, p);
+    p = fmaf(v.z, v.z, p);
+    p = fmaf(v.w, v.w, p);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) p = p + __shfl_xor(p, off);
+    return p;
+}
+
+__global__ __launch_bounds__(256) void descmap_norm_kernel(float* __restrict__ dmap, int64_t cells) {
+    const int64_t cell = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (cell >= cells) return;
+    const int lane = threadIdx.x & 63;
+    float4* p = reinterpret_cast<float4*>(dmap + cell * 256) + lane;
+    float4 v = *p;
+    const float d = fmaxf(sqrtf(wave_sumsq256(v)), 1e-12f);
+    v.x = v.x / d; v.y = v.y / d; v.z = v.z / d; v.w = v.w / d;
+    *p = v;
+}
+void launch_descmap_norm(hipStream_t s, float* dmap, int64_t cells) {
+    hipLaunchKernelGGL(descmap_norm_kernel, dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, s, dmap, cells);
+}
+
+// one wave per keypoint: bilinear grid_sample(align_corners=True, zero padding) of the normalised
+// descriptor map at ((x-3.5)/(W-4.5), (y-3.5)/(H-4.5)), then L2 normalise.
+__global__ __launch_bounds__(256) void desc_sample_kernel(const float* __restrict__ dmap, int Hc, int Wc, int H, int W,
+                                                          const int32_t* __restrict__ n, const int32_t* __restrict__ kxy,
+                                                          int Kmax, float* __restrict__ desc) {
+    const int b = blockIdx.y;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= Kmax) return;
+    const int lane = threadIdx.x & 63;
+    float4* o = reinterpret_cast<float4*>(desc + ((size_t)b * Kmax + k) * 256) + lane;
+    if (k >= n[b]) { *o = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+    const int x = kxy[((size_t)b * Kmax + k) * 2], y = kxy[((size_t)b * Kmax + k) * 2 + 1];
+    const float gx = (((float)x - 3.5f) / ((float)W - 4.5f)) * 2.0f - 1.0f;
+    const float gy = (((float)y - 3.5f) / ((float)H - 4.5f)) * 2.0f - 1.0f;
+    const float ix = ((gx + 1.0f) * 0.5f) * (float)(Wc - 1);
+    const float iy = ((gy + 1.0f) * 0.5f) * (float)(Hc - 1);
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = ix - fx0, wy1 = iy - fy0, wx0 = (fx0 + 1.0f) - ix, wy0 = (fy0 + 1.0f) - iy;
+    const float wnw = wx0 * wy0, wne = wx1 * wy0, wsw = wx0 * wy1, wse = wx1 * wy1;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* mb = dmap + (size_t)b * Hc * Wc * 256;
+    const bool vx0 = x0 >= 0 && x0 < Wc, vx1 = x1 >= 0 && x1 < Wc, vy0 = y0 >= 0 && y0 < Hc, vy1 = y1 >= 0 && y1 < Hc;
+    const float4 nw = (vx0 && vy0) ? reinterpret_cast<const float4*>(mb + ((size_t)y0 * Wc + x0) * 256)[lane] : z;
+    const float4 ne = (vx1 && vy0) ? reinterpret_cast<const float4*>(mb + ((size_t)y0 * Wc + x1) * 256)[lane] : z;
+    const float4 sw = (vx0 && vy1) ? reinterpret_cast<const float4*>(mb + ((size_t)y1 * Wc + x0) * 256)[lane] : z;
+    const float4 se = (vx1 && vy1) ? reinterpret_cast<const float4*>(mb + ((size_t)y1 * Wc + x1) * 256)[lane] : z;
+    float4 v;
+    v.x = fmaf(se.x, wse, fmaf(sw.x, wsw, fmaf(ne.x, wne, nw.x * wnw)));
+    v.y = fmaf(se.y, wse, fmaf(sw.y, wsw, fmaf(ne.y, wne, nw.y * wnw)));
+    v.z = fmaf(se.z, wse, fmaf(sw.z, wsw, fmaf(ne.z, wne, nw.z * wnw)));
+    v.w = fmaf(se.w, wse, fmaf(sw.w, wsw, fmaf(ne.w, wne, nw.w * wnw)));
+    const float d = fmaxf(sqrtf(wave_sumsq256(v)), 1e-12f);
+    v.x = v.x / d; v.y = v.y / d; v.z = v.z / d; v.w = v.w / d;
+    *o = v;
+}
+void launch_desc_sample(hipStream_t s, const float* dmap, int B, int Hc, int Wc, int H, int W, const int32_t* n,
+                        const int32_t* kxy, int Kmax, float* desc) {
+    hipLaunchKernelGGL(desc_sample_kernel, dim3((Kmax + 3) / 4, B), dim3(256), 0, s, dmap, Hc, Wc, H, W, n, kxy, Kmax, desc);
+}
+
+}  // namespace rfe
