@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the SuperPoint + LightGlue front end on synthetic 640x480 grayscale frames.
+
+Workload (BASELINE.json configs[3], per GPU): 33 device-resident u8 frames are extracted and frame i is
+matched with frame i+1 (32 pairs) through rfe_extract_match_stream_dev; 32 frames are counted per
+GPU per step (the 33rd is the one-frame overlap that makes the ranks independent).
+Kmax = 1024, detection threshold 0.0005, match filter 0.1, seeded synthetic weights.
+Multi-GPU: one process per GPU (torch.distributed / RCCL), frames sharded, no data-path collective
+except the trivial gather of the compact results (counts, keypoints, matches) to rank 0.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
+timed with HIP events on the library's stream inside the timed region) and `cpu_baseline`
+(the CPU oracle, rank 0, N=1 only, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W, KMAX = 480, 640, 1024
+FRAMES_PER_GPU = 32
+PEAK_F32_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
+PEAK_HBM_GBS = 8000.0
+
+# SuperPoint 3x3 layers: (stage, Cin, Cout, downscale)
+SP_CONV = {"conv1b": (64, 64, 1), "conv2a": (64, 64, 2), "conv2b": (64, 64, 2), "conv3a": (64, 128, 4),
+           "conv3b": (128, 128, 4), "conv4a": (128, 128, 8), "conv4b": (128, 128, 8), "convPa": (128, 256, 8),
+           "convDa": (128, 256, 8)}
+
+
+def stage_flops(name, B, lens):
+    """ALGORITHMIC FLOPs of one launch of a profiled stage (DESIGN.md 'Work per unit')."""
+    P = B - 1
+    rows = 2 * P * KMAX
+    if name in SP_CONV:
+        cin, cout, ds = SP_CONV[name]
+        return 2.0 * 9 * cin * cout * (H // ds) * (W // ds) * B
+    if name == "convPb":
+        return 2.0 * 256 * 65 * (H // 8) * (W // 8) * B
+    if name == "convDb":
+        return 2.0 * 256 * 256 * (H // 8) * (W // 8) * B
+    if name == "lg_qkv":
+        return 2.0 * rows * 256 * 768
+    if name == "lg_proj":
+        return 2.0 * rows * 256 * 256
+    if name == "lg_ffn1":
+        return 2.0 * rows * 512 * 512
+    if name == "lg_ffn2":
+        return 2.0 * rows * 512 * 256
+    if name == "lg_sim":
+        return 2.0 * 256 * float(np.sum(lens[:-1].astype(np.float64) * lens[1:]))
+    if name == "lg_attention":
+        # average of self (n_i^2) and cross (n_i * n_j) launches: 4 heads * (QK^T + PV) * 64 dims
+        a, b = lens[:-1].astype(np.float64), lens[1:].astype(np.float64)
+        self_f = 4 * 4.0 * 64 * float(np.sum(a * a) + np.sum(b * b))
+        cross_f = 4 * 4.0 * 64 * float(2 * np.sum(a * b))
+        return 0.5 * (self_f + cross_f)
+    return None
+
+
+def cpu_baseline(frames, wsp, wlg):
+    """The CPU oracle (a port, not the reference's ONNXRuntime path -- that cannot run here: no
+    onnxruntime, no .onnx blobs) on a bounded sample: 4 frames extracted + 3 consecutive pairs matched."""
+    from oracle import oracle as O
+    O.build()
+    nf = 4
+    t0 = time.perf_counter()
+    res = [O.superpoint(wsp, frames[i], kmax=KMAX) for i in range(nf)]
+    for i in range(nf - 1):
+        a, b = res[i], res[i + 1]
+        O.lightglue(wlg, O.normalize_keypoints(a["kxy"][:a["n"]].astype(np.float32), H, W),
+                    O.normalize_keypoints(b["kxy"][:b["n"]].astype(np.float32), H, W), a["desc"][:a["n"]], b["desc"][:b["n"]])
+    dt = time.perf_counter() - t0
+    return {"value": round((nf - 1) / dt, 4), "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{nf} frames 640x480 extracted + {nf - 1} consecutive pairs matched (K<=1024) by oracle/rfe_oracle.c, "
+                      f"OpenMP on {os.cpu_count()} host threads, {dt:.1f} s; {nf - 1} frames counted"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather-desc", action="store_true", help="also gather the 256-d descriptors to rank 0")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from rover_slam_amd import capi, weights as Wt, synth
+    ctx = capi.Context(local_rank)
+    wsp, wlg = Wt.make_superpoint(seed=7), Wt.make_lightglue(seed=11)
+    ctx.set_weights(capi.KIND_SUPERPOINT, wsp)
+    ctx.set_weights(capi.KIND_LIGHTGLUE, wlg)
+    stream = torch.cuda.Stream(dev)          # library kernels and the RCCL gather share this stream
+    torch.cuda.set_stream(stream)
+    ctx.set_stream(stream.cuda_stream)
+
+    B = FRAMES_PER_GPU + 1
+    # each rank owns frames [32r, 32r+32]: one frame of overlap, no inter-GPU dependency
+    frames_np, _ = synth.make_frames(B, H, W, seed=20240314 + 1000 * rank)
+    frames = torch.from_numpy(frames_np).to(dev)
+    n = torch.zeros(B, dtype=torch.int32, device=dev)
+    kxy = torch.zeros(B, KMAX, 2, dtype=torch.int32, device=dev)
+    score = torch.zeros(B, KMAX, dtype=torch.float32, device=dev)
+    desc = torch.zeros(B, KMAX, 256, dtype=torch.float32, device=dev)
+    S = torch.zeros(B - 1, dtype=torch.int32, device=dev)
+    pairs = torch.zeros(B - 1, KMAX, 2, dtype=torch.int32, device=dev)
+    ms = torch.zeros(B - 1, KMAX, dtype=torch.float32, device=dev)
+    gather_bufs = None
+    if world > 1:
+        send = [n, kxy, S, pairs] + ([desc] if args.gather_desc else [])
+        gather_bufs = [[torch.empty_like(t) for _ in range(world)] if rank == 0 else None for t in send]
+
+    def step():
+        ctx._chk(capi.lib.rfe_extract_match_stream_dev(
+            ctx.h, frames.data_ptr(), H, W, W, B, KMAX, 0.0005, 0.1, n.data_ptr(), kxy.data_ptr(), score.data_ptr(),
+            desc.data_ptr(), S.data_ptr(), pairs.data_ptr(), ms.data_ptr()))
+        if world > 1:   # the trivial gather over RCCL/xGMI (compact results only unless --gather-desc)
+            for t, g in zip(send, gather_bufs):
+                dist.gather(t, g, dst=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.profile(True)
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile(False)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        lens = n.cpu().numpy()
+        total_frames = FRAMES_PER_GPU * world * args.steps
+        value = total_frames / dt
+        # dominant kernel = the profiled stage with the largest accumulated time
+        dom = max(prof.items(), key=lambda kv: kv[1][0])
+        dom_name, (dom_ms, dom_calls) = dom
+        fl = stage_flops(dom_name, B, lens)
+        avg_ms = dom_ms / max(dom_calls, 1)
+        achieved = fl / (avg_ms * 1e-3) / 1e12 if fl else None
+        stages = {}
+        for k, (msv, calls) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
+            f = stage_flops(k, B, lens)
+            stages[k] = {"ms_per_step": round(msv / args.steps, 4), "launches_per_step": calls // args.steps,
+                         "tflops": round(f / (msv / calls * 1e-3) / 1e12, 2) if f else None}
+        out = {
+            "metric": "frames/s SuperPoint+LightGlue 640x480", "value": round(value, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[3] per GPU: 33 synthetic 640x480 u8 frames resident in HBM, SuperPoint extract "
+                                   "(Kmax=1024, thr=0.0005) + LightGlue match of 32 consecutive pairs (9 layers, filter 0.1); "
+                                   "32 frames counted per GPU per step; seeded synthetic weights",
+                       "frames_per_gpu": FRAMES_PER_GPU, "kmax": KMAX, "mean_keypoints": float(lens.mean()),
+                       "sharding": f"frames sharded over {world} GPU(s), 1 overlap frame per rank"
+                                   + ("; gather of counts/keypoints/matches to rank 0 over RCCL" if world > 1 else "")},
+            "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2) if achieved else None,
+                         "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_TFLOPS, 4) if achieved else None,
+                         "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": dom_calls,
+                         "flops_per_launch": fl},
+            "stages": stages,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames_np, wsp, wlg)
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

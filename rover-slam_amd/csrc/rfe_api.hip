@@ -34,20 +34,20 @@ ProfScope::ProfScope(rfe_ctx* ctx, const char* name) : c(ctx), idx(-1) {
     if (!c->prof) return;
     for (size_t i = 0; i < c->stages.size(); ++i) if (c->stages[i].name == name) idx = (int)i;
     if (idx < 0) { c->stages.push_back(Stage{name, 0, 0}); idx = (int)c->stages.size() - 1; }
-    auto get = [&]() { hipEvent_t e; if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); } else hipEventCreate(&e); return e; };
+    auto get = [&]() { hipEvent_t e; if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
     e0 = get(); e1 = get();
-    hipEventRecord(e0, c->stream);
+    (void)hipEventRecord(e0, c->stream);
 }
 ProfScope::~ProfScope() {
     if (idx < 0) return;
-    hipEventRecord(e1, c->stream);
+    (void)hipEventRecord(e1, c->stream);
     c->pending.push_back({idx, {e0, e1}});
 }
 void prof_collect(rfe_ctx* c) {
     for (auto& p : c->pending) {
         float ms = 0.f;
-        hipEventSynchronize(p.second.second);
-        hipEventElapsedTime(&ms, p.second.first, p.second.second);
+        (void)hipEventSynchronize(p.second.second);
+        (void)hipEventElapsedTime(&ms, p.second.first, p.second.second);
         c->stages[p.first].ms += ms; c->stages[p.first].calls += 1;
         c->ev_pool.push_back(p.second.first); c->ev_pool.push_back(p.second.second);
     }
@@ -102,16 +102,16 @@ extern "C" int rfe_init(int device, rfe_ctx** out) {
 
 extern "C" void rfe_destroy(rfe_ctx* c) {
     if (!c) return;
-    hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
-    for (auto e : c->ev_pool) hipEventDestroy(e);
-    auto fr = [](void* p) { if (p) hipFree(p); };
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    auto fr = [](void* p) { if (p) (void)hipFree(p); };
     fr(c->sp.conv1a_w);
     for (int l = 0; l < 12; ++l) { fr(c->sp.packed[l]); fr(c->sp.bias[l]); }
     fr(c->lg.blob);
     fr(c->ws_sp); fr(c->ws_lg); fr(c->ws_io); fr(c->ws_tmp);
-    hipStreamDestroy(c->own_stream);
+    (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
 
@@ -323,9 +323,8 @@ int sp_forward_maps(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, in
     { ProfScope p(c, "conv4b"); launch_conv3x3(s, b.a4, B, Hc, Wc, 128, w.packed[L_4B], w.bias[L_4B], 128, true, false, b.f4, L_4B); }
     { ProfScope p(c, "convPa"); launch_conv3x3(s, b.f4, B, Hc, Wc, 128, w.packed[L_PA], w.bias[L_PA], 256, true, false, b.pa, L_PA); }
     { ProfScope p(c, "convDa"); launch_conv3x3(s, b.f4, B, Hc, Wc, 128, w.packed[L_DA], w.bias[L_DA], 256, true, false, b.da, L_DA); }
-    { ProfScope p(c, "head_gemm");
-      launch_gemm_nt(s, gemm_plain(b.pa, 256, w.packed[L_PB], 256, w.bias[L_PB], b.logits, 65, cells, 65, 256));
-      launch_gemm_nt(s, gemm_plain(b.da, 256, w.packed[L_DB], 256, w.bias[L_DB], b.dmap, 256, cells, 256, 256)); }
+    { ProfScope p(c, "convPb"); launch_gemm_nt(s, gemm_plain(b.pa, 256, w.packed[L_PB], 256, w.bias[L_PB], b.logits, 65, cells, 65, 256)); }
+    { ProfScope p(c, "convDb"); launch_gemm_nt(s, gemm_plain(b.da, 256, w.packed[L_DB], 256, w.bias[L_DB], b.dmap, 256, cells, 256, 256)); }
     { ProfScope p(c, "sp_post");
       launch_softmax65_d2s(s, b.logits, 65, B, Hc, Wc, b.smap);
       launch_nms(s, b.smap, B, H, W, 4, b.ss, b.mask, b.supp, b.nmap);
@@ -418,12 +417,12 @@ void lg_carve(void* ws, int P, int L, LgBuffers& b) {
 void lg_ffn(rfe_ctx* c, LgBuffers& b, int rows, const float* w1, const float* b1, const float* g, const float* be,
             const float* w2, const float* b2) {
     hipStream_t s = c->stream;
-    { ProfScope p(c, "lg_gemm");
+    { ProfScope p(c, "lg_ffn1");
       GemmArgs a = gemm_plain(b.x, 256, w1, 512, b1, b.h, 512, rows, 512, 512);
       a.A2 = b.msg; a.lda2 = 256; a.K1 = 256;
       launch_gemm_nt(s, a); }
     { ProfScope p(c, "lg_ln_gelu"); launch_lg_ln_gelu(s, b.h, g, be, rows); }
-    { ProfScope p(c, "lg_gemm");
+    { ProfScope p(c, "lg_ffn2");
       GemmArgs a = gemm_plain(b.h, 512, w2, 512, b2, b.x, 256, rows, 256, 512);
       a.R = b.x; a.ldr = 256;
       launch_gemm_nt(s, a); }
@@ -439,24 +438,24 @@ int lg_forward(rfe_ctx* c, LgBuffers& b, int P, int L, float thr, int cap, int32
     for (int l = 0; l < LG_LAYERS; ++l) {
         const LgLayerDev& Lw = W.L[l];
         // ---- self block
-        { ProfScope p(c, "lg_gemm"); launch_gemm_nt(s, gemm_plain(b.x, 256, Lw.wqkv, 256, Lw.bqkv, b.qkv, 768, rows, 768, 256)); }
+        { ProfScope p(c, "lg_qkv"); launch_gemm_nt(s, gemm_plain(b.x, 256, Lw.wqkv, 256, Lw.bqkv, b.qkv, 768, rows, 768, 256)); }
         { ProfScope p(c, "lg_misc"); launch_lg_rope_split(s, b.qkv, b.cs, b.sn, rows, b.q, b.k, b.v); }
         { ProfScope p(c, "lg_attention"); launch_lg_attention(s, b.q, b.k, b.v, b.ctx, nseq, L, L, b.lens, b.lens, nullptr); }
-        { ProfScope p(c, "lg_gemm"); launch_gemm_nt(s, gemm_plain(b.ctx, 256, Lw.wo, 256, Lw.bo, b.msg, 256, rows, 256, 256)); }
+        { ProfScope p(c, "lg_proj"); launch_gemm_nt(s, gemm_plain(b.ctx, 256, Lw.wo, 256, Lw.bo, b.msg, 256, rows, 256, 256)); }
         lg_ffn(c, b, rows, Lw.w1, Lw.b1, Lw.lng, Lw.lnb, Lw.w2, Lw.b2);
         // ---- cross block
-        { ProfScope p(c, "lg_gemm");
-          launch_gemm_nt(s, gemm_plain(b.x, 256, Lw.cwqk, 256, Lw.cbqk, b.q, 256, rows, 256, 256));
-          launch_gemm_nt(s, gemm_plain(b.x, 256, Lw.cwv, 256, Lw.cbv, b.v, 256, rows, 256, 256)); }
+        { ProfScope p(c, "lg_proj"); launch_gemm_nt(s, gemm_plain(b.x, 256, Lw.cwqk, 256, Lw.cbqk, b.q, 256, rows, 256, 256)); }
+        { ProfScope p(c, "lg_proj"); launch_gemm_nt(s, gemm_plain(b.x, 256, Lw.cwv, 256, Lw.cbv, b.v, 256, rows, 256, 256)); }
         { ProfScope p(c, "lg_attention"); launch_lg_attention(s, b.q, b.q, b.v, b.ctx, nseq, L, L, b.lens, b.lens, b.kvmap); }
-        { ProfScope p(c, "lg_gemm"); launch_gemm_nt(s, gemm_plain(b.ctx, 256, Lw.cwo, 256, Lw.cbo, b.msg, 256, rows, 256, 256)); }
+        { ProfScope p(c, "lg_proj"); launch_gemm_nt(s, gemm_plain(b.ctx, 256, Lw.cwo, 256, Lw.cbo, b.msg, 256, rows, 256, 256)); }
         lg_ffn(c, b, rows, Lw.cw1, Lw.cb1, Lw.clng, Lw.clnb, Lw.cw2, Lw.cb2);
     }
     // ---- assignment
-    { ProfScope p(c, "lg_gemm");
+    { ProfScope p(c, "lg_proj");
       GemmArgs a = gemm_plain(b.x, 256, W.wp, 256, W.bp, b.md, 256, rows, 256, 256);
       a.alpha = 0.25f;  // / 256^(1/4)
-      launch_gemm_nt(s, a);
+      launch_gemm_nt(s, a); }
+    { ProfScope p(c, "lg_sim");
       GemmArgs g = gemm_plain(b.md, 256, b.md + (size_t)P * L * 256, 256, nullptr, b.sim, L, L, L, 256);
       g.batch = P; g.sA = (long long)L * 256; g.sB = (long long)L * 256; g.sC = (long long)L * L;
       g.m_valid = b.lens;
@@ -603,14 +602,14 @@ extern "C" int rfe_extract_match_stream_dev(rfe_ctx* c, const uint8_t* img, int 
 extern "C" int rfe_profile_enable(rfe_ctx* c, int on) { if (!c) return RFE_ERR_INVALID; c->prof = on != 0; return RFE_OK; }
 extern "C" int rfe_profile_reset(rfe_ctx* c) {
     if (!c) return RFE_ERR_INVALID;
-    hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
     c->stages.clear();
     return RFE_OK;
 }
 extern "C" int rfe_profile_read(rfe_ctx* c, char* names, size_t names_cap, double* ms, int64_t* calls, int cap) {
     if (!c) return RFE_ERR_INVALID;
-    hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
     std::string all;
     int k = 0;
