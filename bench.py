@@ -103,7 +103,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from rover_slam_amd import capi, weights as Wt, synth
+    from rover_slam_amd import capi, weights as Wt, synth, sharding
     ctx = capi.Context(local_rank)
     wsp, wlg = Wt.make_superpoint(seed=7), Wt.make_lightglue(seed=11)
     ctx.set_weights(capi.KIND_SUPERPOINT, wsp)
@@ -112,7 +112,8 @@ def main():
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
 
-    B = FRAMES_PER_GPU + 1
+    shard = sharding.shard_frames(FRAMES_PER_GPU, world, rank)
+    B = shard.frames
     # each rank owns frames [32r, 32r+32]: one frame of overlap, no inter-GPU dependency
     frames_np, _ = synth.make_frames(B, H, W, seed=20240314 + 1000 * rank)
     frames = torch.from_numpy(frames_np).to(dev)
@@ -123,18 +124,14 @@ def main():
     S = torch.zeros(B - 1, dtype=torch.int32, device=dev)
     pairs = torch.zeros(B - 1, KMAX, 2, dtype=torch.int32, device=dev)
     ms = torch.zeros(B - 1, KMAX, dtype=torch.float32, device=dev)
-    gather_bufs = None
-    if world > 1:
-        send = [n, kxy, S, pairs] + ([desc] if args.gather_desc else [])
-        gather_bufs = [[torch.empty_like(t) for _ in range(world)] if rank == 0 else None for t in send]
+    send = [n, kxy, S, pairs] + ([desc] if args.gather_desc else [])
 
     def step():
         ctx._chk(capi.lib.rfe_extract_match_stream_dev(
             ctx.h, frames.data_ptr(), H, W, W, B, KMAX, 0.0005, 0.1, n.data_ptr(), kxy.data_ptr(), score.data_ptr(),
             desc.data_ptr(), S.data_ptr(), pairs.data_ptr(), ms.data_ptr()))
         if world > 1:   # the trivial gather over RCCL/xGMI (compact results only unless --gather-desc)
-            for t, g in zip(send, gather_bufs):
-                dist.gather(t, g, dst=0)
+            sharding.gather_to_root(send, world, rank)
 
     def fence():
         if world > 1:

@@ -1,0 +1,154 @@
+// superpoint_onnx.h -- drop-in for the reference's SuperPointOnnxRunner
+// (include/Extractors/superpoint_onnx.h:10-68, src/Extractors/superpoint_onnx.cc): same class name,
+// public members and method names, but the "session" is an rfe_ctx of librover_fe.so (hand-written
+// HIP kernels for gfx950) instead of an Ort::Session, and tensors are rfe::Tensor instead of Ort::Value.
+//
+// Behavioural notes w.r.t. the reference:
+//  * InitOrtEnv returns EXIT_SUCCESS / EXIT_FAILURE and prints to std::cerr on failure, as
+//    superpoint_onnx.cc:59-65 does.  cfg.device is ignored (the only backend is HIP); cfg.extractorPath
+//    names an RFEW weight file (see Matchers/Configuration.h).
+//  * Extractor_Inference takes the NormalizeImage()d CV_32F image like superpoint_onnx.cc:88 and
+//    stores {keypoints i64 [1,K,2], scores f32 [1,K], descriptors f32 [1,K,256]} in
+//    extractor_outputtensors, K = number of detected keypoints (<= max_keypoints).
+//  * Extractor_PostProcess fills response = scores[idx]; the reference indexes scores[2*idx]
+//    (superpoint_onnx.cc:227, out of bounds for idx >= K/2) -- the intended value is used here.
+#pragma once
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <iostream>
+#include <string>
+#include <utility>
+#include <vector>
+#include "../rover_fe.h"
+#include "../rfe/cv_compat.h"
+#include "../rfe/tensor.h"
+#include "../Matchers/Configuration.h"
+#include "../Matchers/transform.h"
+
+class SuperPointOnnxRunner {
+public:
+    const unsigned int num_threads;
+    rfe_ctx* ExtractorSession = nullptr;            // reference: Ort::Session*
+    std::vector<std::vector<int64_t>> ExtractorInputNodeShapes = {{1, 1, -1, -1}};
+    float matchThresh = 0.0f;
+    long long extractor_timer = 0;
+    long long matcher_timer = 0;
+    float lastmatch = 0;
+    std::vector<float> scales = {1.0f, 1.0f};
+    int max_keypoints = 1024;                       // export-time max_num_keypoints of the reference graph
+    float detection_threshold = 0.0005f;
+    std::vector<std::vector<rfe::Tensor>> extractor_outputtensors;
+    std::pair<std::vector<cv::Point2f>, std::vector<cv::Point2f>> keypoints_result;
+
+    explicit SuperPointOnnxRunner(unsigned int threads = 1) : num_threads(threads) {
+        if (const char* e = std::getenv("RFE_MAX_KEYPOINTS")) max_keypoints = std::atoi(e);
+    }
+    ~SuperPointOnnxRunner() { if (ExtractorSession) rfe_destroy(ExtractorSession); }
+    SuperPointOnnxRunner(const SuperPointOnnxRunner&) = delete;
+    SuperPointOnnxRunner& operator=(const SuperPointOnnxRunner&) = delete;
+
+    int InitOrtEnv(Configuration cfg) {
+        std::string path = cfg.extractorPath;
+        if (const char* e = std::getenv("RFE_SP_WEIGHTS")) path = e;
+        if (path.empty() || path.size() < 5 || path.substr(path.size() - 5) != ".rfew") path = "onnxmodel/superpoint.rfew";
+        int dev = 0;
+        if (const char* e = std::getenv("RFE_DEVICE")) dev = std::atoi(e);
+        int rc = rfe_init(dev, &ExtractorSession);
+        if (rc != RFE_OK) {
+            std::cerr << "[ERROR] rover_fe environment created failed : " << rfe_last_error(nullptr) << '\n';
+            ExtractorSession = nullptr;
+            return EXIT_FAILURE;
+        }
+        rc = rfe_load_weights(ExtractorSession, path.c_str(), nullptr);
+        if (rc != RFE_OK) {
+            std::cerr << "[ERROR] rover_fe environment created failed : " << rfe_last_error(ExtractorSession) << '\n';
+            return EXIT_FAILURE;
+        }
+        return EXIT_SUCCESS;
+    }
+
+    // reference superpoint_onnx.cc:68-86 (unused there as well)
+    cv::Mat Extractor_PreProcess(Configuration, const cv::Mat& srcImage, float&) {
+        cv::Mat t = srcImage.clone();
+        return NormalizeImage(t);
+    }
+
+    // u8 fast path used by SPextractor::ExtractSingleLayer (NormalizeImage is fused into the first kernel)
+    int Extractor_Inference_u8(const unsigned char* img, int H, int W, int stride) {
+        extractor_outputtensors.clear();
+        if (!ExtractorSession) { std::cerr << "[ERROR] Extractor inference failed : no session" << std::endl; return EXIT_FAILURE; }
+        const int K = max_keypoints;
+        std::vector<int32_t> kxy((size_t)K * 2);
+        std::vector<float> sc(K), desc((size_t)K * 256);
+        int32_t n = 0;
+        auto t0 = std::chrono::high_resolution_clock::now();
+        int rc = rfe_extract_u8(ExtractorSession, img, H, W, stride, 1, K, detection_threshold, &n, kxy.data(), sc.data(), desc.data());
+        extractor_timer += std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count();
+        if (rc != RFE_OK) {
+            std::cerr << "[ERROR] Extractor inference failed : " << rfe_last_error(ExtractorSession) << std::endl;
+            return EXIT_FAILURE;
+        }
+        std::vector<rfe::Tensor> out;
+        out.emplace_back(std::vector<int64_t>{1, n, 2}, sizeof(int64_t));
+        out.emplace_back(std::vector<int64_t>{1, n}, sizeof(float));
+        out.emplace_back(std::vector<int64_t>{1, n, 256}, sizeof(float));
+        int64_t* k64 = out[0].GetTensorMutableData<int64_t>();
+        for (int i = 0; i < 2 * n; ++i) k64[i] = kxy[i];
+        std::copy(sc.begin(), sc.begin() + n, out[1].GetTensorMutableData<float>());
+        std::copy(desc.begin(), desc.begin() + (size_t)n * 256, out[2].GetTensorMutableData<float>());
+        extractor_outputtensors.emplace_back(std::move(out));
+        return EXIT_SUCCESS;
+    }
+
+    // reference superpoint_onnx.cc:88-162: image is the CV_32F output of NormalizeImage
+    int Extractor_Inference(Configuration, const cv::Mat& image) {
+        const int H = image.rows, W = image.cols;
+        std::vector<unsigned char> u8((size_t)H * W);
+        for (int r = 0; r < H; ++r) {
+            const float* s = image.ptr<float>(r);
+            for (int c = 0; c < W; ++c) {
+                const float v = s[c] * 255.0f, q = std::nearbyint(v);
+                if (std::fabs(v - q) > 1e-3f || q < 0.f || q > 255.f) {
+                    std::cerr << "[ERROR] Extractor inference failed : image is not an 8-bit image scaled by 1/255" << std::endl;
+                    return EXIT_FAILURE;
+                }
+                u8[(size_t)r * W + c] = (unsigned char)q;
+            }
+        }
+        return Extractor_Inference_u8(u8.data(), H, W, W);
+    }
+
+    // reference superpoint_onnx.cc:165-255
+    void Extractor_PostProcess(Configuration, std::vector<rfe::Tensor> tensor, std::vector<cv::KeyPoint>& vKeyPoints,
+                               cv::Mat& Descriptors) {
+        if (tensor.size() < 3) { std::cerr << "[ERROR] Extractor postprocess failed : missing tensors" << std::endl; return; }
+        const std::vector<int64_t> kshape = tensor[0].GetTensorTypeAndShapeInfo().GetShape();
+        const int64_t* kpts = tensor[0].GetTensorMutableData<int64_t>();
+        const float* scores = tensor[1].GetTensorMutableData<float>();
+        const std::vector<int64_t> dshape = tensor[2].GetTensorTypeAndShapeInfo().GetShape();
+        const float* desc = tensor[2].GetTensorMutableData<float>();
+        const float threshold = 0;  // adaptive branch disabled in the reference (superpoint_onnx.cc:190-193)
+        int keep = 0;
+        for (int64_t i = 0; i < kshape[1]; ++i) if (!(scores[i] < threshold)) ++keep;
+        cv::Mat mat1(keep, (int)dshape[2], CV_32F);
+        int row = 0;
+        for (int64_t i = 0; i < kshape[1]; ++i) {
+            if (scores[i] < threshold) continue;
+            cv::KeyPoint kp;
+            kp.pt = cv::Point2f((float)kpts[2 * i], (float)kpts[2 * i + 1]);
+            kp.response = scores[i];
+            kp.size = 10;
+            kp.octave = 0;
+            vKeyPoints.emplace_back(kp);
+            std::copy(desc + i * dshape[2], desc + (i + 1) * dshape[2], mat1.ptr<float>(row));
+            ++row;
+        }
+        Descriptors = mat1;
+    }
+
+    float GetMatchThresh() { return matchThresh; }
+    void SetMatchThresh(float thresh) { matchThresh = thresh; }
+    double GetTimer(std::string name) { return name == "extractor" ? (double)extractor_timer : (double)matcher_timer; }
+    std::pair<std::vector<cv::Point2f>, std::vector<cv::Point2f>> GetKeypointsResult() { return keypoints_result; }
+};

@@ -1,0 +1,59 @@
+"""GPU: the drop-in C++ headers (include/Extractors/SPextractor.h, include/Matchers/SPmatcher.h) driven the
+way the reference's callers drive them (tests/cpp/shim_driver.cpp: mock Frame, extractor operator(),
+the Frame and KeyPoint overloads of MatchingPoints_onnx) give the same results as the oracle."""
+import os
+import shutil
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from rover_slam_amd import weights as Wt, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="no g++")
+def test_cpp_shims_match_oracle(tmp_path, oracle):
+    H, W = 120, 160
+    exe = str(tmp_path / "shim_driver")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "shim_driver.cpp"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "rover-slam_amd"), "-lrover_fe", "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + os.path.join(ROOT, "rover-slam_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    wsp, wlg = Wt.make_superpoint(seed=7), Wt.make_lightglue(seed=11)
+    Wt.save(str(tmp_path / "sp.rfew"), wsp, 1)
+    Wt.save(str(tmp_path / "lg.rfew"), wlg, 2)
+    frames, _ = synth.make_frames(2, H, W, seed=42)
+    frames.tofile(str(tmp_path / "frames.u8"))
+    env = dict(os.environ, RFE_SP_WEIGHTS=str(tmp_path / "sp.rfew"), RFE_LG_WEIGHTS=str(tmp_path / "lg.rfew"),
+               RFE_MAX_KEYPOINTS="200")
+    r = subprocess.run([exe, str(tmp_path / "frames.u8"), str(H), str(W), str(tmp_path / "out.bin")], env=env,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    buf = open(str(tmp_path / "out.bin"), "rb").read()
+    off = 0
+    ext = []
+    for i in range(2):
+        n = struct.unpack_from("<i", buf, off)[0]; off += 4
+        kp = np.frombuffer(buf, np.float32, n * 5, off).reshape(n, 5); off += n * 20
+        desc = np.frombuffer(buf, np.float32, n * 256, off).reshape(n, 256); off += n * 1024
+        ext.append((n, kp, desc))
+    s_frame, s_quirk, m = struct.unpack_from("<iii", buf, off); off += 12
+    vn_frame = np.frombuffer(buf, np.int32, m, off); off += 4 * m
+    vn_quirk = np.frombuffer(buf, np.int32, m, off)
+    ref = [oracle.superpoint(wsp, frames[i], kmax=200) for i in range(2)]
+    for (n, kp, desc), r_ in zip(ext, ref):
+        assert n == r_["n"]
+        assert np.array_equal(kp[:, :2], r_["kxy"][:n].astype(np.float32))   # pt = float of integer pixel
+        assert np.array_equal(kp[:, 2], r_["score"][:n])                     # response = scores[idx]
+        assert (kp[:, 3] == 10).all() and (kp[:, 4] == 0).all()              # size = 10, octave = 0
+        assert np.array_equal(desc, r_["desc"][:n])
+    kp0, kp1 = [r_["kxy"][:r_["n"]].astype(np.float32) for r_ in ref]
+    d0, d1 = [r_["desc"][:r_["n"]] for r_ in ref]
+    for (rows, cols), s_got, vn_got in (((H, W), s_frame, vn_frame), ((300, 400), s_quirk, vn_quirk)):
+        lg = oracle.lightglue(wlg, oracle.normalize_keypoints(kp0, rows, cols), oracle.normalize_keypoints(kp1, rows, cols), d0, d1)
+        s_ref, vn_ref = oracle.postprocess_fused(lg["pairs"], lg["ms"], 0.0, len(kp0))
+        assert s_got == s_ref and np.array_equal(vn_got, vn_ref)
