@@ -6,17 +6,23 @@
 // (the arithmetic of superpoint.onnx / lightglue_sim.onnx that the reference runs through
 // Ort::Session::Run, src/Extractors/superpoint_onnx.cc:135, src/Matchers/lightglue_onnx.cpp:213).
 //
-// Workgroup 256 threads = 2x2 waves, tile 128x128x32; each wave 64x64 = 2x2 v_mfma_f32_32x32x2_f32
-// accumulators.  LDS tiles [128][33] (odd row stride -> the 32 rows of a fragment hit 32 banks).
+// Workgroup 256 threads = 2x2 waves, tile 128 x 256 x 32 (128 x 128 when N is not a multiple of 256);
+// each wave 64 x 128 = 2x4 v_mfma_f32_32x32x2_f32 accumulators.  LDS tiles [rows][33] (odd row stride ->
+// the 32 rows of a fragment hit 32 banks), single buffered so that 3 workgroups share a CU.
 // Reduction order: k ascending, accumulator initialised with the bias (== oracle rfo_linear, bit-exact).
 // Roofline: fp32 MFMA peak 157.3 TFLOP/s, algorithmic 2*M*N*K FLOP.
 #include "rfe_internal.h"
 
 namespace rfe {
 
-constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 1;
+constexpr int BM = 128, BK = 32, LDT = BK + 1;
 
+// NB = 32-column MFMA blocks per wave: wave tile 64 x (NB*32), workgroup tile 128 x (NB*64).
+// NB = 4 (128x256 tile, 49 KB LDS, 3 workgroups/CU) measured best for N % 256 == 0
+// (tools/kbench/gemm_variants.hip: 119-132 TFLOP/s vs 110-125 for 128x128 double-buffered).
+template <int NB>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
+    constexpr int BN = NB * 64;
     __shared__ float As[BM * LDT];
     __shared__ float Bs[BN * LDT];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -34,42 +40,63 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     const float* B = g.B + (size_t)z * g.sB;
     float* C = g.C + (size_t)z * g.sC;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NB];
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        const int n = n0 + wn * 64 + nb * 32 + i;
+    for (int nb = 0; nb < NB; ++nb) {
+        const int n = n0 + (wn * NB + nb) * 32 + i;
         const float bv = (g.bias && n < g.N) ? g.bias[n] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[0][nb][r] = bv; acc[1][nb][r] = bv; }
     }
 
-    const int lrow = tid >> 3, lkq = tid & 7;  // 32 rows x 8 float4 per pass
-    for (int k0 = 0; k0 < g.K; k0 += BK) {
-        __syncthreads();
-        const float* Asrc = A; int lda = g.lda; int kk = k0;
-        if (A2 && k0 >= g.K1) { Asrc = A2; lda = g.lda2; kk = k0 - g.K1; }
+    // staging: thread -> (row = tid/8 + 32*it, 4 consecutive k).  Rows past the M / N edge are CLAMPED
+    // (their products land in accumulators that are never stored), so the loop has no bounds branches.
+    constexpr int A_IT = BM / 32, B_IT = BN / 32;
+    const int lrow = tid >> 3, lkq = tid & 7;
+    size_t aoff[A_IT], a2off[A_IT], boff[B_IT];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int row = lrow + 32 * it;
-            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-            if (m0 + row < M) va = *reinterpret_cast<const float4*>(Asrc + (size_t)(m0 + row) * lda + kk + lkq * 4);
-            if (n0 + row < g.N) vb = *reinterpret_cast<const float4*>(B + (size_t)(n0 + row) * g.ldb + k0 + lkq * 4);
-            float* da = As + row * LDT + lkq * 4;
-            float* db = Bs + row * LDT + lkq * 4;
-            da[0] = va.x; da[1] = va.y; da[2] = va.z; da[3] = va.w;
-            db[0] = vb.x; db[1] = vb.y; db[2] = vb.z; db[3] = vb.w;
+    for (int it = 0; it < A_IT; ++it) {
+        int row = m0 + lrow + 32 * it; row = row < M ? row : M - 1;
+        aoff[it] = (size_t)row * g.lda + lkq * 4;
+        a2off[it] = (size_t)row * g.lda2 + lkq * 4;
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+        int row = n0 + lrow + 32 * it; row = row < g.N ? row : g.N - 1;
+        boff[it] = (size_t)row * g.ldb + lkq * 4;
+    }
+    float* const da = As + lrow * LDT + lkq * 4;
+    float* const db = Bs + lrow * LDT + lkq * 4;
+    const float* const ap = As + (wm * 64 + i) * LDT + h;
+    const float* const bp = Bs + (wn * NB * 32 + i) * LDT + h;
+
+    for (int k0 = 0; k0 < g.K; k0 += BK) {
+        float4 ra[A_IT], rb[B_IT];
+        if (A2 && k0 >= g.K1) {
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) ra[it] = *reinterpret_cast<const float4*>(A2 + a2off[it] + (k0 - g.K1));
+        } else {
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) ra[it] = *reinterpret_cast<const float4*>(A + aoff[it] + k0);
         }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) rb[it] = *reinterpret_cast<const float4*>(B + boff[it] + k0);
+        __syncthreads();   // previous tile fully consumed
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) { float* d = da + it * 32 * LDT; d[0] = ra[it].x; d[1] = ra[it].y; d[2] = ra[it].z; d[3] = ra[it].w; }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) { float* d = db + it * 32 * LDT; d[0] = rb[it].x; d[1] = rb[it].y; d[2] = rb[it].z; d[3] = rb[it].w; }
         __syncthreads();
-        const float* ap = As + (wm * 64 + i) * LDT + h;
-        const float* bp = Bs + (wn * 64 + i) * LDT + h;
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
             const float a0 = ap[2 * s], a1 = ap[32 * LDT + 2 * s];
-            const float b0 = bp[2 * s], b1 = bp[32 * LDT + 2 * s];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            float b[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) b[nb] = bp[nb * 32 * LDT + 2 * s];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[nb], acc[0][nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[nb], acc[1][nb], 0, 0, 0);
         }
     }
 
@@ -81,8 +108,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
             const int m = m0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (m >= M) continue;
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                const int n = n0 + wn * 64 + nb * 32 + i;
+            for (int nb = 0; nb < NB; ++nb) {
+                const int n = n0 + (wn * NB + nb) * 32 + i;
                 if (n >= g.N) continue;
                 float v = acc[mb][nb][r] * g.alpha;
                 if (g.relu) v = fmaxf(v, 0.f);
@@ -93,8 +120,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 }
 
 void launch_gemm_nt(hipStream_t s, const GemmArgs& g) {
-    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.batch > 0 ? g.batch : 1);
-    hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), 0, s, g);
+    const int batch = g.batch > 0 ? g.batch : 1;
+    if (g.N % 256 == 0) {
+        dim3 grid(g.N / 256, (g.M + BM - 1) / BM, batch);
+        hipLaunchKernelGGL(gemm_nt_kernel<4>, grid, dim3(256), 0, s, g);
+    } else {
+        dim3 grid((g.N + 127) / 128, (g.M + BM - 1) / BM, batch);
+        hipLaunchKernelGGL(gemm_nt_kernel<2>, grid, dim3(256), 0, s, g);
+    }
 }
 
 }  // namespace rfe

@@ -4,6 +4,7 @@
 // Ort::Session::Run (src/Matchers/lightglue_onnx.cpp:210-214); output contract matches0 [S,2] /
 // mscores0 [S] as consumed by Matcher_PostProcess_fused (lightglue_onnx.cpp:404-409).
 // fp32 throughout (descriptor tolerance 1e-4 of the north star rules out bf16 operands).
+#include <stdlib.h>
 #include "rfe_internal.h"
 
 namespace rfe {
@@ -52,12 +53,18 @@ void launch_lg_rope_split(hipStream_t s, const float* qkv, const float* cs, cons
 // 64 MFMA (32x32x2 f32) per 32x32 tile, no wasted FLOPs: 4*L*L*64 per head.
 constexpr int AT_Q = 128, AT_K = 64, AT_LDK = 65;
 
+template <bool DBUF>
 __global__ __launch_bounds__(256, 2) void lg_attention_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, float* __restrict__ out,
-    int Lq, int Lk, const int* __restrict__ qlen, const int* __restrict__ klen, const int* __restrict__ kv_map) {
-    __shared__ float Ks[AT_K * AT_LDK];
-    __shared__ float Vs[AT_K * 64];
-    const int seq = blockIdx.z, head = blockIdx.y, qb = blockIdx.x;
+    int Lq, int Lk, int nqb, const int* __restrict__ qlen, const int* __restrict__ klen, const int* __restrict__ kv_map) {
+    // K/V tiles double buffered in LDS; the next tile is prefetched global->registers under the MFMAs
+    __shared__ float Ks[DBUF ? 2 : 1][AT_K * AT_LDK];
+    __shared__ float Vs[DBUF ? 2 : 1][AT_K * 64];
+    // XCD-aware decode (blocks are dealt round-robin to the 8 XCDs): all query blocks of one
+    // (sequence, head) run on the same XCD so its K/V (512 KB) is fetched into one L2 only.
+    const int Lb = blockIdx.x, xcd = Lb & 7, t_ = Lb >> 3;
+    const int qb = t_ % nqb, unit = (t_ / nqb) * 8 + xcd;
+    const int seq = unit >> 2, head = unit & 3;
     const int kvseq = kv_map ? kv_map[seq] : seq;
     const int nq = qlen ? qlen[seq] : Lq;
     const int nk = klen ? klen[kvseq] : Lk;
@@ -71,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void lg_attention_kernel(
     }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
-    const int qrow = qb * AT_Q + wave * 32 + j;  // this lane's query (may be >= nq: computed, not stored)
+    const int qrow = qb * AT_Q + wave * 32 + j;  // this lane's query (may be >= nq: computed, stored as 0)
     const float* qp = q + ((size_t)seq * Lq + (qrow < Lq ? qrow : Lq - 1)) * 256 + head * 64 + h;
     float qreg[32];
 #pragma unroll
@@ -80,26 +87,49 @@ __global__ __launch_bounds__(256, 2) void lg_attention_kernel(
     f32x16 o0, o1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;   // running max in the log2 domain, running sum
 
     const float* kbase = k + (size_t)kvseq * Lk * 256 + head * 64;
     const float* vbase = v + (size_t)kvseq * Lk * 256 + head * 64;
-    for (int k0 = 0; k0 < nk; k0 += AT_K) {
-        __syncthreads();
-        // stage K,V tile: 64 keys x 64 dims each; thread -> (key = tid/4 [+0], 16 dims)
+    const int skey = tid >> 4, sdq = tid & 15;  // staging: thread -> (key, 4 dims), 4 passes of 16 keys
+    float4 rk[4], rv[4];
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int key = (tid >> 4) + 16 * it, dq = tid & 15;
-            float4 kv4 = make_float4(0.f, 0.f, 0.f, 0.f), vv4 = kv4;
-            if (k0 + key < nk) {
-                kv4 = *reinterpret_cast<const float4*>(kbase + (size_t)(k0 + key) * 256 + dq * 4);
-                vv4 = *reinterpret_cast<const float4*>(vbase + (size_t)(k0 + key) * 256 + dq * 4);
+            const int key = k0 + skey + 16 * it;
+            rk[it] = make_float4(0.f, 0.f, 0.f, 0.f); rv[it] = rk[it];
+            if (key < nk) {
+                rk[it] = *reinterpret_cast<const float4*>(kbase + (size_t)key * 256 + sdq * 4);
+                rv[it] = *reinterpret_cast<const float4*>(vbase + (size_t)key * 256 + sdq * 4);
             }
-            float* dk = Ks + key * AT_LDK + dq * 4;
-            dk[0] = kv4.x; dk[1] = kv4.y; dk[2] = kv4.z; dk[3] = kv4.w;
-            *reinterpret_cast<float4*>(Vs + key * 64 + dq * 4) = vv4;
         }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int key = skey + 16 * it;
+            float* dk = Ks[buf] + key * AT_LDK + sdq * 4;
+            dk[0] = rk[it].x; dk[1] = rk[it].y; dk[2] = rk[it].z; dk[3] = rk[it].w;
+            *reinterpret_cast<float4*>(Vs[buf] + key * 64 + sdq * 4) = rv[it];
+        }
+    };
+    if (DBUF) {
+        fetch(0);
+        stash(0);
         __syncthreads();
+    }
+    int buf = 0;
+    constexpr float kScale = 0.125f * 1.44269504088896341f;  // 1/sqrt(64) * log2(e): softmax in base 2
+    for (int k0 = 0; k0 < nk; k0 += AT_K) {
+        const bool more = DBUF && (k0 + AT_K < nk);
+        if (DBUF) {
+            if (more) fetch(k0 + AT_K);
+        } else {
+            __syncthreads();
+            fetch(k0);
+            stash(0);
+            __syncthreads();
+        }
 #pragma unroll
         for (int sub = 0; sub < AT_K / 32; ++sub) {
             if (k0 + sub * 32 >= nk) break;
@@ -107,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void lg_attention_kernel(
             f32x16 st;
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[r] = 0.f;
-            const float* ka = Ks + (sub * 32 + j) * AT_LDK + h;
+            const float* ka = Ks[buf] + (sub * 32 + j) * AT_LDK + h;
 #pragma unroll
             for (int s = 0; s < 32; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[2 * s], qreg[s], st, 0, 0, 0);
             // ---- online softmax over this lane's 16 keys (+ the other half-wave's 16)
@@ -115,28 +145,33 @@ __global__ __launch_bounds__(256, 2) void lg_attention_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = k0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                st[r] = key < nk ? st[r] * 0.125f : -INFINITY;
+                st[r] = key < nk ? st[r] * kScale : -INFINITY;
                 mx = fmaxf(mx, st[r]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float m_new = fmaxf(m_run, mx);
-            const float alpha = expf(m_run - m_new);  // m_run = -inf on the first tile -> 0
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // m_run = -inf on the first tile -> 0
             float ps = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { st[r] = expf(st[r] - m_new); ps += st[r]; }
+            for (int r = 0; r < 16; ++r) { st[r] = __builtin_amdgcn_exp2f(st[r] - m_new); ps += st[r]; }
             ps += __shfl_xor(ps, 32);
             l_run = l_run * alpha + ps;
             m_run = m_new;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
             // ---- O^T[d][query] += sum_key V[key][d] * P[key][query]; k-step r uses key(r,h)
-            const float* va = Vs + (sub * 32 + 4 * h) * 64 + j;
+            const float* va = Vs[buf] + (sub * 32 + 4 * h) * 64 + j;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kr = (r & 3) + 8 * (r >> 2);
                 o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[kr * 64], st[r], o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[kr * 64 + 32], st[r], o1, 0, 0, 0);
             }
+        }
+        if (DBUF) {
+            if (more) stash(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
         }
     }
     if (qrow < Lq) {
@@ -153,8 +188,13 @@ __global__ __launch_bounds__(256, 2) void lg_attention_kernel(
 
 void launch_lg_attention(hipStream_t s, const float* q, const float* k, const float* v, float* out, int nseq, int Lq,
                          int Lk, const int* qlen, const int* klen, const int* kv_map) {
-    dim3 grid((Lq + AT_Q - 1) / AT_Q, 4, nseq);
-    hipLaunchKernelGGL(lg_attention_kernel, grid, dim3(256), 0, s, q, k, v, out, Lq, Lk, qlen, klen, kv_map);
+    const int nqb = (Lq + AT_Q - 1) / AT_Q;
+    // 4*nseq (sequence, head) units; nseq = 2P is even so the unit count is a multiple of 8 (XCD decode is bijective)
+    static const bool single = getenv("RFE_ATT_DBUF") == nullptr;   // tuning switch: RFE_ATT_DBUF=1 selects the double-buffered variant
+    if (single)
+        hipLaunchKernelGGL(lg_attention_kernel<false>, dim3(nqb * 4 * nseq), dim3(256), 0, s, q, k, v, out, Lq, Lk, nqb, qlen, klen, kv_map);
+    else
+        hipLaunchKernelGGL(lg_attention_kernel<true>, dim3(nqb * 4 * nseq), dim3(256), 0, s, q, k, v, out, Lq, Lk, nqb, qlen, klen, kv_map);
 }
 
 // ---------------------------------------------------------------- LayerNorm(512) + GELU(erf), in place

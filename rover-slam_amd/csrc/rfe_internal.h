@@ -24,7 +24,7 @@ constexpr int64_t SP_COUNT = 1300865;
 constexpr int64_t LG_COUNT = 11321153;
 
 // conv3x3 implicit-GEMM tiling (see sp_conv.hip)
-constexpr int CONV_CK = 16;   // input channels per LDS chunk
+constexpr int CONV_CK = 8;    // input channels per LDS chunk (RFE_CONV_CK=16 selects the larger chunk)
 constexpr int CONV_NT = 64;   // output channels per workgroup
 
 // device-side packed SuperPoint weights

@@ -15,6 +15,7 @@
 //   Epilogue: ReLU, optional fused 2x2/2 max-pool (all four taps of a window live in one lane:
 //   D rows (r, r+1) of the two M-blocks), coalesced 128-B stores.
 // Roofline: compute bound on the fp32 MFMA peak (157.3 TFLOP/s); algorithmic 2*9*Cin*Cout FLOP/px.
+#include <stdlib.h>
 #include "rfe_internal.h"
 
 namespace rfe {
@@ -22,15 +23,20 @@ namespace rfe {
 constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 2;
 constexpr int TWS = IW;            // LDS row stride (words)
 constexpr int PLANE = IH * TWS;    // 340 words per input-channel plane
-constexpr int CK = CONV_CK;
-constexpr int KCH = CK * 9;        // 144 kappa per chunk
 constexpr int NT = CONV_NT;
+
+// input channels per LDS chunk: 16 (58.6 KB LDS, 2 workgroups/CU) or 8 (29.3 KB, 3-4 workgroups/CU)
+int conv_ck() {
+    static const int ck = [] { const char* e = getenv("RFE_CONV_CK"); const int v = e ? atoi(e) : CONV_CK; return (v == 8 || v == 16) ? v : CONV_CK; }();
+    return ck;
+}
 
 size_t packed_conv3x3_count(int cin, int cout) { return (size_t)cout * cin * 9; }
 
-// [Cout/64][Cin/16][144][64] : element (ct, ch, kl, j) = w[ct*64+j][ch*16 + kl/9][(kl%9)/3][kl%3]
+// [Cout/64][Cin/CK][CK*9][64] : element (ct, ch, kl, j) = w[ct*64+j][ch*CK + kl/9][(kl%9)/3][kl%3]
 void pack_conv3x3_weights(const float* w, int cin, int cout, std::vector<float>& out) {
     out.assign(packed_conv3x3_count(cin, cout), 0.f);
+    const int CK = conv_ck(), KCH = CK * 9;
     const int nch = cin / CK, nct = cout / NT;
     for (int ct = 0; ct < nct; ++ct)
         for (int ch = 0; ch < nch; ++ch)
@@ -42,10 +48,11 @@ void pack_conv3x3_weights(const float* w, int cin, int cout, std::vector<float>&
 }
 
 // TAG only gives each SuperPoint layer its own kernel symbol (per-layer rows in rocprofv3 --stats)
-template <int CIN, bool POOL, bool RELU, int TAG>
+template <int CIN, bool POOL, bool RELU, int TAG, int CK>
 __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ out, int H, int W, int COUT) {
+    constexpr int KCH = CK * 9;
     __shared__ __attribute__((aligned(16))) float lds[CK * PLANE + KCH * NT];
     float* lds_in = lds;
     float* lds_w = lds + CK * PLANE;
@@ -98,7 +105,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
             const float4* src = reinterpret_cast<const float4*>(wp_ct + (size_t)ch * KCH * NT);
             float4* dst = reinterpret_cast<float4*>(lds_w);
 #pragma unroll
-            for (int it = 0; it < KCH * NT / 4 / 256; ++it) dst[it * 256 + tid] = src[it * 256 + tid];
+            for (int it = 0; it < (KCH * NT / 4 + 255) / 256; ++it)
+                if (it * 256 + tid < KCH * NT / 4) dst[it * 256 + tid] = src[it * 256 + tid];
         }
         __syncthreads();
         // ---- 72 k-steps x 4 MFMA
@@ -155,13 +163,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     }
 }
 
-#define RFE_CONV_LAUNCH(CIN, POOL, RELU, TAG) \
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, POOL, RELU, TAG>), grid, dim3(256), 0, s, in, wp, bias, out, H, W, cout)
+#define RFE_CONV_LAUNCH(CIN, POOL, RELU, TAG)                                                                            \
+    do {                                                                                                                \
+        if (ck8) hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, POOL, RELU, TAG, 8>), grid, dim3(256), 0, s, in, wp, bias, out, H, W, cout); \
+        else hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, POOL, RELU, TAG, 16>), grid, dim3(256), 0, s, in, wp, bias, out, H, W, cout);   \
+    } while (0)
 
 // tag: SuperPoint layer id (L_1B .. L_DA) for the production path, 0 for the generic test hook
 void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin, const float* wp,
                     const float* bias, int cout, bool relu, bool pool, float* out, int tag) {
     dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B * (cout / NT));
+    const bool ck8 = conv_ck() == 8;
     switch (tag) {
         case L_1B: RFE_CONV_LAUNCH(64, true, true, L_1B); return;
         case L_2A: RFE_CONV_LAUNCH(64, false, true, L_2A); return;

@@ -1,0 +1,165 @@
+// kbench: GEMM NT tiling variants on fp32 MFMA (tuning harness, not product code).
+// hipcc --offload-arch=gfx950 -O3 -ffp-contract=off gemm_variants.hip -o gemm_variants
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+// pure MFMA issue-rate ceiling
+__global__ __launch_bounds__(256) void mfma_peak(float* out, int iters) {
+    f32x16 a0 = {0}, a1 = {0}, a2 = {0}, a3 = {0};
+    float x = threadIdx.x * 1e-3f, y = blockIdx.x * 1e-3f;
+    for (int i = 0; i < iters; ++i) {
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a3, 0, 0, 0);
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = a0[0] + a1[1] + a2[2] + a3[3];
+}
+
+// WG = WM x WN waves; wave tile = (MB*32) x (NB*32); K tile BK; DBUF: LDS double buffer + reg prefetch
+template <int WM, int WN, int MB, int NB, int BK, bool DBUF, int MINW>
+__global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_v(const float* __restrict__ A, const float* __restrict__ B,
+                                                              const float* __restrict__ bias, float* __restrict__ C,
+                                                              int M, int N, int K) {
+    constexpr int T = WM * WN * 64, BMt = WM * MB * 32, BNt = WN * NB * 32, LDT = BK + 1;
+    constexpr int NBUF = DBUF ? 2 : 1;
+    extern __shared__ float lds[];
+    float* As = lds;                       // [NBUF][BMt*LDT]
+    float* Bs = lds + NBUF * BMt * LDT;    // [NBUF][BNt*LDT]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int i = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * BMt, n0 = blockIdx.x * BNt;
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const float bv = bias[n0 + wn * NB * 32 + nb * 32 + i];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = bv;
+    }
+    constexpr int F4ROW = BK / 4;                      // float4 per tile row
+    constexpr int A_IT = BMt * F4ROW / T, B_IT = BNt * F4ROW / T;
+    float4 ra[A_IT], rb[B_IT];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) { const int idx = tid + it * T; ra[it] = *reinterpret_cast<const float4*>(A + (size_t)(m0 + idx / F4ROW) * K + k0 + (idx % F4ROW) * 4); }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) { const int idx = tid + it * T; rb[it] = *reinterpret_cast<const float4*>(B + (size_t)(n0 + idx / F4ROW) * K + k0 + (idx % F4ROW) * 4); }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) { const int idx = tid + it * T; float* d = As + buf * BMt * LDT + (idx / F4ROW) * LDT + (idx % F4ROW) * 4; d[0] = ra[it].x; d[1] = ra[it].y; d[2] = ra[it].z; d[3] = ra[it].w; }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) { const int idx = tid + it * T; float* d = Bs + buf * BNt * LDT + (idx / F4ROW) * LDT + (idx % F4ROW) * 4; d[0] = rb[it].x; d[1] = rb[it].y; d[2] = rb[it].z; d[3] = rb[it].w; }
+    };
+    auto compute = [&](int buf) {
+        const float* ap = As + buf * BMt * LDT + (wm * MB * 32 + i) * LDT + h;
+        const float* bp = Bs + buf * BNt * LDT + (wn * NB * 32 + i) * LDT + h;
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            float a[MB], b[NB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) a[mb] = ap[mb * 32 * LDT + 2 * s];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) b[nb] = bp[nb * 32 * LDT + 2 * s];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
+        }
+    };
+    if (DBUF) {
+        fetch(0); stash(0); __syncthreads();
+        int buf = 0;
+        for (int k0 = 0; k0 < K; k0 += BK) {
+            const bool more = k0 + BK < K;
+            if (more) fetch(k0 + BK);
+            compute(buf);
+            if (more) stash(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    } else {
+        for (int k0 = 0; k0 < K; k0 += BK) {
+            __syncthreads();
+            fetch(k0); stash(0);
+            __syncthreads();
+            compute(0);
+        }
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (wm * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) C[(size_t)m * N + n0 + (wn * NB + nb) * 32 + i] = acc[mb][nb][r];
+        }
+}
+
+template <int WM, int WN, int MB, int NB, int BK, bool DBUF, int MINW>
+static double run(const char* name, const float* A, const float* B, const float* bias, float* C, int M, int N, int K) {
+    constexpr int BMt = WM * MB * 32, BNt = WN * NB * 32, LDT = BK + 1;
+    const size_t lds = (size_t)(DBUF ? 2 : 1) * (BMt + BNt) * LDT * 4;
+    if (N % BNt || M % BMt) return 0;
+    auto kern = gemm_v<WM, WN, MB, NB, BK, DBUF, MINW>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid(N / BNt, M / BMt);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, 0, A, B, bias, C, M, N, K);
+    hipEventRecord(e0);
+    const int reps = 20;
+    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, 0, A, B, bias, C, M, N, K);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double tf = 2.0 * M * N * K * reps / (ms * 1e-3) / 1e12;
+    printf("  %-34s M=%d N=%d K=%d lds=%zuKB  %.1f us  %.1f TF\n", name, M, N, K, lds / 1024, ms / reps * 1e3, tf);
+    return tf;
+}
+
+int main() {
+    const int M = 65536;
+    float *A, *B, *bias, *C, *o;
+    CK(hipMalloc(&A, (size_t)M * 512 * 4)); CK(hipMalloc(&B, (size_t)768 * 512 * 4)); CK(hipMalloc(&bias, 768 * 4));
+    CK(hipMalloc(&C, (size_t)M * 768 * 4)); CK(hipMalloc(&o, 1 << 22));
+    std::vector<float> h((size_t)M * 512);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 65536.f - 0.5f;
+    CK(hipMemcpy(A, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(B, h.data(), (size_t)768 * 512 * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(bias, h.data(), 768 * 4, hipMemcpyHostToDevice));
+    {   // MFMA ceiling
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        const int iters = 20000, blocks = 256 * 4;
+        hipLaunchKernelGGL(mfma_peak, dim3(blocks), dim3(256), 0, 0, o, iters);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(mfma_peak, dim3(blocks), dim3(256), 0, 0, o, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("mfma_peak: %.1f TF (%.2f ms)\n", (double)blocks * 4 * iters * 4 * 4096 / (ms * 1e-3) / 1e12, ms);
+    }
+    const int shapes[4][2] = {{256, 256}, {512, 512}, {256, 512}, {768, 256}};  // N, K
+    for (auto& s : shapes) {
+        const int N = s[0], K = s[1];
+        printf("N=%d K=%d\n", N, K);
+        run<2, 2, 2, 2, 32, true, 2>("2x2w 64x64 BK32 dbuf (current)", A, B, bias, C, M, N, K);
+        run<2, 2, 2, 2, 32, false, 2>("2x2w 64x64 BK32 single", A, B, bias, C, M, N, K);
+        run<2, 2, 2, 2, 32, false, 3>("2x2w 64x64 BK32 single minw3", A, B, bias, C, M, N, K);
+        run<2, 2, 2, 2, 64, false, 2>("2x2w 64x64 BK64 single", A, B, bias, C, M, N, K);
+        run<2, 2, 2, 2, 16, true, 3>("2x2w 64x64 BK16 dbuf minw3", A, B, bias, C, M, N, K);
+        run<2, 2, 2, 4, 32, true, 2>("2x2w 64x128 BK32 dbuf", A, B, bias, C, M, N, K);
+        run<2, 2, 2, 4, 32, false, 2>("2x2w 64x128 BK32 single", A, B, bias, C, M, N, K);
+        run<4, 1, 2, 4, 32, false, 2>("4x1w 64x128 BK32 single", A, B, bias, C, M, N, K);
+        run<1, 4, 4, 2, 32, false, 2>("1x4w 128x64 BK32 single", A, B, bias, C, M, N, K);
+        run<2, 2, 4, 2, 32, false, 2>("2x2w 128x64 BK32 single", A, B, bias, C, M, N, K);
+        run<2, 4, 2, 2, 32, true, 2>("2x4w(512t) 64x64 BK32 dbuf", A, B, bias, C, M, N, K);
+        run<2, 4, 2, 2, 32, false, 2>("2x4w(512t) 64x64 BK32 single", A, B, bias, C, M, N, K);
+        run<1, 4, 2, 2, 32, true, 2>("1x4w 64x64 BK32 dbuf (64x256)", A, B, bias, C, M, N, K);
+    }
+    return 0;
+}
