@@ -41,6 +41,10 @@ def stage_flops(name, B, lens):
     if name in SP_CONV:
         cin, cout, ds = SP_CONV[name]
         return 2.0 * 9 * cin * cout * (H // ds) * (W // ds) * B
+    if name == "conv1ab":   # conv1a (1->64) recomputed in LDS + conv1b (64->64): count both layers once
+        return 2.0 * 9 * (1 * 64 + 64 * 64) * H * W * B
+    if name == "lg_cross_qkv":
+        return 2.0 * rows * 256 * 512
     if name == "convPb":
         return 2.0 * 256 * 65 * (H // 8) * (W // 8) * B
     if name == "convDb":

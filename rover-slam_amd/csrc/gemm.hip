@@ -23,8 +23,10 @@ constexpr int BM = 128, BK = 32, LDT = BK + 1;
 template <int NB>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     constexpr int BN = NB * 64;
-    __shared__ float As[BM * LDT];
-    __shared__ float Bs[BN * LDT];
+    __shared__ float lds_ab[(BM + BN) * LDT];   // A tile | B tile; reused for the rotary tables in the epilogue
+    float* const As = lds_ab;
+    float* const Bs = lds_ab + BM * LDT;
+    static_assert((BM + BN) * LDT >= BM * 65, "rotary table staging must fit");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -101,17 +103,38 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     }
 
     const float* R = g.R ? g.R + (size_t)z * g.sR : nullptr;
+    const bool rope = g.rope_cs != nullptr;
+    if (rope) {   // stage this tile's rotary tables [128 rows][32 cos | 32 sin] in the (now free) A/B LDS space
+        __syncthreads();
+        for (int idx = tid; idx < BM * 16; idx += 256) {
+            const int row = idx >> 4, q4 = idx & 15;     // 16 float4 per row: 8 cos + 8 sin
+            int m = m0 + row; m = m < M ? m : M - 1;
+            const float* src = (q4 < 8 ? g.rope_cs : g.rope_sn) + (size_t)m * 32 + (q4 & 7) * 4;
+            const float4 v4 = *reinterpret_cast<const float4*>(src);
+            float* d = As + row * 65 + (q4 < 8 ? 0 : 32) + (q4 & 7) * 4;   // row stride 65: conflict-free reads below
+            d[0] = v4.x; d[1] = v4.y; d[2] = v4.z; d[3] = v4.w;
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (m >= M) continue;
+            const int ml = wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int m = m0 + ml;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const int n = n0 + (wn * NB + nb) * 32 + i;
-                if (n >= g.N) continue;
                 float v = acc[mb][nb][r] * g.alpha;
+                if (rope) {   // LightGlue rotary on (q,k): t' = t*cos + rot(t)*sin, rot pairs (2f,2f+1) -> (-t1, t0)
+                    const float partner = __shfl_xor(v, 1);   // column n^1 of the same row
+                    if (n < g.rope_ncols) {
+                        const int f = (n & 63) >> 1;
+                        const float c = As[ml * 65 + f], sn = As[ml * 65 + 32 + f];
+                        v = (n & 1) ? v * c + partner * sn : v * c - partner * sn;
+                    }
+                }
+                if (m >= M || n >= g.N) continue;
                 if (g.relu) v = fmaxf(v, 0.f);
                 if (R) v = R[(size_t)m * g.ldr + n] + v;
                 C[(size_t)m * g.ldc + n] = v;

@@ -23,26 +23,6 @@ void launch_lg_posenc(hipStream_t s, const float* kn, const float* wr, int rows,
     hipLaunchKernelGGL(lg_posenc_kernel, dim3((rows * 32 + 255) / 256), dim3(256), 0, s, kn, wr, rows, cs, sn);
 }
 
-// qkv [rows,768] -> q,k (rotary applied, pairs (2f,2f+1) per head) and v, each [rows,256]
-__global__ void lg_rope_split_kernel(const float* __restrict__ qkv, const float* __restrict__ cs,
-                                     const float* __restrict__ sn, int rows, float* __restrict__ q,
-                                     float* __restrict__ k, float* __restrict__ v) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (row, channel pair)
-    if (gid >= rows * 128) return;
-    const int i = gid >> 7, c2 = gid & 127;                 // c2: pair index 0..127 ; freq = c2 & 31
-    const float c = cs[i * 32 + (c2 & 31)], s = sn[i * 32 + (c2 & 31)];
-    const float2 qq = *reinterpret_cast<const float2*>(qkv + (size_t)i * 768 + 2 * c2);
-    const float2 kk = *reinterpret_cast<const float2*>(qkv + (size_t)i * 768 + 256 + 2 * c2);
-    const float2 vv = *reinterpret_cast<const float2*>(qkv + (size_t)i * 768 + 512 + 2 * c2);
-    *reinterpret_cast<float2*>(q + (size_t)i * 256 + 2 * c2) = make_float2(qq.x * c - qq.y * s, qq.y * c + qq.x * s);
-    *reinterpret_cast<float2*>(k + (size_t)i * 256 + 2 * c2) = make_float2(kk.x * c - kk.y * s, kk.y * c + kk.x * s);
-    *reinterpret_cast<float2*>(v + (size_t)i * 256 + 2 * c2) = vv;
-}
-void launch_lg_rope_split(hipStream_t s, const float* qkv, const float* cs, const float* sn, int rows, float* q,
-                          float* k, float* v) {
-    hipLaunchKernelGGL(lg_rope_split_kernel, dim3((rows * 128 + 255) / 256), dim3(256), 0, s, qkv, cs, sn, rows, q, k, v);
-}
-
 // ---------------------------------------------------------------- fused attention
 // softmax(Q K^T / 8) V per (sequence, head), online softmax, never materialising the L x L matrix.
 // Workgroup = 4 waves = 128 queries of one head; wave = 32 queries.  Per 64-key tile staged in LDS:
@@ -55,7 +35,7 @@ constexpr int AT_Q = 128, AT_K = 64, AT_LDK = 65;
 
 template <bool DBUF>
 __global__ __launch_bounds__(256, 2) void lg_attention_kernel(
-    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, float* __restrict__ out,
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld, float* __restrict__ out,
     int Lq, int Lk, int nqb, const int* __restrict__ qlen, const int* __restrict__ klen, const int* __restrict__ kv_map) {
     // K/V tiles double buffered in LDS; the next tile is prefetched global->registers under the MFMAs
     __shared__ float Ks[DBUF ? 2 : 1][AT_K * AT_LDK];
@@ -79,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void lg_attention_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int qrow = qb * AT_Q + wave * 32 + j;  // this lane's query (may be >= nq: computed, stored as 0)
-    const float* qp = q + ((size_t)seq * Lq + (qrow < Lq ? qrow : Lq - 1)) * 256 + head * 64 + h;
+    const float* qp = q + ((size_t)seq * Lq + (qrow < Lq ? qrow : Lq - 1)) * ld + head * 64 + h;
     float qreg[32];
 #pragma unroll
     for (int s = 0; s < 32; ++s) qreg[s] = qp[2 * s];
@@ -89,8 +69,8 @@ __global__ __launch_bounds__(256, 2) void lg_attention_kernel(
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;   // running max in the log2 domain, running sum
 
-    const float* kbase = k + (size_t)kvseq * Lk * 256 + head * 64;
-    const float* vbase = v + (size_t)kvseq * Lk * 256 + head * 64;
+    const float* kbase = k + (size_t)kvseq * Lk * ld + head * 64;
+    const float* vbase = v + (size_t)kvseq * Lk * ld + head * 64;
     const int skey = tid >> 4, sdq = tid & 15;  // staging: thread -> (key, 4 dims), 4 passes of 16 keys
     float4 rk[4], rv[4];
     auto fetch = [&](int k0) {
@@ -99,8 +79,8 @@ __global__ __launch_bounds__(256, 2) void lg_attention_kernel(
             const int key = k0 + skey + 16 * it;
             rk[it] = make_float4(0.f, 0.f, 0.f, 0.f); rv[it] = rk[it];
             if (key < nk) {
-                rk[it] = *reinterpret_cast<const float4*>(kbase + (size_t)key * 256 + sdq * 4);
-                rv[it] = *reinterpret_cast<const float4*>(vbase + (size_t)key * 256 + sdq * 4);
+                rk[it] = *reinterpret_cast<const float4*>(kbase + (size_t)key * ld + sdq * 4);
+                rv[it] = *reinterpret_cast<const float4*>(vbase + (size_t)key * ld + sdq * 4);
             }
         }
     };
@@ -186,15 +166,15 @@ __global__ __launch_bounds__(256, 2) void lg_attention_kernel(
     }
 }
 
-void launch_lg_attention(hipStream_t s, const float* q, const float* k, const float* v, float* out, int nseq, int Lq,
+void launch_lg_attention(hipStream_t s, const float* q, const float* k, const float* v, int ld, float* out, int nseq, int Lq,
                          int Lk, const int* qlen, const int* klen, const int* kv_map) {
     const int nqb = (Lq + AT_Q - 1) / AT_Q;
     // 4*nseq (sequence, head) units; nseq = 2P is even so the unit count is a multiple of 8 (XCD decode is bijective)
     static const bool single = getenv("RFE_ATT_DBUF") == nullptr;   // tuning switch: RFE_ATT_DBUF=1 selects the double-buffered variant
     if (single)
-        hipLaunchKernelGGL(lg_attention_kernel<false>, dim3(nqb * 4 * nseq), dim3(256), 0, s, q, k, v, out, Lq, Lk, nqb, qlen, klen, kv_map);
+        hipLaunchKernelGGL(lg_attention_kernel<false>, dim3(nqb * 4 * nseq), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map);
     else
-        hipLaunchKernelGGL(lg_attention_kernel<true>, dim3(nqb * 4 * nseq), dim3(256), 0, s, q, k, v, out, Lq, Lk, nqb, qlen, klen, kv_map);
+        hipLaunchKernelGGL(lg_attention_kernel<true>, dim3(nqb * 4 * nseq), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map);
 }
 
 // ---------------------------------------------------------------- LayerNorm(512) + GELU(erf), in place

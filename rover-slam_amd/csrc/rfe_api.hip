@@ -2,6 +2,7 @@
 // each entry point replaces).  Host-side orchestration only: weight packing, workspaces, the two
 // kernel pipelines (SuperPoint, LightGlue) and the batched stream mode.  No CPU compute path.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <mutex>
@@ -109,7 +110,7 @@ extern "C" void rfe_destroy(rfe_ctx* c) {
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
     fr(c->sp.conv1a_w);
     for (int l = 0; l < 12; ++l) { fr(c->sp.packed[l]); fr(c->sp.bias[l]); }
-    fr(c->lg.blob);
+    fr(c->lg.blob); fr(c->lg.extra);
     fr(c->ws_sp); fr(c->ws_lg); fr(c->ws_io); fr(c->ws_tmp);
     (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -214,6 +215,18 @@ static int set_lg(rfe_ctx* c, const float* blob) {
     }
     W.wp = take(256 * 256); W.bp = take(256); W.wm = take(256); W.bm = take(1);
     if (p - c->lg.blob != LG_COUNT) return fail(c, RFE_ERR_INVALID, "internal: LightGlue blob layout mismatch");
+    // pack the two cross-attention input projections of every layer into one [512][256] Linear
+    if (W.extra) { RFE_HIP(c, hipFree(W.extra)); W.extra = nullptr; }
+    const size_t per = 512 * 256 + 512;
+    RFE_HIP(c, hipMalloc((void**)&W.extra, per * LG_LAYERS * sizeof(float)));
+    for (int l = 0; l < LG_LAYERS; ++l) {
+        LgLayerDev& L = W.L[l];
+        L.cwqkv = W.extra + per * l; L.cbqkv = L.cwqkv + 512 * 256;
+        RFE_HIP(c, hipMemcpy(L.cwqkv, L.cwqk, 256 * 256 * 4, hipMemcpyDeviceToDevice));
+        RFE_HIP(c, hipMemcpy(L.cwqkv + 256 * 256, L.cwv, 256 * 256 * 4, hipMemcpyDeviceToDevice));
+        RFE_HIP(c, hipMemcpy(L.cbqkv, L.cbqk, 256 * 4, hipMemcpyDeviceToDevice));
+        RFE_HIP(c, hipMemcpy(L.cbqkv + 256, L.cbv, 256 * 4, hipMemcpyDeviceToDevice));
+    }
     c->has_lg = true;
     return RFE_OK;
 }
@@ -313,8 +326,14 @@ int sp_forward_maps(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, in
     hipStream_t s = c->stream;
     const SpWeightsDev& w = c->sp;
     const int Hc = H / 8, Wc = W / 8, cells = B * Hc * Wc;
-    { ProfScope p(c, "conv1a"); launch_conv1a_u8(s, img, stride, B, H, W, w.conv1a_w, w.bias[L_1A], b.a1); }
-    { ProfScope p(c, "conv1b"); launch_conv3x3(s, b.a1, B, H, W, 64, w.packed[L_1B], w.bias[L_1B], 64, true, true, b.p1, L_1B); }
+    static const bool unfused = getenv("RFE_UNFUSED_CONV1") != nullptr;   // tuning / test switch
+    if (unfused) {
+        { ProfScope p(c, "conv1a"); launch_conv1a_u8(s, img, stride, B, H, W, w.conv1a_w, w.bias[L_1A], b.a1); }
+        { ProfScope p(c, "conv1b"); launch_conv3x3(s, b.a1, B, H, W, 64, w.packed[L_1B], w.bias[L_1B], 64, true, true, b.p1, L_1B); }
+    } else {   // conv1a recomputed inside conv1b's LDS staging: the [B,H,W,64] activation never touches HBM
+        ProfScope p(c, "conv1ab");
+        launch_conv1ab_fused(s, img, stride, B, H, W, w.conv1a_w, w.bias[L_1A], w.packed[L_1B], w.bias[L_1B], b.p1);
+    }
     { ProfScope p(c, "conv2a"); launch_conv3x3(s, b.p1, B, H / 2, W / 2, 64, w.packed[L_2A], w.bias[L_2A], 64, true, false, b.a2, L_2A); }
     { ProfScope p(c, "conv2b"); launch_conv3x3(s, b.a2, B, H / 2, W / 2, 64, w.packed[L_2B], w.bias[L_2B], 64, true, true, b.p2, L_2B); }
     { ProfScope p(c, "conv3a"); launch_conv3x3(s, b.p2, B, H / 4, W / 4, 64, w.packed[L_3A], w.bias[L_3A], 128, true, false, b.a3, L_3A); }
@@ -385,14 +404,14 @@ extern "C" int rfe_extract_u8(rfe_ctx* c, const uint8_t* img, int H, int W, int 
 namespace {
 
 struct LgBuffers {
-    float *x, *kn, *cs, *sn, *qkv, *q, *k, *v, *ctx, *msg, *h, *md, *z, *sim, *rowlse, *collse, *mx0;
+    float *x, *kn, *cs, *sn, *qkv, *ctx, *msg, *h, *md, *z, *sim, *rowlse, *collse, *mx0;
     int32_t *a0, *a1, *lens, *kvmap;
 };
 
 size_t lg_ws_bytes(int P, int L) {
     const size_t rows = (size_t)2 * P * L;
     size_t t = 0;
-    t += al(rows * 256 * 4) * 7;  // x q k v ctx msg md
+    t += al(rows * 256 * 4) * 4;  // x ctx msg md
     t += al(rows * 2 * 4) + al(rows * 32 * 4) * 2 + al(rows * 768 * 4) + al(rows * 512 * 4) + al(rows * 4);
     t += al((size_t)P * L * L * 4);
     t += al((size_t)P * L * 4) * 5;
@@ -402,8 +421,7 @@ size_t lg_ws_bytes(int P, int L) {
 void lg_carve(void* ws, int P, int L, LgBuffers& b) {
     const size_t rows = (size_t)2 * P * L;
     Bump a(ws);
-    b.x = a.take<float>(rows * 256); b.q = a.take<float>(rows * 256); b.k = a.take<float>(rows * 256);
-    b.v = a.take<float>(rows * 256); b.ctx = a.take<float>(rows * 256); b.msg = a.take<float>(rows * 256);
+    b.x = a.take<float>(rows * 256); b.ctx = a.take<float>(rows * 256); b.msg = a.take<float>(rows * 256);
     b.md = a.take<float>(rows * 256);
     b.kn = a.take<float>(rows * 2); b.cs = a.take<float>(rows * 32); b.sn = a.take<float>(rows * 32);
     b.qkv = a.take<float>(rows * 768); b.h = a.take<float>(rows * 512); b.z = a.take<float>(rows);
@@ -438,15 +456,16 @@ int lg_forward(rfe_ctx* c, LgBuffers& b, int P, int L, float thr, int cap, int32
     for (int l = 0; l < LG_LAYERS; ++l) {
         const LgLayerDev& Lw = W.L[l];
         // ---- self block
-        { ProfScope p(c, "lg_qkv"); launch_gemm_nt(s, gemm_plain(b.x, 256, Lw.wqkv, 256, Lw.bqkv, b.qkv, 768, rows, 768, 256)); }
-        { ProfScope p(c, "lg_misc"); launch_lg_rope_split(s, b.qkv, b.cs, b.sn, rows, b.q, b.k, b.v); }
-        { ProfScope p(c, "lg_attention"); launch_lg_attention(s, b.q, b.k, b.v, b.ctx, nseq, L, L, b.lens, b.lens, nullptr); }
+        { ProfScope p(c, "lg_qkv");   // q,k,v = Wqkv x + b with the rotary applied to q,k in the GEMM epilogue
+          GemmArgs a = gemm_plain(b.x, 256, Lw.wqkv, 256, Lw.bqkv, b.qkv, 768, rows, 768, 256);
+          a.rope_cs = b.cs; a.rope_sn = b.sn; a.rope_ncols = 512;
+          launch_gemm_nt(s, a); }
+        { ProfScope p(c, "lg_attention"); launch_lg_attention(s, b.qkv, b.qkv + 256, b.qkv + 512, 768, b.ctx, nseq, L, L, b.lens, b.lens, nullptr); }
         { ProfScope p(c, "lg_proj"); launch_gemm_nt(s, gemm_plain(b.ctx, 256, Lw.wo, 256, Lw.bo, b.msg, 256, rows, 256, 256)); }
         lg_ffn(c, b, rows, Lw.w1, Lw.b1, Lw.lng, Lw.lnb, Lw.w2, Lw.b2);
         // ---- cross block
-        { ProfScope p(c, "lg_proj"); launch_gemm_nt(s, gemm_plain(b.x, 256, Lw.cwqk, 256, Lw.cbqk, b.q, 256, rows, 256, 256)); }
-        { ProfScope p(c, "lg_proj"); launch_gemm_nt(s, gemm_plain(b.x, 256, Lw.cwv, 256, Lw.cbv, b.v, 256, rows, 256, 256)); }
-        { ProfScope p(c, "lg_attention"); launch_lg_attention(s, b.q, b.q, b.v, b.ctx, nseq, L, L, b.lens, b.lens, b.kvmap); }
+        { ProfScope p(c, "lg_cross_qkv"); launch_gemm_nt(s, gemm_plain(b.x, 256, Lw.cwqkv, 256, Lw.cbqkv, b.qkv, 512, rows, 512, 256)); }
+        { ProfScope p(c, "lg_attention"); launch_lg_attention(s, b.qkv, b.qkv, b.qkv + 256, 512, b.ctx, nseq, L, L, b.lens, b.lens, b.kvmap); }
         { ProfScope p(c, "lg_proj"); launch_gemm_nt(s, gemm_plain(b.ctx, 256, Lw.cwo, 256, Lw.cbo, b.msg, 256, rows, 256, 256)); }
         lg_ffn(c, b, rows, Lw.cw1, Lw.cb1, Lw.clng, Lw.clnb, Lw.cw2, Lw.cb2);
     }

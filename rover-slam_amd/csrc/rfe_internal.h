@@ -37,9 +37,11 @@ struct SpWeightsDev {
 struct LgLayerDev {
     float *wqkv, *bqkv, *wo, *bo, *w1, *b1, *lng, *lnb, *w2, *b2;
     float *cwqk, *cbqk, *cwv, *cbv, *cwo, *cbo, *cw1, *cb1, *clng, *clnb, *cw2, *cb2;
+    float *cwqkv, *cbqkv;   // packed [512][256] = [Wqk ; Wv] and [512] bias (device copy made at load time)
 };
 struct LgWeightsDev {
     float* blob = nullptr;  // whole canonical blob on device; pointers below index into it
+    float* extra = nullptr; // packed cross-attention projection weights (cwqkv / cbqkv of every layer)
     float* wr;
     LgLayerDev L[LG_LAYERS];
     float *wp, *bp, *wm, *bm;
@@ -60,6 +62,9 @@ struct GemmArgs {
     long long sA, sA2, sB, sC, sR;    // batch strides (grid.z)
     const int* m_valid;               // optional per-batch valid row count (rows >= m_valid skipped)
     int batch;
+    const float* rope_cs;             // optional fused rotary epilogue: cos/sin tables [M][32], applied to
+    const float* rope_sn;             //   columns n < rope_ncols in adjacent pairs (2f, 2f+1), f = (n%64)/2
+    int rope_ncols;
 };
 
 }  // namespace rfe
@@ -113,6 +118,8 @@ void launch_conv1a_u8(hipStream_t s, const uint8_t* img, int stride, int B, int 
 void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin,
                     const float* wpacked, const float* bias, int cout, bool relu, bool pool, float* out,
                     int tag = 0);
+void launch_conv1ab_fused(hipStream_t s, const uint8_t* img, int stride, int B, int H, int W, const float* w1a,
+                          const float* b1a, const float* wp, const float* bias, float* out);
 // gemm.hip
 void launch_gemm_nt(hipStream_t s, const GemmArgs& g);
 // sp_post.hip
@@ -126,10 +133,8 @@ void launch_desc_sample(hipStream_t s, const float* dmap, int B, int Hc, int Wc,
                         const int32_t* n, const int32_t* kxy, int Kmax, float* desc);
 // lg_kernels.hip
 void launch_lg_posenc(hipStream_t s, const float* kn, const float* wr, int rows, float* cs, float* sn);
-void launch_lg_rope_split(hipStream_t s, const float* qkv, const float* cs, const float* sn, int rows,
-                          float* q, float* k, float* v);
-void launch_lg_attention(hipStream_t s, const float* q, const float* k, const float* v, float* out,
-                         int nseq, int Lq, int Lk, const int* qlen, const int* klen,
+void launch_lg_attention(hipStream_t s, const float* q, const float* k, const float* v, int ld /*row stride of q,k,v*/,
+                         float* out, int nseq, int Lq, int Lk, const int* qlen, const int* klen,
                          const int* kv_map /*seq -> kv seq index, or null = identity*/);
 void launch_lg_ln_gelu(hipStream_t s, float* h, const float* g, const float* b, int64_t rows);
 void launch_lg_assign(hipStream_t s, const float* sim, const float* z0, const float* z1, int P, int L,

@@ -47,34 +47,8 @@ void pack_conv3x3_weights(const float* w, int cin, int cout, std::vector<float>&
                 }
 }
 
-// TAG only gives each SuperPoint layer its own kernel symbol (per-layer rows in rocprofv3 --stats)
-template <int CIN, bool POOL, bool RELU, int TAG, int CK>
-__global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
-    const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
-    float* __restrict__ out, int H, int W, int COUT) {
-    constexpr int KCH = CK * 9;
-    __shared__ __attribute__((aligned(16))) float lds[CK * PLANE + KCH * NT];
-    float* lds_in = lds;
-    float* lds_w = lds + CK * PLANE;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int col = lane & 31, h = lane >> 5;
-    const int nct = COUT / NT;
-    const int b = blockIdx.z / nct, ct = blockIdx.z % nct;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    const int co0 = ct * NT;
-
-    f32x16 acc[2][2];
-    {
-        const float b0 = bias[co0 + col], b1 = bias[co0 + 32 + col];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[0][0][r] = b0; acc[1][0][r] = b0; acc[0][1][r] = b1; acc[1][1][r] = b1; }
-    }
-
-    // per-lane A offsets for the 9 k-steps of an 18-kappa period (two input channels)
-    int aoff[9];
+// per-lane A offsets for the 9 k-steps of an 18-kappa period (two input channels)
+__device__ __forceinline__ void conv_a_offsets(int (&aoff)[9], int h, int wave, int col) {
 #pragma unroll
     for (int s = 0; s < 9; ++s) {
         const int k0 = 2 * s, k1 = 2 * s + 1;
@@ -82,51 +56,42 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
         const int o1 = (k1 / 9) * PLANE + ((k1 % 9) / 3) * TWS + (k1 % 9) % 3;
         aoff[s] = (h ? o1 : o0) + (2 * wave) * TWS + col;
     }
-    const int boff = h * NT + col;
+}
 
-    const float* in_b = in + (size_t)b * H * W * CIN;
-    const float* wp_ct = wp + (size_t)ct * (CIN / CK) * KCH * NT;
-
-    for (int ch = 0; ch < CIN / CK; ++ch) {
-        __syncthreads();
-        // ---- stage input tile: NHWC global -> channel-planar LDS (zero padding materialised)
-        for (int idx = tid; idx < IH * IW * (CK / 4); idx += 256) {
-            const int cq = idx % (CK / 4), pix = idx / (CK / 4);
-            const int py = pix / IW, px = pix % IW;
-            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-                v = *reinterpret_cast<const float4*>(in_b + ((size_t)gy * W + gx) * CIN + ch * CK + cq * 4);
-            float* d = lds_in + (cq * 4) * PLANE + py * TWS + px;
-            d[0] = v.x; d[PLANE] = v.y; d[2 * PLANE] = v.z; d[3 * PLANE] = v.w;
-        }
-        // ---- stage weight chunk (linear 36 KB copy)
-        {
-            const float4* src = reinterpret_cast<const float4*>(wp_ct + (size_t)ch * KCH * NT);
-            float4* dst = reinterpret_cast<float4*>(lds_w);
-#pragma unroll
-            for (int it = 0; it < (KCH * NT / 4 + 255) / 256; ++it)
-                if (it * 256 + tid < KCH * NT / 4) dst[it * 256 + tid] = src[it * 256 + tid];
-        }
-        __syncthreads();
-        // ---- 72 k-steps x 4 MFMA
+// one staged chunk of CK input channels: CK*9/2 k-steps x 4 MFMA per wave
+template <int CK>
+__device__ __forceinline__ void conv_chunk_mma(const float* lds_in, const float* lds_w, const int (&aoff)[9], int boff,
+                                               f32x16 (&acc)[2][2]) {
 #pragma unroll 1
-        for (int cp = 0; cp < CK / 2; ++cp) {
-            const float* ap = lds_in + cp * 2 * PLANE;
-            const float* bp = lds_w + cp * 18 * NT + boff;
+    for (int cp = 0; cp < CK / 2; ++cp) {
+        const float* ap = lds_in + cp * 2 * PLANE;
+        const float* bp = lds_w + cp * 18 * NT + boff;
 #pragma unroll
-            for (int s = 0; s < 9; ++s) {
-                const float a0 = ap[aoff[s]], a1 = ap[aoff[s] + TWS];
-                const float b0 = bp[2 * s * NT], b1 = bp[2 * s * NT + 32];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            }
+        for (int s = 0; s < 9; ++s) {
+            const float a0 = ap[aoff[s]], a1 = ap[aoff[s] + TWS];
+            const float b0 = bp[2 * s * NT], b1 = bp[2 * s * NT + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
     }
+}
 
-    // ---- epilogue.  D layout: lane holds channel (lane&31), pixel column (r&3)+8*(r>>2)+4*h
+template <int CK>
+__device__ __forceinline__ void conv_stage_weights(float* lds_w, const float* src_chunk, int tid) {
+    constexpr int KCH = CK * 9;
+    const float4* src = reinterpret_cast<const float4*>(src_chunk);
+    float4* dst = reinterpret_cast<float4*>(lds_w);
+#pragma unroll
+    for (int it = 0; it < (KCH * NT / 4 + 255) / 256; ++it)
+        if (it * 256 + tid < KCH * NT / 4) dst[it * 256 + tid] = src[it * 256 + tid];
+}
+
+// epilogue.  D layout: lane holds channel (lane&31), pixel column (r&3)+8*(r>>2)+4*h of rows 2*wave+{0,1}
+template <bool POOL, bool RELU>
+__device__ __forceinline__ void conv_store(const f32x16 (&acc)[2][2], float* __restrict__ out, int b, int H, int W, int COUT,
+                                           int x0, int y0, int co0, int wave, int col, int h) {
     if (!POOL) {
         float* out_b = out + (size_t)b * H * W * COUT;
 #pragma unroll
@@ -161,6 +126,135 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
             }
         }
     }
+}
+
+// TAG only gives each SuperPoint layer its own kernel symbol (per-layer rows in rocprofv3 --stats)
+template <int CIN, bool POOL, bool RELU, int TAG, int CK>
+__global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
+    const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
+    float* __restrict__ out, int H, int W, int COUT) {
+    constexpr int KCH = CK * 9;
+    __shared__ __attribute__((aligned(16))) float lds[CK * PLANE + KCH * NT];
+    float* lds_in = lds;
+    float* lds_w = lds + CK * PLANE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, h = lane >> 5;
+    const int nct = COUT / NT;
+    const int b = blockIdx.z / nct, ct = blockIdx.z % nct;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int co0 = ct * NT;
+
+    f32x16 acc[2][2];
+    {
+        const float b0 = bias[co0 + col], b1 = bias[co0 + 32 + col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][0][r] = b0; acc[1][0][r] = b0; acc[0][1][r] = b1; acc[1][1][r] = b1; }
+    }
+    int aoff[9];
+    conv_a_offsets(aoff, h, wave, col);
+    const int boff = h * NT + col;
+
+    const float* in_b = in + (size_t)b * H * W * CIN;
+    const float* wp_ct = wp + (size_t)ct * (CIN / CK) * KCH * NT;
+
+    for (int ch = 0; ch < CIN / CK; ++ch) {
+        __syncthreads();
+        // ---- stage input tile: NHWC global -> channel-planar LDS (zero padding materialised)
+        for (int idx = tid; idx < IH * IW * (CK / 4); idx += 256) {
+            const int cq = idx % (CK / 4), pix = idx / (CK / 4);
+            const int py = pix / IW, px = pix % IW;
+            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+                v = *reinterpret_cast<const float4*>(in_b + ((size_t)gy * W + gx) * CIN + ch * CK + cq * 4);
+            float* d = lds_in + (cq * 4) * PLANE + py * TWS + px;
+            d[0] = v.x; d[PLANE] = v.y; d[2 * PLANE] = v.z; d[3 * PLANE] = v.w;
+        }
+        conv_stage_weights<CK>(lds_w, wp_ct + (size_t)ch * KCH * NT, tid);
+        __syncthreads();
+        conv_chunk_mma<CK>(lds_in, lds_w, aoff, boff, acc);
+    }
+    conv_store<POOL, RELU>(acc, out, b, H, W, COUT, x0, y0, co0, wave, col, h);
+}
+
+// ------------------------------------------------------------------------------------------
+// conv1a + conv1b fused: the 64-channel input tile of conv1b is never read from HBM; every staged
+// 8-channel chunk is recomputed in LDS from the u8 image tile (NormalizeImage * 1/255, conv1a 1->64,
+// bias, ReLU -- same fmaf chain as conv1a_u8_kernel / the oracle, so still bit-exact), then conv1b +
+// ReLU + 2x2 max-pool as above.  Removes the 78.6 MB/frame round trip of the largest activation.
+template <int CK>
+__global__ __launch_bounds__(256, 2) void conv1ab_fused_kernel(
+    const uint8_t* __restrict__ img, int stride, const float* __restrict__ w1a /*[9][64]*/, const float* __restrict__ b1a,
+    const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ out, int H, int W) {
+    constexpr int CIN = 64, COUT = 64, KCH = CK * 9;
+    constexpr int MH = TH + 4, MW = TW + 4;   // image tile with a 2-pixel halo
+    __shared__ __attribute__((aligned(16))) float lds[CK * PLANE + KCH * NT + MH * MW];
+    float* lds_in = lds;
+    float* lds_w = lds + CK * PLANE;
+    float* lds_img = lds_w + KCH * NT;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+
+    f32x16 acc[2][2];
+    {
+        const float b0 = bias[col], b1 = bias[32 + col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][0][r] = b0; acc[1][0][r] = b0; acc[0][1][r] = b1; acc[1][1][r] = b1; }
+    }
+    int aoff[9];
+    conv_a_offsets(aoff, h, wave, col);
+    const int boff = h * NT + col;
+
+    const uint8_t* im = img + (size_t)b * stride * H;
+    for (int idx = tid; idx < MH * MW; idx += 256) {
+        const int py = idx / MW, px = idx % MW;
+        const int gy = y0 - 2 + py, gx = x0 - 2 + px;
+        float v = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = (float)im[(size_t)gy * stride + gx] * 0.003921568859368563f;
+        lds_img[idx] = v;
+    }
+
+    for (int ch = 0; ch < CIN / CK; ++ch) {
+        __syncthreads();
+        // ---- conv1a for CK channels on the haloed tile; pixels outside the image are conv1b's zero padding
+        for (int p = tid; p < IH * IW; p += 256) {
+            const int py = p / IW, px = p % IW;
+            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            const bool inb = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            float iv[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) iv[k] = lds_img[(py + k / 3) * MW + px + k % 3];
+#pragma unroll
+            for (int e = 0; e < CK; ++e) {
+                const int c = ch * CK + e;
+                float a = b1a[c];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) a = fmaf(iv[k], w1a[k * 64 + c], a);
+                lds_in[e * PLANE + py * TWS + px] = inb ? fmaxf(a, 0.f) : 0.f;
+            }
+        }
+        conv_stage_weights<CK>(lds_w, wp + (size_t)ch * KCH * NT, tid);
+        __syncthreads();
+        conv_chunk_mma<CK>(lds_in, lds_w, aoff, boff, acc);
+    }
+    conv_store<true, true>(acc, out, b, H, W, COUT, x0, y0, 0, wave, col, h);
+}
+
+void launch_conv1ab_fused(hipStream_t s, const uint8_t* img, int stride, int B, int H, int W, const float* w1a,
+                          const float* b1a, const float* wp, const float* bias, float* out) {
+    dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B);
+    if (conv_ck() == 8)
+        hipLaunchKernelGGL((conv1ab_fused_kernel<8>), grid, dim3(256), 0, s, img, stride, w1a, b1a, wp, bias, out, H, W);
+    else
+        hipLaunchKernelGGL((conv1ab_fused_kernel<16>), grid, dim3(256), 0, s, img, stride, w1a, b1a, wp, bias, out, H, W);
 }
 
 #define RFE_CONV_LAUNCH(CIN, POOL, RELU, TAG)                                                                            \
