@@ -68,6 +68,24 @@ def stage_flops(name, B, lens):
     return None
 
 
+STAGE_KERNEL = {"lg_attention": "lg_attention_kernel", "conv1ab": "conv1ab_fused_kernel", "conv1b": "true, true, 1,",
+                "conv2a": "false, true, 2,", "conv2b": "true, true, 3,", "conv3a": "false, true, 4,", "conv3b": "true, true, 5,"}
+
+
+def pmc_traffic(stage):
+    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes of this same
+    bench command (profiles/r01_pmc_traffic.json, made by tools/profile_round.sh + tools/rocpd_pmc.py):
+    (2*FETCH_SIZE + WRITE_SIZE)*1024 as the MI355X guide prescribes.  None when no PMC pass covers it."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    key = STAGE_KERNEL.get(stage)
+    if not key or not os.path.exists(path):
+        return None, None
+    for name, v in json.load(open(path))["kernels"].items():
+        if key in name:
+            return v["traffic_bytes"], "profiles/r01_pmc_traffic.json:" + name
+    return None, None
+
+
 def cpu_baseline(frames, wsp, wlg):
     """The CPU oracle (a port, not the reference's ONNXRuntime path -- that cannot run here: no
     onnxruntime, no .onnx blobs) on a bounded sample: 4 frames extracted + 3 consecutive pairs matched."""
@@ -169,6 +187,7 @@ def main():
         fl = stage_flops(dom_name, B, lens)
         avg_ms = dom_ms / max(dom_calls, 1)
         achieved = fl / (avg_ms * 1e-3) / 1e12 if fl else None
+        traffic, traffic_src = pmc_traffic(dom_name)
         stages = {}
         for k, (msv, calls) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
             f = stage_flops(k, B, lens)
@@ -186,7 +205,8 @@ def main():
                                    + ("; gather of counts/keypoints/matches to rank 0 over RCCL" if world > 1 else "")},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2) if achieved else None,
                          "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_TFLOPS, 4) if achieved else None,
-                         "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": dom_calls,
+                         "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 PMC, separate pass)",
+                         "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4), "launches": dom_calls,
                          "flops_per_launch": fl},
             "stages": stages,
         }

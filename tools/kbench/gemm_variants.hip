@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void mfma_peak(float* out, int iters) {
 }
 
 // WG = WM x WN waves; wave tile = (MB*32) x (NB*32); K tile BK; DBUF: LDS double buffer + reg prefetch
-template <int WM, int WN, int MB, int NB, int BK, bool DBUF, int MINW>
+template <int WM, int WN, int MB, int NB, int BK, bool DBUF, int MINW, int PIPE = 0>
 __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_v(const float* __restrict__ A, const float* __restrict__ B,
                                                               const float* __restrict__ bias, float* __restrict__ C,
                                                               int M, int N, int K) {
@@ -61,6 +61,32 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_v(const float* __rest
     auto compute = [&](int buf) {
         const float* ap = As + buf * BMt * LDT + (wm * MB * 32 + i) * LDT + h;
         const float* bp = Bs + buf * BNt * LDT + (wn * NB * 32 + i) * LDT + h;
+        if (PIPE) {   // explicit operand pipelining: LDS reads of step s+PIPE are issued before the MFMAs of step s
+            float a[BK / 2][MB], b[BK / 2][NB];
+#pragma unroll
+            for (int s = 0; s < PIPE; ++s) {
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) a[s][mb] = ap[mb * 32 * LDT + 2 * s];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) b[s][nb] = bp[nb * 32 * LDT + 2 * s];
+            }
+#pragma unroll
+            for (int s = 0; s < BK / 2; ++s) {
+                if (s + PIPE < BK / 2) {
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) a[s + PIPE][mb] = ap[mb * 32 * LDT + 2 * (s + PIPE)];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) b[s + PIPE][nb] = bp[nb * 32 * LDT + 2 * (s + PIPE)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][mb], b[s][nb], acc[mb][nb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
             float a[MB], b[NB];
@@ -103,12 +129,12 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_v(const float* __rest
         }
 }
 
-template <int WM, int WN, int MB, int NB, int BK, bool DBUF, int MINW>
+template <int WM, int WN, int MB, int NB, int BK, bool DBUF, int MINW, int PIPE = 0>
 static double run(const char* name, const float* A, const float* B, const float* bias, float* C, int M, int N, int K) {
     constexpr int BMt = WM * MB * 32, BNt = WN * NB * 32, LDT = BK + 1;
     const size_t lds = (size_t)(DBUF ? 2 : 1) * (BMt + BNt) * LDT * 4;
     if (N % BNt || M % BMt) return 0;
-    auto kern = gemm_v<WM, WN, MB, NB, BK, DBUF, MINW>;
+    auto kern = gemm_v<WM, WN, MB, NB, BK, DBUF, MINW, PIPE>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid(N / BNt, M / BMt);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -147,19 +173,17 @@ int main() {
     for (auto& s : shapes) {
         const int N = s[0], K = s[1];
         printf("N=%d K=%d\n", N, K);
-        run<2, 2, 2, 2, 32, true, 2>("2x2w 64x64 BK32 dbuf (current)", A, B, bias, C, M, N, K);
         run<2, 2, 2, 2, 32, false, 2>("2x2w 64x64 BK32 single", A, B, bias, C, M, N, K);
-        run<2, 2, 2, 2, 32, false, 3>("2x2w 64x64 BK32 single minw3", A, B, bias, C, M, N, K);
-        run<2, 2, 2, 2, 64, false, 2>("2x2w 64x64 BK64 single", A, B, bias, C, M, N, K);
-        run<2, 2, 2, 2, 16, true, 3>("2x2w 64x64 BK16 dbuf minw3", A, B, bias, C, M, N, K);
-        run<2, 2, 2, 4, 32, true, 2>("2x2w 64x128 BK32 dbuf", A, B, bias, C, M, N, K);
+        run<2, 2, 2, 2, 32, false, 2, 1>("2x2w 64x64 BK32 single pipe1", A, B, bias, C, M, N, K);
+        run<2, 2, 2, 2, 32, false, 2, 2>("2x2w 64x64 BK32 single pipe2", A, B, bias, C, M, N, K);
+        run<2, 2, 2, 2, 32, false, 2, 4>("2x2w 64x64 BK32 single pipe4", A, B, bias, C, M, N, K);
+        run<2, 2, 2, 2, 32, true, 2, 2>("2x2w 64x64 BK32 dbuf pipe2", A, B, bias, C, M, N, K);
         run<2, 2, 2, 4, 32, false, 2>("2x2w 64x128 BK32 single", A, B, bias, C, M, N, K);
-        run<4, 1, 2, 4, 32, false, 2>("4x1w 64x128 BK32 single", A, B, bias, C, M, N, K);
-        run<1, 4, 4, 2, 32, false, 2>("1x4w 128x64 BK32 single", A, B, bias, C, M, N, K);
-        run<2, 2, 4, 2, 32, false, 2>("2x2w 128x64 BK32 single", A, B, bias, C, M, N, K);
-        run<2, 4, 2, 2, 32, true, 2>("2x4w(512t) 64x64 BK32 dbuf", A, B, bias, C, M, N, K);
-        run<2, 4, 2, 2, 32, false, 2>("2x4w(512t) 64x64 BK32 single", A, B, bias, C, M, N, K);
-        run<1, 4, 2, 2, 32, true, 2>("1x4w 64x64 BK32 dbuf (64x256)", A, B, bias, C, M, N, K);
+        run<2, 2, 2, 4, 32, false, 2, 1>("2x2w 64x128 BK32 single pipe1", A, B, bias, C, M, N, K);
+        run<2, 2, 2, 4, 32, false, 2, 2>("2x2w 64x128 BK32 single pipe2", A, B, bias, C, M, N, K);
+        run<2, 2, 2, 4, 32, true, 2, 2>("2x2w 64x128 BK32 dbuf pipe2", A, B, bias, C, M, N, K);
+        run<2, 2, 4, 2, 32, false, 2, 2>("2x2w 128x64 BK32 single pipe2", A, B, bias, C, M, N, K);
+        run<2, 2, 2, 2, 16, false, 3, 2>("2x2w 64x64 BK16 single pipe2 minw3", A, B, bias, C, M, N, K);
     }
     return 0;
 }
