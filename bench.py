@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the short PCIe-inclusive measurement (N=1)")
     ap.add_argument("--gather-desc", action="store_true", help="also gather the 256-d descriptors to rank 0")
     args = ap.parse_args()
 
@@ -119,14 +120,20 @@ def main():
 
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("RFE_BENCH_BACKEND", "nccl")   # "gloo": functional check of the N>1 flow on a 1-GPU box
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from rover_slam_amd import capi, weights as Wt, synth, sharding
-    ctx = capi.Context(local_rank)
+    ctx = capi.Context(dev_index)
     wsp, wlg = Wt.make_superpoint(seed=7), Wt.make_lightglue(seed=11)
     ctx.set_weights(capi.KIND_SUPERPOINT, wsp)
     ctx.set_weights(capi.KIND_LIGHTGLUE, wlg)
@@ -177,6 +184,23 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    pcie = None
+    if world == 1 and not args.no_pcie:
+        # PCIe-inclusive variant (never the headline `value`): frames start in pinned host memory, results end there
+        h_frames = torch.from_numpy(frames_np).pin_memory()
+        h_out = [torch.empty_like(t, device="cpu").pin_memory() for t in (n, kxy, score, desc, S, pairs, ms)]
+        def step_pcie():
+            frames.copy_(h_frames, non_blocking=True)
+            step()
+            for h, t in zip(h_out, (n, kxy, score, desc, S, pairs, ms)):
+                h.copy_(t, non_blocking=True)
+        step_pcie(); fence()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            step_pcie()
+        fence()
+        pcie = FRAMES_PER_GPU * 3 / (time.perf_counter() - t1)
+
     if rank == 0:
         lens = n.cpu().numpy()
         total_frames = FRAMES_PER_GPU * world * args.steps
@@ -210,6 +234,9 @@ def main():
                          "flops_per_launch": fl},
             "stages": stages,
         }
+        if pcie is not None:
+            out["pcie_inclusive"] = {"value": round(pcie, 2), "unit": "frames/s",
+                                     "note": "same step with H2D of the 33 u8 frames and D2H of all results (descriptors included) per step, pinned host memory; not the headline value"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames_np, wsp, wlg)
         print(json.dumps(out))
