@@ -225,3 +225,67 @@ def test_full_size_properties(ctx):
     size, vn = ctx.match_fused(kp[0], kp[1], desc[0, :n[0]], desc[1, :n[1]], 480, 640)
     j = vn[vn >= 0]
     assert size == len(j) and len(np.unique(j)) == len(j)
+
+
+# ------------------------------------------------------------------ shapes / concurrency / errors
+def test_extract_752x480_stereo_size(ctx, oracle):
+    """EuRoC native size (BASELINE config 5): W = 752 is not a multiple of the 32-px conv tile."""
+    frames, _ = synth.make_frames(2, 480, 752, seed=752)
+    n, kxy, score, desc = ctx.extract(frames, kmax=1024)
+    w = Wt.make_superpoint(seed=7)
+    r = oracle.superpoint(w, frames[1], kmax=1024)
+    assert n[1] == r["n"] and np.array_equal(kxy[1], r["kxy"])
+    assert np.array_equal(score[1], r["score"]) and np.array_equal(desc[1], r["desc"])
+
+
+def test_two_contexts_concurrently(oracle):
+    """Left / right extractors of a stereo frame run in two threads with one session each in the reference
+    (src/Frame.cc:142-147): two ctxs on one device must work concurrently and agree with the oracle."""
+    import threading
+    from rover_slam_amd import capi
+    w = Wt.make_superpoint(seed=7)
+    frames, _ = synth.make_frames(2, 120, 160, seed=99)
+    out = [None, None]
+
+    def work(i):
+        c = capi.Context(0)
+        c.set_weights(capi.KIND_SUPERPOINT, w)
+        for _ in range(5):
+            out[i] = c.extract(frames[i], kmax=256)
+        c.close()
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for i in range(2):
+        r = oracle.superpoint(w, frames[i], kmax=256)
+        n, kxy, score, desc = out[i]
+        assert n[0] == r["n"] and np.array_equal(kxy[0], r["kxy"]) and np.array_equal(desc[0], r["desc"])
+
+
+def test_error_paths(ctx):
+    from rover_slam_amd import capi
+    c = capi.Context(0)
+    img = np.zeros((1, 64, 96), np.uint8)
+    with pytest.raises(capi.RfeError, match="weights not loaded"):
+        c.extract(img)
+    c.set_weights(capi.KIND_SUPERPOINT, Wt.make_superpoint(seed=7))
+    with pytest.raises(capi.RfeError, match="multiples of 8"):
+        c.extract(np.zeros((1, 60, 100), np.uint8))
+    with pytest.raises(capi.RfeError, match="wrong float count"):
+        c.set_weights(capi.KIND_LIGHTGLUE, np.zeros(10, np.float32))
+    with pytest.raises(capi.RfeError):
+        c.load_weights(sp_path="/nonexistent/sp.rfew")
+    # empty sides: no crash, no matches (reference would index an empty ORT output, lightglue_onnx.cpp:404)
+    size, vn = ctx.match_fused(np.zeros((0, 2), np.float32), np.zeros((5, 2), np.float32), np.zeros((0, 256), np.float32),
+                               np.zeros((5, 256), np.float32), 480, 640)
+    assert size == 0 and len(vn) == 0
+    c.close()
+
+
+def test_constant_image_no_crash(ctx, oracle):
+    """Constant images tie everywhere under the equality-based NMS (SURVEY 8d warns): still must agree with the oracle."""
+    img = np.full((1, 64, 96), 128, np.uint8)
+    n, kxy, score, desc = ctx.extract(img, kmax=64)
+    r = oracle.superpoint(Wt.make_superpoint(seed=7), img[0], kmax=64)
+    assert n[0] == r["n"] and np.array_equal(kxy[0], r["kxy"]) and np.array_equal(score[0], r["score"])
