@@ -120,6 +120,21 @@ int rfe_extract_match_stream_dev(rfe_ctx* ctx, const uint8_t* img_dev, int H, in
                                  int32_t* kxy_dev, float* score_dev, float* desc_dev,
                                  int32_t* S_dev, int32_t* pairs_dev, float* ms_dev);
 
+/* ---- sparse stereo matching ----
+ * Frame::ComputeStereoMatches (src/Frame.cc:1159-1446) for nLevels == 1: for every left keypoint, best right
+ * keypoint within +-2 rows and the disparity range [0, mbf/mb) by 256-d L2 distance
+ * (SPmatcher::DescriptorDistance_sp, src/Matchers/SPmatcher.cc:2184-2189; accepted below (TH_HIGH+TH_LOW)/2 = 1.3),
+ * 11x11 SAD refinement over +-5 px on the raw images, parabola sub-pixel fit, median outlier cut.
+ * kL/kR: pixel keypoints [N,2]/[Nr,2]; dL/dR: descriptors [N,256]/[Nr,256]; mb, mbf: baseline (m) and
+ * baseline*fx of the Frame.  Outputs mvuRight / mvDepth: [N], -1 = no match.  Deviation: left keypoints whose
+ * 11x11 patch leaves the image are skipped (the reference's cv::Mat::rowRange would throw). */
+int rfe_stereo_match(rfe_ctx* ctx, const uint8_t* imgL, const uint8_t* imgR, int H, int W, int stride,
+                     const float* kL, int N, const float* kR, int Nr, const float* dL, const float* dR,
+                     float mb, float mbf, float* uRight, float* depth);
+int rfe_stereo_match_dev(rfe_ctx* ctx, const uint8_t* imgL, const uint8_t* imgR, int H, int W, int stride,
+                         const float* kL, int N, const float* kR, int Nr, const float* dL, const float* dR,
+                         float mb, float mbf, float* uRight, float* depth);
+
 /* ---- per-stage timing (hipEvent on the ctx stream), for bench.py's roofline object ----
  * Enable, run, then read back: names is a ';'-separated list of stage names, ms / calls the
  * accumulated time and launch count per stage since the last reset. */

@@ -50,6 +50,7 @@ def lib():
         L.rfo_normalize_keypoints.argtypes = [fp, C.c_int, C.c_int, C.c_int, fp]
         L.rfo_postprocess_fused.restype = C.c_int
         L.rfo_postprocess_fused.argtypes = [ip, fp, C.c_int, C.c_float, ip, C.c_int]
+        L.rfo_stereo_match.argtypes = [u8p, u8p, C.c_int, C.c_int, fp, C.c_int, fp, C.c_int, fp, fp, C.c_float, C.c_float, fp, fp]
         _lib = L
     return _lib
 
@@ -193,3 +194,16 @@ def postprocess_fused(pairs, ms, match_thresh, M):
     size = lib().rfo_postprocess_fused(pairs.ctypes.data_as(C.POINTER(C.c_int32)), _opt(ms), int(ms.shape[0]),
                                        match_thresh, vn.ctypes.data_as(C.POINTER(C.c_int32)), M)
     return int(size), vn
+
+
+def stereo_match(img_l, img_r, k_l, k_r, d_l, d_r, mb, mbf):
+    """Frame::ComputeStereoMatches restatement.  k_*: [N,2] pixel keypoints; returns (uRight[N], depth[N])."""
+    il = np.ascontiguousarray(img_l, np.uint8); ir = np.ascontiguousarray(img_r, np.uint8)
+    H, W = il.shape
+    kl, klp = _f(k_l); kr, krp = _f(k_r)
+    dl, dlp = _f(d_l); dr, drp = _f(d_r)
+    N, Nr = kl.shape[0], kr.shape[0]
+    u = np.empty((max(N, 1),), np.float32); d = np.empty((max(N, 1),), np.float32)
+    lib().rfo_stereo_match(il.ctypes.data_as(C.POINTER(C.c_uint8)), ir.ctypes.data_as(C.POINTER(C.c_uint8)), H, W,
+                           klp, N, krp, Nr, dlp, drp, mb, mbf, _opt(u), _opt(d))
+    return u[:N], d[:N]

@@ -591,3 +591,102 @@ int rfo_postprocess_fused(const int32_t* pairs, const float* ms, int S, float ma
         if (ms[i] > match_thresh) { ++size; vnMatches12[pairs[2 * i]] = pairs[2 * i + 1]; }
     return size;
 }
+
+
+/* ================================================================== */
+/* Sparse stereo matching: restatement of Frame::ComputeStereoMatches  */
+/* (reference src/Frame.cc:1159-1446) for nLevels == 1 (octave 0,      */
+/* scale 1), the only configuration the SuperPoint path supports.      */
+/* Canonical descriptor distance (DescriptorDistance_sp,               */
+/* src/Matchers/SPmatcher.cc:2184-2189 = cv::norm L2): float           */
+/* differences, double accumulation; lane l owns dims 4l..4l+3 then an */
+/* xor butterfly 32..1 (fixed order shared with the HIP kernel).       */
+/* Deviation: keypoints whose 11x11 patch leaves the image rows are    */
+/* skipped (the reference's rowRange would throw a cv::Exception).     */
+/* ================================================================== */
+static float rfo_desc_dist(const float* a, const float* b) {
+    double p[64];
+    for (int l = 0; l < 64; ++l) {
+        double s = 0.0;
+        for (int e = 0; e < 4; ++e) { float d = a[4 * l + e] - b[4 * l + e]; s += (double)d * (double)d; }
+        p[l] = s;
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        double q[64];
+        for (int l = 0; l < 64; ++l) q[l] = p[l] + p[l ^ off];
+        memcpy(p, q, sizeof(p));
+    }
+    return (float)sqrt(p[0]);
+}
+
+typedef struct { int d; int i; } sad_idx_t;
+static int sad_idx_cmp(const void* a, const void* b) {
+    const sad_idx_t* x = (const sad_idx_t*)a; const sad_idx_t* y = (const sad_idx_t*)b;
+    if (x->d != y->d) return x->d < y->d ? -1 : 1;
+    return (x->i > y->i) - (x->i < y->i);
+}
+
+void rfo_stereo_match(const uint8_t* imgL, const uint8_t* imgR, int H, int W, const float* kL, int N,
+                      const float* kR, int Nr, const float* dL, const float* dR, float mb, float mbf,
+                      float* uRight, float* depth) {
+    const float TH_HIGH = 1.4f, TH_LOW = 1.2f;
+    const float thOrbDist = (TH_HIGH + TH_LOW) / 2;
+    const float minD = 0, maxD = mbf / mb;
+    sad_idx_t* v = (sad_idx_t*)malloc(sizeof(sad_idx_t) * (size_t)(N > 0 ? N : 1));
+    int nv = 0;
+    for (int iL = 0; iL < N; ++iL) {
+        uRight[iL] = -1.0f; depth[iL] = -1.0f;
+        const float uL = kL[2 * iL], vL = kL[2 * iL + 1];
+        const float minU = uL - maxD, maxU = uL - minD;
+        if (maxU < 0) continue;
+        float bestDist = TH_HIGH; int bestIdxR = -1;
+        for (int iR = 0; iR < Nr; ++iR) {
+            const float uR = kR[2 * iR], yR = kR[2 * iR + 1];
+            /* row table: right keypoint iR is listed in rows floor(y-2) .. ceil(y+2) (Frame.cc:1207-1218) */
+            const int row = (int)vL;
+            if (row < (int)floorf(yR - 2.0f) || row > (int)ceilf(yR + 2.0f)) continue;
+            if (uR >= minU && uR <= maxU) {
+                const float dist = rfo_desc_dist(dL + (size_t)iL * 256, dR + (size_t)iR * 256);
+                if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+            }
+        }
+        if (!(bestDist < thOrbDist) || bestIdxR < 0) continue;
+        const float uR0 = kR[2 * bestIdxR];
+        const int su = (int)roundf(uL), sv = (int)roundf(vL), sr = (int)roundf(uR0);
+        const int w = 5, Lh = 5;
+        if (sr - Lh - w < 0 || sr + Lh + w + 1 >= W) continue;                 /* Frame.cc:1325-1330 */
+        if (sv - w < 0 || sv + w >= H || su - w < 0 || su + w >= W) continue;   /* see deviation note */
+        float vd[11]; float best = 2147483647.0f; int bestinc = 0;
+        for (int inc = -Lh; inc <= Lh; ++inc) {
+            int sad = 0;
+            for (int y = -w; y <= w; ++y)
+                for (int x = -w; x <= w; ++x)
+                    sad += abs((int)imgL[(size_t)(sv + y) * W + su + x] - (int)imgR[(size_t)(sv + y) * W + sr + inc + x]);
+            const float dist = (float)sad;
+            if (dist < best) { best = dist; bestinc = inc; }
+            vd[Lh + inc] = dist;
+        }
+        if (bestinc == -Lh || bestinc == Lh) continue;
+        const float d1 = vd[Lh + bestinc - 1], d2 = vd[Lh + bestinc], d3 = vd[Lh + bestinc + 1];
+        const float deltaR = (d1 - d3) / (2.0f * (d1 + d3 - 2.0f * d2));
+        if (deltaR < -1 || deltaR > 1) continue;
+        float bestuR = 1.0f * ((float)sr + (float)bestinc + deltaR);
+        float disparity = uL - bestuR;
+        if (disparity >= minD && disparity < maxD) {
+            if (disparity <= 0) { disparity = 0.01f; bestuR = uL - 0.01f; }
+            depth[iL] = mbf / disparity;
+            uRight[iL] = bestuR;
+            v[nv].d = (int)best; v[nv].i = iL; ++nv;
+        }
+    }
+    if (nv > 0) {
+        qsort(v, nv, sizeof(sad_idx_t), sad_idx_cmp);
+        const float median = (float)v[nv / 2].d;
+        const float thDist = 1.5f * 1.4f * median;
+        for (int i = nv - 1; i >= 0; --i) {
+            if ((float)v[i].d < thDist) break;
+            uRight[v[i].i] = -1; depth[v[i].i] = -1;
+        }
+    }
+    free(v);
+}

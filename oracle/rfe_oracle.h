@@ -71,6 +71,11 @@ void rfo_normalize_keypoints(const float* kxy, int n, int h, int w, float* out);
 int  rfo_postprocess_fused(const int32_t* pairs, const float* ms, int S, float match_thresh,
                            int32_t* vnMatches12, int M);                       /* lightglue_onnx.cpp:437-453 */
 
+/* sparse stereo matching, Frame::ComputeStereoMatches (src/Frame.cc:1159-1446), nLevels == 1 */
+void rfo_stereo_match(const uint8_t* imgL, const uint8_t* imgR, int H, int W, const float* kL, int N,
+                      const float* kR, int Nr, const float* dL, const float* dR, float mb, float mbf,
+                      float* uRight, float* depth);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,7 +15,7 @@ EXPORTS = [
     "rfe_init", "rfe_destroy", "rfe_last_error", "rfe_version", "rfe_load_weights", "rfe_set_weights",
     "rfe_weight_count", "rfe_set_stream", "rfe_synchronize", "rfe_malloc", "rfe_free", "rfe_memcpy_h2d",
     "rfe_memcpy_d2h", "rfe_extract_u8", "rfe_extract_u8_dev", "rfe_match", "rfe_match_dev", "rfe_match_fused",
-    "rfe_extract_match_stream_dev", "rfe_profile_enable", "rfe_profile_reset", "rfe_profile_read",
+    "rfe_extract_match_stream_dev", "rfe_stereo_match", "rfe_stereo_match_dev", "rfe_profile_enable", "rfe_profile_reset", "rfe_profile_read",
     "rfe_k_conv3x3", "rfe_k_linear", "rfe_k_scoremap", "rfe_k_lightglue_taps",
 ]
 
@@ -52,6 +52,9 @@ lib.rfe_match_fused.argtypes = [C.c_void_p, _fp, C.c_int, _fp, C.c_int, _fp, _fp
                                 C.c_float, _ip]
 lib.rfe_extract_match_stream_dev.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                              C.c_float, _ip, _ip, _fp, _fp, _ip, _ip, _fp]
+_st = [C.c_void_p, _u8p, _u8p, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_float, C.c_float, _fp, _fp]
+lib.rfe_stereo_match.argtypes = _st
+lib.rfe_stereo_match_dev.argtypes = _st
 lib.rfe_profile_enable.argtypes = [C.c_void_p, C.c_int]
 lib.rfe_profile_reset.argtypes = [C.c_void_p]
 lib.rfe_profile_read.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
@@ -188,6 +191,18 @@ class Context:
         size = self._chk(lib.rfe_match_fused(self.h, kpts0.ctypes.data, M, kpts1.ctypes.data, N, desc0.ctypes.data,
                                              desc1.ctypes.data, rows, cols, filter_thr, match_thresh, vn.ctypes.data))
         return size, vn[:M]
+
+    def stereo_match(self, img_l, img_r, k_l, k_r, d_l, d_r, mb, mbf):
+        """Frame::ComputeStereoMatches on host arrays; returns (uRight[N], depth[N])."""
+        il = np.ascontiguousarray(img_l, np.uint8); ir = np.ascontiguousarray(img_r, np.uint8)
+        kl = np.ascontiguousarray(k_l, np.float32).reshape(-1, 2); kr = np.ascontiguousarray(k_r, np.float32).reshape(-1, 2)
+        dl = np.ascontiguousarray(d_l, np.float32); dr = np.ascontiguousarray(d_r, np.float32)
+        H, W = il.shape
+        N, Nr = kl.shape[0], kr.shape[0]
+        u = np.full((max(N, 1),), -1, np.float32); z = np.full((max(N, 1),), -1, np.float32)
+        self._chk(lib.rfe_stereo_match(self.h, il.ctypes.data, ir.ctypes.data, H, W, W, kl.ctypes.data, N, kr.ctypes.data, Nr,
+                                       dl.ctypes.data, dr.ctypes.data, mb, mbf, u.ctypes.data, z.ctypes.data))
+        return u[:N], z[:N]
 
     # ---- profiling
     def profile(self, on=True):

@@ -616,6 +616,57 @@ extern "C" int rfe_extract_match_stream_dev(rfe_ctx* c, const uint8_t* img, int 
 }
 
 // =====================================================================================
+// sparse stereo matching (Frame::ComputeStereoMatches, src/Frame.cc:1159-1446)
+// =====================================================================================
+extern "C" int rfe_stereo_match_dev(rfe_ctx* c, const uint8_t* imgL, const uint8_t* imgR, int H, int W, int stride,
+                                    const float* kL, int N, const float* kR, int Nr, const float* dL, const float* dR,
+                                    float mb, float mbf, float* uRight, float* depth) {
+    if (!c) return RFE_ERR_INVALID;
+    if (N < 0 || Nr < 0 || N > 4096 || H <= 0 || W <= 0 || stride < W || !(mb > 0.f)) return fail(c, RFE_ERR_INVALID, "stereo_match: bad argument (0 <= N <= 4096, mb > 0, stride >= W)");
+    if (N == 0) return RFE_OK;
+    if (!imgL || !imgR || !kL || !dL || !uRight || !depth || (Nr > 0 && (!kR || !dR))) return fail(c, RFE_ERR_INVALID, "stereo_match: null pointer");
+    RFE_HIP(c, hipSetDevice(c->device));
+    int rc = ensure_ws(c, &c->ws_tmp, &c->ws_tmp_bytes, al((size_t)N * 4));
+    if (rc) return rc;
+    ProfScope p(c, "stereo_match");
+    launch_stereo_match(c->stream, imgL, imgR, H, W, stride, kL, N, kR, Nr, dL, dR, mb, mbf, uRight, depth, (int32_t*)c->ws_tmp);
+    RFE_HIP(c, hipGetLastError());
+    return RFE_OK;
+}
+
+extern "C" int rfe_stereo_match(rfe_ctx* c, const uint8_t* imgL, const uint8_t* imgR, int H, int W, int stride,
+                                const float* kL, int N, const float* kR, int Nr, const float* dL, const float* dR,
+                                float mb, float mbf, float* uRight, float* depth) {
+    if (!c) return RFE_ERR_INVALID;
+    if (N < 0 || Nr < 0 || N > 4096 || H <= 0 || W <= 0 || stride < W) return fail(c, RFE_ERR_INVALID, "stereo_match: bad argument");
+    if (N == 0) return RFE_OK;
+    RFE_HIP(c, hipSetDevice(c->device));
+    const size_t bi = al((size_t)H * stride), bkl = al((size_t)N * 8), bkr = al((size_t)std::max(Nr, 1) * 8),
+                 bdl = al((size_t)N * 1024), bdr = al((size_t)std::max(Nr, 1) * 1024), bo = al((size_t)N * 4);
+    int rc = ensure_ws(c, &c->ws_io, &c->ws_io_bytes, 2 * bi + bkl + bkr + bdl + bdr + 2 * bo);
+    if (rc) return rc;
+    char* p = (char*)c->ws_io;
+    uint8_t* dIL = (uint8_t*)p; p += bi; uint8_t* dIR = (uint8_t*)p; p += bi;
+    float* dkl = (float*)p; p += bkl; float* dkr = (float*)p; p += bkr; float* ddl = (float*)p; p += bdl; float* ddr = (float*)p; p += bdr;
+    float* du = (float*)p; p += bo; float* dz = (float*)p;
+    hipStream_t s = c->stream;
+    RFE_HIP(c, hipMemcpyAsync(dIL, imgL, (size_t)H * stride, hipMemcpyHostToDevice, s));
+    RFE_HIP(c, hipMemcpyAsync(dIR, imgR, (size_t)H * stride, hipMemcpyHostToDevice, s));
+    RFE_HIP(c, hipMemcpyAsync(dkl, kL, (size_t)N * 8, hipMemcpyHostToDevice, s));
+    RFE_HIP(c, hipMemcpyAsync(ddl, dL, (size_t)N * 1024, hipMemcpyHostToDevice, s));
+    if (Nr > 0) {
+        RFE_HIP(c, hipMemcpyAsync(dkr, kR, (size_t)Nr * 8, hipMemcpyHostToDevice, s));
+        RFE_HIP(c, hipMemcpyAsync(ddr, dR, (size_t)Nr * 1024, hipMemcpyHostToDevice, s));
+    }
+    if ((rc = rfe_stereo_match_dev(c, dIL, dIR, H, W, stride, dkl, N, dkr, Nr, ddl, ddr, mb, mbf, du, dz))) return rc;
+    RFE_HIP(c, hipMemcpyAsync(uRight, du, (size_t)N * 4, hipMemcpyDeviceToHost, s));
+    RFE_HIP(c, hipMemcpyAsync(depth, dz, (size_t)N * 4, hipMemcpyDeviceToHost, s));
+    RFE_HIP(c, hipStreamSynchronize(s));
+    prof_collect(c);
+    return RFE_OK;
+}
+
+// =====================================================================================
 // profiling
 // =====================================================================================
 extern "C" int rfe_profile_enable(rfe_ctx* c, int on) { if (!c) return RFE_ERR_INVALID; c->prof = on != 0; return RFE_OK; }

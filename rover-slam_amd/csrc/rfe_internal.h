@@ -145,4 +145,9 @@ void launch_lg_matchability(hipStream_t s, const float* x, const float* w, const
 void launch_copy_f32(hipStream_t s, const float* src, float* dst, int64_t n);
 void launch_normalize_kpts(hipStream_t s, const int32_t* kxy, int64_t n, int rows, int cols, float* out);
 
+// stereo.hip
+void launch_stereo_match(hipStream_t s, const uint8_t* imgL, const uint8_t* imgR, int H, int W, int stride,
+                         const float* kL, int N, const float* kR, int Nr, const float* dL, const float* dR, float mb,
+                         float mbf, float* uRight, float* depth, int32_t* sadv);
+
 }  // namespace rfe

@@ -10,11 +10,18 @@
 #include "Matchers/SPmatcher.h"
 #include "SuperPoint.h"
 #include "super_glue.h"
+#include "rfe/stereo_match.h"
 
 struct MockFrame {                      // the three members SPmatcher::MatchingPoints_onnx(Frame&,Frame&) reads
     std::vector<cv::KeyPoint> mvKeys;
     cv::Mat mDescriptors;
     cv::Mat imgLeft;
+};
+struct MockStereoFrame {                // members Frame::ComputeStereoMatches uses (src/Frame.cc:1159-1446)
+    std::vector<cv::KeyPoint> mvKeys, mvKeysRight;
+    cv::Mat mDescriptors, mDescriptorsRight, imgLeft, imgRight;
+    float mb = 0.11f, mbf = 0.11f * 435.0f;
+    std::vector<float> mvuRight, mvDepth;
 };
 
 static void put(FILE* f, const void* p, size_t n) { fwrite(p, 1, n, f); }
@@ -40,6 +47,12 @@ int main(int argc, char** argv) {
     const int sFrame = matcher.MatchingPoints_onnx(f[0], f[1], vnFrame);                                    // true image size
     const int sQuirk = matcher.MatchingPoints_onnx(f[0].mvKeys, f[1].mvKeys, f[0].mDescriptors, f[1].mDescriptors, vnQuirk);  // 300x400
 
+    // the two frames again as the left / right views of one stereo frame
+    MockStereoFrame sf;
+    sf.mvKeys = f[0].mvKeys; sf.mvKeysRight = f[1].mvKeys; sf.mDescriptors = f[0].mDescriptors; sf.mDescriptorsRight = f[1].mDescriptors;
+    sf.imgLeft = f[0].imgLeft; sf.imgRight = f[1].imgLeft;
+    if (ORB_SLAM3::ComputeStereoMatches_rfe(ext.featureExtractor->ExtractorSession, sf) != 0) return 5;
+
     FILE* fo = fopen(argv[4], "wb");
     for (int i = 0; i < 2; ++i) {
         const int32_t n = (int32_t)f[i].mvKeys.size();
@@ -50,6 +63,7 @@ int main(int argc, char** argv) {
     const int32_t s[2] = {sFrame, sQuirk}, m = (int32_t)vnFrame.size();
     put(fo, s, 8); put(fo, &m, 4);
     put(fo, vnFrame.data(), (size_t)m * 4); put(fo, vnQuirk.data(), (size_t)m * 4);
+    put(fo, sf.mvuRight.data(), sf.mvuRight.size() * 4); put(fo, sf.mvDepth.data(), sf.mvDepth.size() * 4);
     fclose(fo);
     printf("shim_driver: %d / %d keypoints, %d matches (frame overload), %d (300x400 overload)\n",
            (int)f[0].mvKeys.size(), (int)f[1].mvKeys.size(), sFrame, sQuirk);

@@ -43,7 +43,9 @@ def test_cpp_shims_match_oracle(tmp_path, oracle):
         ext.append((n, kp, desc))
     s_frame, s_quirk, m = struct.unpack_from("<iii", buf, off); off += 12
     vn_frame = np.frombuffer(buf, np.int32, m, off); off += 4 * m
-    vn_quirk = np.frombuffer(buf, np.int32, m, off)
+    vn_quirk = np.frombuffer(buf, np.int32, m, off); off += 4 * m
+    u_right = np.frombuffer(buf, np.float32, m, off); off += 4 * m
+    z_depth = np.frombuffer(buf, np.float32, m, off)
     ref = [oracle.superpoint(wsp, frames[i], kmax=200) for i in range(2)]
     for (n, kp, desc), r_ in zip(ext, ref):
         assert n == r_["n"]
@@ -57,3 +59,6 @@ def test_cpp_shims_match_oracle(tmp_path, oracle):
         lg = oracle.lightglue(wlg, oracle.normalize_keypoints(kp0, rows, cols), oracle.normalize_keypoints(kp1, rows, cols), d0, d1)
         s_ref, vn_ref = oracle.postprocess_fused(lg["pairs"], lg["ms"], 0.0, len(kp0))
         assert s_got == s_ref and np.array_equal(vn_got, vn_ref)
+    # Frame::ComputeStereoMatches through include/rfe/stereo_match.h (frames 0 / 1 as left / right view)
+    u_ref, z_ref = oracle.stereo_match(frames[0], frames[1], kp0, kp1, d0, d1, 0.11, 0.11 * 435.0)
+    assert np.array_equal(u_right, u_ref) and np.array_equal(z_depth, z_ref)
