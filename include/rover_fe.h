@@ -135,6 +135,14 @@ int rfe_stereo_match_dev(rfe_ctx* ctx, const uint8_t* imgL, const uint8_t* imgR,
                          const float* kL, int N, const float* kR, int Nr, const float* dL, const float* dR,
                          float mb, float mbf, float* uRight, float* depth);
 
+/* ---- descriptor helpers for the callers' classic searches, host pointers ----
+ * rfe_l2_distance_matrix: out[i*N + j] = SPmatcher::DescriptorDistance_sp(a_i, b_j)
+ *   (src/Matchers/SPmatcher.cc:2184-2189) for all pairs of a [M,256] x b [N,256]; the candidate lists of
+ *   SearchByProjection / Fuse (SPmatcher.cc:1170-1354, 49-357) stay with the caller.
+ * rfe_binarize_descriptors: Frame::binarize_descriptors (src/Frame.cc:1034-1043): out u8 [rows,256] = desc > 0. */
+int rfe_l2_distance_matrix(rfe_ctx* ctx, const float* a, int M, const float* b, int N, float* out);
+int rfe_binarize_descriptors(rfe_ctx* ctx, const float* desc, int rows, uint8_t* out);
+
 /* ---- per-stage timing (hipEvent on the ctx stream), for bench.py's roofline object ----
  * Enable, run, then read back: names is a ';'-separated list of stage names, ms / calls the
  * accumulated time and launch count per stage since the last reset. */

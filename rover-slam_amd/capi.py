@@ -15,7 +15,8 @@ EXPORTS = [
     "rfe_init", "rfe_destroy", "rfe_last_error", "rfe_version", "rfe_load_weights", "rfe_set_weights",
     "rfe_weight_count", "rfe_set_stream", "rfe_synchronize", "rfe_malloc", "rfe_free", "rfe_memcpy_h2d",
     "rfe_memcpy_d2h", "rfe_extract_u8", "rfe_extract_u8_dev", "rfe_match", "rfe_match_dev", "rfe_match_fused",
-    "rfe_extract_match_stream_dev", "rfe_stereo_match", "rfe_stereo_match_dev", "rfe_profile_enable", "rfe_profile_reset", "rfe_profile_read",
+    "rfe_extract_match_stream_dev", "rfe_stereo_match", "rfe_stereo_match_dev", "rfe_l2_distance_matrix", "rfe_binarize_descriptors",
+    "rfe_profile_enable", "rfe_profile_reset", "rfe_profile_read",
     "rfe_k_conv3x3", "rfe_k_linear", "rfe_k_scoremap", "rfe_k_lightglue_taps",
 ]
 
@@ -55,6 +56,8 @@ lib.rfe_extract_match_stream_dev.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int,
 _st = [C.c_void_p, _u8p, _u8p, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_float, C.c_float, _fp, _fp]
 lib.rfe_stereo_match.argtypes = _st
 lib.rfe_stereo_match_dev.argtypes = _st
+lib.rfe_l2_distance_matrix.argtypes = [C.c_void_p, _fp, C.c_int, _fp, C.c_int, _fp]
+lib.rfe_binarize_descriptors.argtypes = [C.c_void_p, _fp, C.c_int, _u8p]
 lib.rfe_profile_enable.argtypes = [C.c_void_p, C.c_int]
 lib.rfe_profile_reset.argtypes = [C.c_void_p]
 lib.rfe_profile_read.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]

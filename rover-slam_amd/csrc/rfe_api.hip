@@ -666,6 +666,42 @@ extern "C" int rfe_stereo_match(rfe_ctx* c, const uint8_t* imgL, const uint8_t* 
     return RFE_OK;
 }
 
+// all-pairs DescriptorDistance_sp and descriptor binarisation, host pointers
+extern "C" int rfe_l2_distance_matrix(rfe_ctx* c, const float* a, int M, const float* b, int N, float* out) {
+    if (!c) return RFE_ERR_INVALID;
+    if (M < 0 || N < 0 || (M > 0 && N > 0 && (!a || !b || !out))) return fail(c, RFE_ERR_INVALID, "l2_distance_matrix: bad argument");
+    if (M == 0 || N == 0) return RFE_OK;
+    RFE_HIP(c, hipSetDevice(c->device));
+    const size_t ba = al((size_t)M * 1024), bb = al((size_t)N * 1024), bo = al((size_t)M * N * 4);
+    int rc = ensure_ws(c, &c->ws_io, &c->ws_io_bytes, ba + bb + bo);
+    if (rc) return rc;
+    float* da = (float*)c->ws_io; float* db = (float*)((char*)c->ws_io + ba); float* dout = (float*)((char*)c->ws_io + ba + bb);
+    RFE_HIP(c, hipMemcpyAsync(da, a, (size_t)M * 1024, hipMemcpyHostToDevice, c->stream));
+    RFE_HIP(c, hipMemcpyAsync(db, b, (size_t)N * 1024, hipMemcpyHostToDevice, c->stream));
+    launch_l2_matrix(c->stream, da, M, db, N, dout);
+    RFE_HIP(c, hipGetLastError());
+    RFE_HIP(c, hipMemcpyAsync(out, dout, (size_t)M * N * 4, hipMemcpyDeviceToHost, c->stream));
+    RFE_HIP(c, hipStreamSynchronize(c->stream));
+    return RFE_OK;
+}
+
+extern "C" int rfe_binarize_descriptors(rfe_ctx* c, const float* desc, int rows, uint8_t* out) {
+    if (!c) return RFE_ERR_INVALID;
+    if (rows < 0 || (rows > 0 && (!desc || !out))) return fail(c, RFE_ERR_INVALID, "binarize_descriptors: bad argument");
+    if (rows == 0) return RFE_OK;
+    RFE_HIP(c, hipSetDevice(c->device));
+    const size_t bd = al((size_t)rows * 1024), bo = al((size_t)rows * 256);
+    int rc = ensure_ws(c, &c->ws_io, &c->ws_io_bytes, bd + bo);
+    if (rc) return rc;
+    float* dd = (float*)c->ws_io; uint8_t* dout = (uint8_t*)c->ws_io + bd;
+    RFE_HIP(c, hipMemcpyAsync(dd, desc, (size_t)rows * 1024, hipMemcpyHostToDevice, c->stream));
+    launch_binarize(c->stream, dd, rows, dout);
+    RFE_HIP(c, hipGetLastError());
+    RFE_HIP(c, hipMemcpyAsync(out, dout, (size_t)rows * 256, hipMemcpyDeviceToHost, c->stream));
+    RFE_HIP(c, hipStreamSynchronize(c->stream));
+    return RFE_OK;
+}
+
 // =====================================================================================
 // profiling
 // =====================================================================================

@@ -150,4 +150,7 @@ void launch_stereo_match(hipStream_t s, const uint8_t* imgL, const uint8_t* imgR
                          const float* kL, int N, const float* kR, int Nr, const float* dL, const float* dR, float mb,
                          float mbf, float* uRight, float* depth, int32_t* sadv);
 
+void launch_l2_matrix(hipStream_t s, const float* a, int M, const float* b, int N, float* out);
+void launch_binarize(hipStream_t s, const float* d, int64_t rows, uint8_t* out);
+
 }  // namespace rfe

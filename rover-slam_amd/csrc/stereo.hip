@@ -145,4 +145,43 @@ void launch_stereo_match(hipStream_t s, const uint8_t* imgL, const uint8_t* imgR
     hipLaunchKernelGGL(stereo_filter_kernel, dim3(1), dim3(1024), (size_t)P2 * 8, s, N, P2, sadv, uRight, depth);
 }
 
+// ------------------------------------------------------------------------------------------
+// all-pairs descriptor distances D[i][j] = DescriptorDistance_sp(a_i, b_j)
+// (src/Matchers/SPmatcher.cc:2184-2189) for the projection / fuse searches, whose candidate lists stay
+// on the CPU (SPmatcher.cc:1170-1354, 49-357): the CPU loop reads D instead of calling cv::norm.
+// One wave per row i, same canonical arithmetic as the stereo kernel (bit-exact vs the oracle).
+__global__ __launch_bounds__(256) void l2_matrix_kernel(const float* __restrict__ a, int M, const float* __restrict__ b, int N,
+                                                        float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= M) return;
+    const float4 av = reinterpret_cast<const float4*>(a + (size_t)i * 256)[lane];
+    for (int j = blockIdx.y; j < N; j += gridDim.y) {
+        const float4 bv = reinterpret_cast<const float4*>(b + (size_t)j * 256)[lane];
+        const float d0 = av.x - bv.x, d1 = av.y - bv.y, d2 = av.z - bv.z, d3 = av.w - bv.w;
+        double p = 0.0;
+        p += (double)d0 * (double)d0; p += (double)d1 * (double)d1; p += (double)d2 * (double)d2; p += (double)d3 * (double)d3;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) p = p + __shfl_xor(p, off);
+        if (lane == 0) out[(size_t)i * N + j] = (float)sqrt(p);
+    }
+}
+void launch_l2_matrix(hipStream_t s, const float* a, int M, const float* b, int N, float* out) {
+    if (M <= 0 || N <= 0) return;
+    hipLaunchKernelGGL(l2_matrix_kernel, dim3((M + 3) / 4, N < 64 ? N : 64), dim3(256), 0, s, a, M, b, N, out);
+}
+
+// SURVEY 8(f) N4 (GPU half): Frame::binarize_descriptors (src/Frame.cc:1034-1043): out = desc > 0 ? 1 : 0, u8 [n,256]
+__global__ void binarize_kernel(const float* __restrict__ d, int64_t n, uint8_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 v = reinterpret_cast<const float4*>(d)[i];
+    reinterpret_cast<uchar4*>(out)[i] = make_uchar4(v.x > 0.f, v.y > 0.f, v.z > 0.f, v.w > 0.f);
+}
+void launch_binarize(hipStream_t s, const float* d, int64_t rows, uint8_t* out) {
+    const int64_t n4 = rows * 64;
+    if (n4 <= 0) return;
+    hipLaunchKernelGGL(binarize_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, d, n4, out);
+}
+
 }  // namespace rfe

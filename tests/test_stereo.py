@@ -63,3 +63,23 @@ def test_stereo_gpu_vs_oracle(oracle, H, W, disp):
     u0, _ = ctx.stereo_match(left, right, kl, kr[:0], dl, dr[:0], mb, mbf)
     assert (u0 == -1).all()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_distance_matrix_and_binarize():
+    """SURVEY 8(f) N3 / N4 helpers: all-pairs DescriptorDistance_sp and Frame::binarize_descriptors."""
+    from rover_slam_amd import capi
+    ctx = capi.Context(0)
+    rng = np.random.default_rng(4)
+    a = rng.standard_normal((37, 256)).astype(np.float32); a /= np.linalg.norm(a, axis=1, keepdims=True)
+    b = rng.standard_normal((101, 256)).astype(np.float32); b /= np.linalg.norm(b, axis=1, keepdims=True)
+    out = np.empty((37, 101), np.float32)
+    ctx._chk(capi.lib.rfe_l2_distance_matrix(ctx.h, a.ctypes.data, 37, b.ctypes.data, 101, out.ctypes.data))
+    ref = np.linalg.norm(a[:, None, :].astype(np.float64) - b[None].astype(np.float64), axis=2)
+    assert np.abs(out - ref).max() < 1e-6
+    # the thresholds the reference applies to these distances (TH_LOW / TH_HIGH, SPmatcher.cc:13-14)
+    assert ((out < 1.2) == (ref < 1.2)).all() and ((out < 1.4) == (ref < 1.4)).all()
+    bits = np.empty((37, 256), np.uint8)
+    ctx._chk(capi.lib.rfe_binarize_descriptors(ctx.h, a.ctypes.data, 37, bits.ctypes.data))
+    assert np.array_equal(bits, (a > 0).astype(np.uint8))
+    ctx.close()
