@@ -432,42 +432,51 @@ void lg_carve(void* ws, int P, int L, LgBuffers& b) {
 }
 
 // x + ffn([x | msg]) in place on b.x
-void lg_ffn(rfe_ctx* c, LgBuffers& b, int rows, const float* w1, const float* b1, const float* g, const float* be,
+void lg_ffn(rfe_ctx* c, LgBuffers& b, float* x, int rows, const float* w1, const float* b1, const float* g, const float* be,
             const float* w2, const float* b2) {
     hipStream_t s = c->stream;
     { ProfScope p(c, "lg_ffn1");
-      GemmArgs a = gemm_plain(b.x, 256, w1, 512, b1, b.h, 512, rows, 512, 512);
+      GemmArgs a = gemm_plain(x, 256, w1, 512, b1, b.h, 512, rows, 512, 512);
       a.A2 = b.msg; a.lda2 = 256; a.K1 = 256;
       launch_gemm_nt(s, a); }
     { ProfScope p(c, "lg_ln_gelu"); launch_lg_ln_gelu(s, b.h, g, be, rows); }
     { ProfScope p(c, "lg_ffn2");
-      GemmArgs a = gemm_plain(b.h, 512, w2, 512, b2, b.x, 256, rows, 256, 512);
-      a.R = b.x; a.ldr = 256;
+      GemmArgs a = gemm_plain(b.h, 512, w2, 512, b2, x, 256, rows, 256, 512);
+      a.R = x; a.ldr = 256;
       launch_gemm_nt(s, a); }
 }
 
-// runs the 9 layers + assignment on already staged b.x / b.kn / b.lens / b.kvmap
+// self block on `nseq` sequences of L tokens held in x (in place); scratch: b.qkv, b.ctx, b.msg, b.h
+void lg_self_block(rfe_ctx* c, LgBuffers& b, const LgLayerDev& Lw, float* x, const float* cs, const float* sn,
+                   const int32_t* lens, int nseq, int L) {
+    hipStream_t s = c->stream;
+    const int rows = nseq * L;
+    { ProfScope p(c, "lg_qkv");   // q,k,v = Wqkv x + b with the rotary applied to q,k in the GEMM epilogue
+      GemmArgs a = gemm_plain(x, 256, Lw.wqkv, 256, Lw.bqkv, b.qkv, 768, rows, 768, 256);
+      a.rope_cs = cs; a.rope_sn = sn; a.rope_ncols = 512;
+      launch_gemm_nt(s, a); }
+    { ProfScope p(c, "lg_attention"); launch_lg_attention(s, b.qkv, b.qkv + 256, b.qkv + 512, 768, b.ctx, nseq, L, L, lens, lens, nullptr); }
+    { ProfScope p(c, "lg_proj"); launch_gemm_nt(s, gemm_plain(b.ctx, 256, Lw.wo, 256, Lw.bo, b.msg, 256, rows, 256, 256)); }
+    lg_ffn(c, b, x, rows, Lw.w1, Lw.b1, Lw.lng, Lw.lnb, Lw.w2, Lw.b2);
+}
+
+// runs the 9 layers + assignment on already staged b.x / b.kn / b.lens / b.kvmap.
+// first_self_done: b.x already holds the output of layer 0's self block and b.cs / b.sn the rotary tables
+// (stream mode computes them once per FRAME instead of once per pair side).
 int lg_forward(rfe_ctx* c, LgBuffers& b, int P, int L, float thr, int cap, int32_t* S, int32_t* pairs, float* ms,
-               float* scores_opt) {
+               float* scores_opt, bool first_self_done = false) {
     hipStream_t s = c->stream;
     const LgWeightsDev& W = c->lg;
     const int rows = 2 * P * L, nseq = 2 * P;
-    { ProfScope p(c, "lg_misc"); launch_lg_posenc(s, b.kn, W.wr, rows, b.cs, b.sn); }
+    if (!first_self_done) { ProfScope p(c, "lg_misc"); launch_lg_posenc(s, b.kn, W.wr, rows, b.cs, b.sn); }
     for (int l = 0; l < LG_LAYERS; ++l) {
         const LgLayerDev& Lw = W.L[l];
-        // ---- self block
-        { ProfScope p(c, "lg_qkv");   // q,k,v = Wqkv x + b with the rotary applied to q,k in the GEMM epilogue
-          GemmArgs a = gemm_plain(b.x, 256, Lw.wqkv, 256, Lw.bqkv, b.qkv, 768, rows, 768, 256);
-          a.rope_cs = b.cs; a.rope_sn = b.sn; a.rope_ncols = 512;
-          launch_gemm_nt(s, a); }
-        { ProfScope p(c, "lg_attention"); launch_lg_attention(s, b.qkv, b.qkv + 256, b.qkv + 512, 768, b.ctx, nseq, L, L, b.lens, b.lens, nullptr); }
-        { ProfScope p(c, "lg_proj"); launch_gemm_nt(s, gemm_plain(b.ctx, 256, Lw.wo, 256, Lw.bo, b.msg, 256, rows, 256, 256)); }
-        lg_ffn(c, b, rows, Lw.w1, Lw.b1, Lw.lng, Lw.lnb, Lw.w2, Lw.b2);
+        if (l > 0 || !first_self_done) lg_self_block(c, b, Lw, b.x, b.cs, b.sn, b.lens, nseq, L);
         // ---- cross block
         { ProfScope p(c, "lg_cross_qkv"); launch_gemm_nt(s, gemm_plain(b.x, 256, Lw.cwqkv, 256, Lw.cbqkv, b.qkv, 512, rows, 512, 256)); }
         { ProfScope p(c, "lg_attention"); launch_lg_attention(s, b.qkv, b.qkv, b.qkv + 256, 512, b.ctx, nseq, L, L, b.lens, b.lens, b.kvmap); }
         { ProfScope p(c, "lg_proj"); launch_gemm_nt(s, gemm_plain(b.ctx, 256, Lw.cwo, 256, Lw.cbo, b.msg, 256, rows, 256, 256)); }
-        lg_ffn(c, b, rows, Lw.cw1, Lw.cb1, Lw.clng, Lw.clnb, Lw.cw2, Lw.cb2);
+        lg_ffn(c, b, b.x, rows, Lw.cw1, Lw.cb1, Lw.clng, Lw.clnb, Lw.cw2, Lw.cb2);
     }
     // ---- assignment
     { ProfScope p(c, "lg_proj");
@@ -609,10 +618,35 @@ extern "C" int rfe_extract_match_stream_dev(rfe_ctx* c, const uint8_t* img, int 
     LgBuffers b;
     lg_carve(c->ws_lg, P, L, b);
     float* kn_all = (float*)((char*)c->ws_lg + lg_ws_bytes(P, L) - 4096 + 256);
+    hipStream_t s = c->stream;
+    static const bool dedup = getenv("RFE_NO_SELF_DEDUP") == nullptr;   // tuning / test switch
+    if (!dedup || L != Kmax) {
+        { ProfScope p(c, "lg_misc");
+          launch_normalize_kpts(s, kxy, (int64_t)B * Kmax, H, W, kn_all);
+          if ((rc = lg_stage(c, b, kn_all, kn_all + (size_t)Kmax * 2, desc, desc + (size_t)Kmax * 256, n, n + 1, P, Kmax, Kmax, L))) return rc; }
+        return lg_forward(c, b, P, L, filter_thr, Kmax, S, pairs, ms, nullptr);
+    }
+    // Every interior frame is side 1 of pair i-1 and side 0 of pair i, and layer 0's self block depends on
+    // the frame alone: run it (and the positional encoding) once per FRAME, then scatter into the pair layout.
+    float* xf = b.md;                        // [B, L, 256]   (md / sim are only used by the assignment at the end)
+    float* csf = b.sim;                      // [B*L, 32]
+    float* snf = b.sim + (size_t)B * L * 32;
     { ProfScope p(c, "lg_misc");
-      launch_normalize_kpts(c->stream, kxy, (int64_t)B * Kmax, H, W, kn_all);
-      if ((rc = lg_stage(c, b, kn_all, kn_all + (size_t)Kmax * 2, desc, desc + (size_t)Kmax * 256, n, n + 1, P, Kmax, Kmax, L))) return rc; }
-    return lg_forward(c, b, P, L, filter_thr, Kmax, S, pairs, ms, nullptr);
+      launch_normalize_kpts(s, kxy, (int64_t)B * Kmax, H, W, kn_all);
+      launch_lg_posenc(s, kn_all, c->lg.wr, B * L, csf, snf);
+      launch_copy_f32(s, desc, xf, (int64_t)B * L * 256);
+      hipLaunchKernelGGL(lg_setup_kernel, dim3((2 * P + 255) / 256), dim3(256), 0, s, n, n + 1, P, Kmax, Kmax, b.lens, b.kvmap); }
+    lg_self_block(c, b, c->lg.L[0], xf, csf, snf, n, B, L);
+    { ProfScope p(c, "lg_misc");
+      const size_t half = (size_t)P * L;
+      launch_copy_f32(s, xf, b.x, (int64_t)half * 256);
+      launch_copy_f32(s, xf + (size_t)L * 256, b.x + half * 256, (int64_t)half * 256);
+      launch_copy_f32(s, csf, b.cs, (int64_t)half * 32);
+      launch_copy_f32(s, csf + (size_t)L * 32, b.cs + half * 32, (int64_t)half * 32);
+      launch_copy_f32(s, snf, b.sn, (int64_t)half * 32);
+      launch_copy_f32(s, snf + (size_t)L * 32, b.sn + half * 32, (int64_t)half * 32); }
+    RFE_HIP(c, hipGetLastError());
+    return lg_forward(c, b, P, L, filter_thr, Kmax, S, pairs, ms, nullptr, true);
 }
 
 // =====================================================================================

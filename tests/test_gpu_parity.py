@@ -289,3 +289,32 @@ def test_constant_image_no_crash(ctx, oracle):
     n, kxy, score, desc = ctx.extract(img, kmax=64)
     r = oracle.superpoint(Wt.make_superpoint(seed=7), img[0], kmax=64)
     assert n[0] == r["n"] and np.array_equal(kxy[0], r["kxy"]) and np.array_equal(score[0], r["score"])
+
+
+def test_stream_mode_equals_pairwise(ctx, oracle):
+    """rfe_extract_match_stream_dev (B frames, matches (i,i+1), first self block shared per frame) gives the same
+    features as rfe_extract_u8 and the same matches as one rfe_match call per pair -- and as the oracle."""
+    from rover_slam_amd import capi
+    B, H, W, K = 5, 120, 160, 128
+    frames, _ = synth.make_frames(B, H, W, seed=11)
+    dimg = _dev(ctx, frames)
+    dn, dk, ds, dd = ctx.alloc(B * 4), ctx.alloc(B * K * 8), ctx.alloc(B * K * 4), ctx.alloc(B * K * 1024)
+    dS, dp, dm = ctx.alloc((B - 1) * 4), ctx.alloc((B - 1) * K * 8), ctx.alloc((B - 1) * K * 4)
+    ctx._chk(capi.lib.rfe_extract_match_stream_dev(ctx.h, dimg.ptr, H, W, W, B, K, 0.0005, 0.1, dn.ptr, dk.ptr, ds.ptr, dd.ptr,
+                                                   dS.ptr, dp.ptr, dm.ptr))
+    ctx.synchronize()
+    n = dn.download((B,), np.int32); kxy = dk.download((B, K, 2), np.int32); desc = dd.download((B, K, 256), np.float32)
+    S = dS.download((B - 1,), np.int32); pairs = dp.download((B - 1, K, 2), np.int32); ms = dm.download((B - 1, K), np.float32)
+    n2, kxy2, _, desc2 = ctx.extract(frames, kmax=K)
+    assert np.array_equal(n, n2) and np.array_equal(kxy, kxy2) and np.array_equal(desc, desc2)
+    wlg = Wt.make_lightglue(seed=11)
+    for i in range(B - 1):
+        k0 = oracle.normalize_keypoints(kxy[i].astype(np.float32), H, W)
+        k1 = oracle.normalize_keypoints(kxy[i + 1].astype(np.float32), H, W)
+        S1, p1, m1 = ctx.match(k0[None], k1[None], desc[i][None], desc[i + 1][None], [n[i]], [n[i + 1]])
+        assert S[i] == S1[0] and np.array_equal(pairs[i, :S[i]], p1[0, :S1[0]])
+        assert np.abs(ms[i, :S[i]] - m1[0, :S1[0]]).max() < 1e-5 if S[i] else True
+        r = oracle.lightglue(wlg, k0[:n[i]], k1[:n[i + 1]], desc[i, :n[i]], desc[i + 1, :n[i + 1]])
+        assert S[i] == r["S"] and np.array_equal(pairs[i, :S[i]], r["pairs"])
+    for d in (dimg, dn, dk, ds, dd, dS, dp, dm):
+        d.free()
