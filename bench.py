@@ -49,22 +49,25 @@ def stage_flops(name, B, lens):
         return 2.0 * 256 * 65 * (H // 8) * (W // 8) * B
     if name == "convDb":
         return 2.0 * 256 * 256 * (H // 8) * (W // 8) * B
-    if name == "lg_qkv":
-        return 2.0 * rows * 256 * 768
-    if name == "lg_proj":
-        return 2.0 * rows * 256 * 256
-    if name == "lg_ffn1":
-        return 2.0 * rows * 512 * 512
+    # stream mode runs layer 0's self block once per FRAME (B sequences) instead of per pair side (2P sequences)
+    rows_f = B * KMAX
+    if name == "lg_qkv":            # 9 launches: 8 on 2P sequences + 1 on B frames
+        return 2.0 * 256 * 768 * (8 * rows + rows_f) / 9
+    if name == "lg_proj":           # 19 launches: 9 self out-proj (one on frames) + 9 cross out-proj + final_proj
+        return 2.0 * 256 * 256 * (18 * rows + rows_f) / 19
+    if name == "lg_ffn1":           # 18 launches, one on frames
+        return 2.0 * 512 * 512 * (17 * rows + rows_f) / 18
     if name == "lg_ffn2":
-        return 2.0 * rows * 512 * 256
+        return 2.0 * 512 * 256 * (17 * rows + rows_f) / 18
     if name == "lg_sim":
         return 2.0 * 256 * float(np.sum(lens[:-1].astype(np.float64) * lens[1:]))
     if name == "lg_attention":
-        # average of self (n_i^2) and cross (n_i * n_j) launches: 4 heads * (QK^T + PV) * 64 dims
+        # average over the 18 launches (9 self, 9 cross): 4 heads * (QK^T + PV) * 64 dims
         a, b = lens[:-1].astype(np.float64), lens[1:].astype(np.float64)
-        self_f = 4 * 4.0 * 64 * float(np.sum(a * a) + np.sum(b * b))
+        self_pairs = 4 * 4.0 * 64 * float(np.sum(a * a) + np.sum(b * b))       # one self launch on 2P sequences
+        self_frames = 4 * 4.0 * 64 * float(np.sum(lens.astype(np.float64) ** 2))  # layer 0: once per frame
         cross_f = 4 * 4.0 * 64 * float(2 * np.sum(a * b))
-        return 0.5 * (self_f + cross_f)
+        return (8 * self_pairs + self_frames + 9 * cross_f) / 18
     return None
 
 

@@ -11,6 +11,7 @@
 // the 32 rows of a fragment hit 32 banks), single buffered so that 3 workgroups share a CU.
 // Reduction order: k ascending, accumulator initialised with the bias (== oracle rfo_linear, bit-exact).
 // Roofline: fp32 MFMA peak 157.3 TFLOP/s, algorithmic 2*M*N*K FLOP.
+#include <stdlib.h>
 #include "rfe_internal.h"
 
 namespace rfe {
@@ -26,7 +27,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     __shared__ float lds_ab[(BM + BN) * LDT];   // A tile | B tile; reused for the rotary tables in the epilogue
     float* const As = lds_ab;
     float* const Bs = lds_ab + BM * LDT;
-    static_assert((BM + BN) * LDT >= BM * 65, "rotary table staging must fit");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -102,49 +102,77 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
         }
     }
 
+    // ---- epilogue: accumulators (lane = column) are transposed through the now free A/B LDS space in 32-row
+    // chunks so that residual loads and result stores are whole-row float4 accesses (4x fewer memory
+    // instructions than per-lane 4-byte accesses; the residual read alone cost 25 % of ffn2 before).
     const float* R = g.R ? g.R + (size_t)z * g.sR : nullptr;
     const bool rope = g.rope_cs != nullptr;
-    if (rope) {   // stage this tile's rotary tables [128 rows][32 cos | 32 sin] in the (now free) A/B LDS space
+    constexpr int CS = BN + 4;                 // chunk row stride (floats), keeps rows 16-byte aligned
+    static_assert(32 * CS <= (BM + BN) * LDT, "epilogue chunk must fit in the tile LDS");
+    float* const ch = lds_ab;
+    float* const tab = lds_ab + 32 * CS;       // rotary tables of the chunk rows: [32][32 cos | 32 sin]
+    static_assert(32 * CS + 32 * 64 <= (BM + BN) * LDT, "rotary table staging must fit");
+    const bool vec_ok = (g.ldc % 4 == 0) && (g.N % 4 == 0) && (!R || g.ldr % 4 == 0);
+#pragma unroll 1
+    for (int c4 = 0; c4 < 4; ++c4) {           // chunk = rows (c4>>1)*64 + (c4&1)*32 .. +31 of the tile
         __syncthreads();
-        for (int idx = tid; idx < BM * 16; idx += 256) {
-            const int row = idx >> 4, q4 = idx & 15;     // 16 float4 per row: 8 cos + 8 sin
-            int m = m0 + row; m = m < M ? m : M - 1;
-            const float* src = (q4 < 8 ? g.rope_cs : g.rope_sn) + (size_t)m * 32 + (q4 & 7) * 4;
-            const float4 v4 = *reinterpret_cast<const float4*>(src);
-            float* d = As + row * 65 + (q4 < 8 ? 0 : 32) + (q4 & 7) * 4;   // row stride 65: conflict-free reads below
-            d[0] = v4.x; d[1] = v4.y; d[2] = v4.z; d[3] = v4.w;
-        }
-        __syncthreads();
-    }
+        if (wm == (c4 >> 1)) {
+            const int mb = c4 & 1;
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ml = wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int m = m0 + ml;
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const int n = n0 + (wn * NB + nb) * 32 + i;
-                float v = acc[mb][nb][r] * g.alpha;
-                if (rope) {   // LightGlue rotary on (q,k): t' = t*cos + rot(t)*sin, rot pairs (2f,2f+1) -> (-t1, t0)
-                    const float partner = __shfl_xor(v, 1);   // column n^1 of the same row
-                    if (n < g.rope_ncols) {
-                        const int f = (n & 63) >> 1;
-                        const float c = As[ml * 65 + f], sn = As[ml * 65 + 32 + f];
-                        v = (n & 1) ? v * c + partner * sn : v * c - partner * sn;
-                    }
+                for (int nb = 0; nb < NB; ++nb) {
+                    // the two M-blocks are distinct registers: select without dynamic indexing
+                    const float v = mb ? acc[1][nb][r] : acc[0][nb][r];
+                    ch[row * CS + (wn * NB + nb) * 32 + i] = v * g.alpha;
                 }
-                if (m >= M || n >= g.N) continue;
-                if (g.relu) v = fmaxf(v, 0.f);
-                if (R) v = R[(size_t)m * g.ldr + n] + v;
-                C[(size_t)m * g.ldc + n] = v;
             }
         }
+        const int mbase = m0 + (c4 >> 1) * 64 + (c4 & 1) * 32;
+        if (rope) {
+            for (int idx = tid; idx < 32 * 16; idx += 256) {
+                const int row = idx >> 4, q4 = idx & 15;     // 16 float4 per row: 8 cos + 8 sin
+                int m = mbase + row; m = m < M ? m : M - 1;
+                const float* src = (q4 < 8 ? g.rope_cs : g.rope_sn) + (size_t)m * 32 + (q4 & 7) * 4;
+                *reinterpret_cast<float4*>(tab + row * 64 + q4 * 4) = *reinterpret_cast<const float4*>(src);
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 32 * (BN / 4); idx += 256) {
+            const int row = idx / (BN / 4), q = idx % (BN / 4);
+            const int m = mbase + row, n = n0 + q * 4;
+            if (m >= M || n >= g.N) continue;
+            float4 v = *reinterpret_cast<const float4*>(ch + row * CS + q * 4);
+            if (rope && n < g.rope_ncols) {   // LightGlue rotary: (t0,t1) -> (t0 c - t1 s, t1 c + t0 s), pairs (2f,2f+1), f = (n%64)/2
+                const int f = (n & 63) >> 1;
+                const float2 c2 = *reinterpret_cast<const float2*>(tab + row * 64 + f);
+                const float2 s2 = *reinterpret_cast<const float2*>(tab + row * 64 + 32 + f);
+                v = make_float4(v.x * c2.x - v.y * s2.x, v.y * c2.x + v.x * s2.x, v.z * c2.y - v.w * s2.y, v.w * c2.y + v.z * s2.y);
+            }
+            if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            float* dst = C + (size_t)m * g.ldc + n;
+            if (vec_ok && n + 3 < g.N) {
+                if (R) { const float4 rv = *reinterpret_cast<const float4*>(R + (size_t)m * g.ldr + n); v.x = rv.x + v.x; v.y = rv.y + v.y; v.z = rv.z + v.z; v.w = rv.w + v.w; }
+                *reinterpret_cast<float4*>(dst) = v;
+            } else {
+                const float* rp = R ? R + (size_t)m * g.ldr + n : nullptr;
+                dst[0] = rp ? rp[0] + v.x : v.x;
+                if (n + 1 < g.N) dst[1] = rp ? rp[1] + v.y : v.y;
+                if (n + 2 < g.N) dst[2] = rp ? rp[2] + v.z : v.z;
+                if (n + 3 < g.N) dst[3] = rp ? rp[3] + v.w : v.w;
+            }
+        }
+    }
 }
 
-void launch_gemm_nt(hipStream_t s, const GemmArgs& g) {
+void launch_gemm_nt(hipStream_t s, const GemmArgs& g0) {
+    GemmArgs g = g0;
+    static const bool dbg_nores = getenv("RFE_DBG_GEMM_NORES") != nullptr;     // timing experiments only (wrong results)
+    static const bool nb2_n256 = getenv("RFE_GEMM_NB2_N256") != nullptr;
+    if (dbg_nores) g.R = nullptr;
     const int batch = g.batch > 0 ? g.batch : 1;
-    if (g.N % 256 == 0) {
+    if (g.N % 256 == 0 && !(nb2_n256 && g.N == 256)) {
         dim3 grid(g.N / 256, (g.M + BM - 1) / BM, batch);
         hipLaunchKernelGGL(gemm_nt_kernel<4>, grid, dim3(256), 0, s, g);
     } else {

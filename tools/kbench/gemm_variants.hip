@@ -179,6 +179,8 @@ int main() {
         run<2, 2, 2, 2, 32, false, 2, 4>("2x2w 64x64 BK32 single pipe4", A, B, bias, C, M, N, K);
         run<2, 2, 2, 2, 32, true, 2, 2>("2x2w 64x64 BK32 dbuf pipe2", A, B, bias, C, M, N, K);
         run<2, 2, 2, 4, 32, false, 2>("2x2w 64x128 BK32 single", A, B, bias, C, M, N, K);
+        run<1, 4, 2, 4, 32, false, 2>("1x4w 64x128 BK32 single (64x512)", A, B, bias, C, M, N, K);
+        run<1, 4, 2, 4, 16, false, 2>("1x4w 64x128 BK16 single (64x512)", A, B, bias, C, M, N, K);
         run<2, 2, 2, 4, 32, false, 2, 1>("2x2w 64x128 BK32 single pipe1", A, B, bias, C, M, N, K);
         run<2, 2, 2, 4, 32, false, 2, 2>("2x2w 64x128 BK32 single pipe2", A, B, bias, C, M, N, K);
         run<2, 2, 2, 4, 32, true, 2, 2>("2x2w 64x128 BK32 dbuf pipe2", A, B, bias, C, M, N, K);
