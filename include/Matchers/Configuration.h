@@ -1,19 +1,23 @@
-// Configuration.h -- same fields as the reference's include/Matchers/Configuration.h:6-20.
-// Extension: lightgluePath / extractorPath name RFEW weight containers (rover-slam_amd/weights.py)
-// instead of .onnx files; when empty the shims use $RFE_LG_WEIGHTS / $RFE_SP_WEIGHTS or the
-// reference's directory with the new extension (onnxmodel/lightglue_sim.rfew, onnxmodel/superpoint.rfew).
-#ifndef CONFIGURATION_H
-#define CONFIGURATION_H
+// Configuration.h -- option bag handed to the runner classes; member names and defaults follow the
+// reference's include/Matchers/Configuration.h:6-20 so that call sites assign the same fields.
+//
+// Differences: the two paths name RFEW weight containers (rover-slam_amd/weights.py), not .onnx files --
+// when they do not end in ".rfew" the shims fall back to $RFE_SP_WEIGHTS / $RFE_LG_WEIGHTS and then to
+// onnxmodel/superpoint.rfew / onnxmodel/lightglue_sim.rfew; `device` is accepted and ignored (the only
+// backend is HIP on gfx950; the reference passes "cuda", SPextractor.cc:92); two fields are additions.
+#pragma once
 #include <string>
+
 struct Configuration {
-    std::string lightgluePath;
-    std::string extractorPath;
-    std::string extractorType;
-    bool isEndtoEnd = true;
-    bool grayScale = false;
+    // model files
+    std::string extractorPath, lightgluePath;
+    std::string extractorType;                 // "superpoint"
+    std::string device;                        // ignored
+    // behaviour flags kept for source compatibility (unused by the reference's live path as well)
+    bool isEndtoEnd = true, grayScale = false, viz = false;
     unsigned int image_size = 512;
     float threshold = 0.0f;
-    std::string device;   // "cuda" in the reference (SPextractor.cc:92); ignored: the only backend is HIP/gfx950
-    bool viz = false;
+    // additions
+    int max_keypoints = 0;                     // 0 = runner default (1024 or $RFE_MAX_KEYPOINTS)
+    float detection_threshold = 0.0005f;       // SuperPoint score threshold of the LightGlue-ONNX export
 };
-#endif

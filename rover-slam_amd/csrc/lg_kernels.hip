@@ -212,7 +212,9 @@ void launch_lg_ln_gelu(hipStream_t s, float* h, const float* g, const float* b, 
     hipLaunchKernelGGL(lg_ln_gelu_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, h, g, b, rows);
 }
 
-// z[row] = x[row] . w + b   (matchability head, 256 -> 1)
+__device__ __forceinline__ float logsigmoid_(float z) { return z >= 0.f ? -log1pf(expf(-z)) : z - log1pf(expf(z)); }
+
+// z[row] = logsigmoid(x[row] . w + b)   (matchability head, 256 -> 1; stored already in the log domain)
 __global__ __launch_bounds__(256) void lg_matchability_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ b, int64_t rows,
                                                               float* __restrict__ z) {
@@ -224,14 +226,13 @@ __global__ __launch_bounds__(256) void lg_matchability_kernel(const float* __res
     float s = fmaf(a.w, ww.w, fmaf(a.z, ww.z, fmaf(a.y, ww.y, a.x * ww.x)));
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) z[row] = s + b[0];
+    if (lane == 0) z[row] = logsigmoid_(s + b[0]);   // the assignment only ever uses log sigmoid(z)
 }
 void launch_lg_matchability(hipStream_t s, const float* x, const float* w, const float* b, int64_t rows, float* z) {
     hipLaunchKernelGGL(lg_matchability_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, w, b, rows, z);
 }
 
 // ---------------------------------------------------------------- assignment
-__device__ __forceinline__ float logsigmoid_(float z) { return z >= 0.f ? -log1pf(expf(-z)) : z - log1pf(expf(z)); }
 
 // row log-sum-exp of sim[p][i][0..n) : one wave per row
 __global__ __launch_bounds__(256) void lg_rowlse_kernel(const float* __restrict__ sim, int L, const int* __restrict__ m,
@@ -293,10 +294,10 @@ __global__ __launch_bounds__(256) void lg_rowarg_kernel(const float* __restrict_
     if (i >= m[p]) return;
     const int nn = n[p];
     const float* r = sim + ((size_t)p * L + i) * L;
-    const float lr = rowlse[(size_t)p * L + i], l0 = logsigmoid_(z0[(size_t)p * L + i]);
+    const float lr = rowlse[(size_t)p * L + i], l0 = z0[(size_t)p * L + i];
     float best = -INFINITY; int bi = 0x7fffffff;
     for (int jj = lane; jj < nn; jj += 64) {
-        const float sc = lg_score(r[jj], lr, collse[(size_t)p * L + jj], l0, logsigmoid_(z1[(size_t)p * L + jj]));
+        const float sc = lg_score(r[jj], lr, collse[(size_t)p * L + jj], l0, z1[(size_t)p * L + jj]);
         if (scores_opt) scores_opt[((size_t)p * L + i) * L + jj] = sc;
         if (sc > best) { best = sc; bi = jj; }
     }
@@ -320,10 +321,9 @@ __global__ __launch_bounds__(256) void lg_colarg_kernel(const float* __restrict_
     const float* base = sim + (size_t)p * L * L;
     float best = -INFINITY; int bi = 0x7fffffff;
     if (jj < nn) {
-        const float lc = collse[(size_t)p * L + jj], l1 = logsigmoid_(z1[(size_t)p * L + jj]);
+        const float lc = collse[(size_t)p * L + jj], l1 = z1[(size_t)p * L + jj];
         for (int i = rg; i < mm; i += 8) {
-            const float sc = lg_score(base[(size_t)i * L + jj], rowlse[(size_t)p * L + i], lc,
-                                      logsigmoid_(z0[(size_t)p * L + i]), l1);
+            const float sc = lg_score(base[(size_t)i * L + jj], rowlse[(size_t)p * L + i], lc, z0[(size_t)p * L + i], l1);
             if (sc > best) { best = sc; bi = i; }
         }
     }

@@ -59,16 +59,16 @@ __device__ __forceinline__ void conv_a_offsets(int (&aoff)[9], int h, int wave, 
 }
 
 // one staged chunk of CK input channels: CK*9/2 k-steps x 4 MFMA per wave
-template <int CK>
+template <int CK, int PLANE_ = PLANE, int BLK1_ = TWS>
 __device__ __forceinline__ void conv_chunk_mma(const float* lds_in, const float* lds_w, const int (&aoff)[9], int boff,
                                                f32x16 (&acc)[2][2]) {
 #pragma unroll 1
     for (int cp = 0; cp < CK / 2; ++cp) {
-        const float* ap = lds_in + cp * 2 * PLANE;
+        const float* ap = lds_in + cp * 2 * PLANE_;
         const float* bp = lds_w + cp * 18 * NT + boff;
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
-            const float a0 = ap[aoff[s]], a1 = ap[aoff[s] + TWS];
+            const float a0 = ap[aoff[s]], a1 = ap[aoff[s] + BLK1_];
             const float b0 = bp[2 * s * NT], b1 = bp[2 * s * NT + 32];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
@@ -78,14 +78,14 @@ __device__ __forceinline__ void conv_chunk_mma(const float* lds_in, const float*
     }
 }
 
-template <int CK>
+template <int CK, int NTHR = 256>
 __device__ __forceinline__ void conv_stage_weights(float* lds_w, const float* src_chunk, int tid) {
     constexpr int KCH = CK * 9;
     const float4* src = reinterpret_cast<const float4*>(src_chunk);
     float4* dst = reinterpret_cast<float4*>(lds_w);
 #pragma unroll
-    for (int it = 0; it < (KCH * NT / 4 + 255) / 256; ++it)
-        if (it * 256 + tid < KCH * NT / 4) dst[it * 256 + tid] = src[it * 256 + tid];
+    for (int it = 0; it < (KCH * NT / 4 + NTHR - 1) / NTHR; ++it)
+        if (it * NTHR + tid < KCH * NT / 4) dst[it * NTHR + tid] = src[it * NTHR + tid];
 }
 
 // epilogue.  D layout: lane holds channel (lane&31), pixel column (r&3)+8*(r>>2)+4*h of rows 2*wave+{0,1}
@@ -181,6 +181,80 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// Wide-tile variant for feature maps whose width is a multiple of 80 (the 60 x 80 grid of 640 x 480
+// frames: conv4a/4b/Pa/Da).  The 8 x 32 tile above wastes 22 % of its MFMAs there (60 = 7.5 x 8,
+// 80 = 2.5 x 32).  Here a workgroup is 5 waves covering 4 rows x 80 columns exactly: an M-block is
+// 2 rows x 16 columns, wave w owns columns 16w..16w+15 of rows 0-1 (block 0) and 2-3 (block 1).
+// Same reduction order (bit-exact), no pooling (none of these layers pools).
+constexpr int WTH = 4, WTW = 80, WIH = WTH + 2, WIW = WTW + 2, WTWS = WIW, WPLANE = WIH * WTWS, WNTHR = 320;
+
+template <int CIN, bool RELU, int TAG, int CK>
+__global__ __launch_bounds__(WNTHR, 2) void conv3x3_wide_kernel(
+    const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
+    float* __restrict__ out, int H, int W, int COUT) {
+    constexpr int KCH = CK * 9;
+    __shared__ __attribute__((aligned(16))) float lds[CK * WPLANE + KCH * NT];
+    float* lds_in = lds;
+    float* lds_w = lds + CK * WPLANE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, h = lane >> 5;
+    const int nct = COUT / NT;
+    const int b = blockIdx.z / nct, ct = blockIdx.z % nct;
+    const int x0 = blockIdx.x * WTW, y0 = blockIdx.y * WTH;
+    const int co0 = ct * NT;
+
+    f32x16 acc[2][2];
+    {
+        const float b0 = bias[co0 + col], b1 = bias[co0 + 32 + col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][0][r] = b0; acc[1][0][r] = b0; acc[0][1][r] = b1; acc[1][1][r] = b1; }
+    }
+    int aoff[9];
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+        const int k0 = 2 * s, k1 = 2 * s + 1;
+        const int o0 = (k0 / 9) * WPLANE + ((k0 % 9) / 3) * WTWS + (k0 % 9) % 3;
+        const int o1 = (k1 / 9) * WPLANE + ((k1 % 9) / 3) * WTWS + (k1 % 9) % 3;
+        aoff[s] = (h ? o1 : o0) + (col >> 4) * WTWS + wave * 16 + (col & 15);
+    }
+    const int boff = h * NT + col;
+    const float* in_b = in + (size_t)b * H * W * CIN;
+    const float* wp_ct = wp + (size_t)ct * (CIN / CK) * KCH * NT;
+
+    for (int ch = 0; ch < CIN / CK; ++ch) {
+        __syncthreads();
+        for (int idx = tid; idx < WIH * WIW * (CK / 4); idx += WNTHR) {
+            const int cq = idx % (CK / 4), pix = idx / (CK / 4);
+            const int py = pix / WIW, px = pix % WIW;
+            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+                v = *reinterpret_cast<const float4*>(in_b + ((size_t)gy * W + gx) * CIN + ch * CK + cq * 4);
+            float* d = lds_in + (cq * 4) * WPLANE + py * WTWS + px;
+            d[0] = v.x; d[WPLANE] = v.y; d[2 * WPLANE] = v.z; d[3 * WPLANE] = v.w;
+        }
+        conv_stage_weights<CK, WNTHR>(lds_w, wp_ct + (size_t)ch * KCH * NT, tid);
+        __syncthreads();
+        conv_chunk_mma<CK, WPLANE, 2 * WTWS>(lds_in, lds_w, aoff, boff, acc);
+    }
+    // D row m = (r&3)+8*(r>>2)+4h of block mb -> pixel (y0 + 2*mb + (m>>4), x0 + 16*wave + (m&15))
+    float* out_b = out + (size_t)b * H * W * COUT;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int y = y0 + 2 * mb + (m >> 4), x = x0 + 16 * wave + (m & 15);
+            if (y >= H || x >= W) continue;
+            float v0 = acc[mb][0][r], v1 = acc[mb][1][r];
+            if (RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+            float* o = out_b + ((size_t)y * W + x) * COUT + co0 + col;
+            o[0] = v0; o[32] = v1;
+        }
+}
+
+// ------------------------------------------------------------------------------------------
 // conv1a + conv1b fused: the 64-channel input tile of conv1b is never read from HBM; every staged
 // 8-channel chunk is recomputed in LDS from the u8 image tile (NormalizeImage * 1/255, conv1a 1->64,
 // bias, ReLU -- same fmaf chain as conv1a_u8_kernel / the oracle, so still bit-exact), then conv1b +
@@ -268,6 +342,16 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
                     const float* bias, int cout, bool relu, bool pool, float* out, int tag) {
     dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B * (cout / NT));
     const bool ck8 = conv_ck() == 8;
+    static const bool no_wide = getenv("RFE_CONV_NO_WIDE") != nullptr;   // tuning / test switch
+    // measured on the 60 x 80 grid: +6 % for the 128-output-channel layers (conv4a/4b), -9 % for the 256-channel
+    // heads (convPa/Da re-stage the larger input tile four times), so only the former use it
+    if (!no_wide && ck8 && !pool && relu && cin == 128 && W % WTW == 0 && (tag == L_4A || tag == L_4B)) {
+        dim3 gw(W / WTW, (H + WTH - 1) / WTH, B * (cout / NT));
+        switch (tag) {
+            case L_4A: hipLaunchKernelGGL((conv3x3_wide_kernel<128, true, L_4A, 8>), gw, dim3(WNTHR), 0, s, in, wp, bias, out, H, W, cout); return;
+            default: hipLaunchKernelGGL((conv3x3_wide_kernel<128, true, L_4B, 8>), gw, dim3(WNTHR), 0, s, in, wp, bias, out, H, W, cout); return;
+        }
+    }
     switch (tag) {
         case L_1B: RFE_CONV_LAUNCH(64, true, true, L_1B); return;
         case L_2A: RFE_CONV_LAUNCH(64, false, true, L_2A); return;
