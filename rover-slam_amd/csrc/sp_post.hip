@@ -163,6 +163,22 @@ __device__ __forceinline__ int block_excl_scan_flag(bool flag, int* wave_tot /*[
     return off + lane_prefix;
 }
 
+// exclusive block scan of one int per thread (wave scan by shuffles + 16 wave totals in LDS)
+__device__ __forceinline__ int block_excl_scan_int(int v, int* wave_tot /*[16]*/, int& total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(x, off); if (lane >= off) x += y; }
+    if (lane == 63) wave_tot[wv] = x;
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SEL_T / 64; ++w) { const int c = wave_tot[w]; if (w < wv) off += c; tot += c; }
+    __syncthreads();
+    total = tot;
+    return off + x - v;
+}
+
 __global__ __launch_bounds__(SEL_T) void select_kernel(const float* __restrict__ nms, int H, int W, int Kmax,
                                                        int P2, float thr, float* __restrict__ cand_score,
                                                        int32_t* __restrict__ cand_idx, int32_t* __restrict__ n_out,
@@ -179,14 +195,26 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(const float* __restrict__
     float* cs = cand_score + (size_t)b * HW;
     int32_t* ci = cand_idx + (size_t)b * HW;
 
+    // ordered (row-major) compaction, 8 consecutive pixels per thread and iteration: one block scan per 8192 pixels
     int count = 0;
-    for (int base = 0; base < HW; base += SEL_T) {
-        const int p = base + tid;
-        const float v = p < HW ? s[p] : -1.f;
-        const bool f = v > thr;
+    for (int base = 0; base < HW; base += SEL_T * 8) {
+        const int p0 = base + tid * 8;
+        float v[8];
+        if (p0 + 7 < HW) {
+            const float4 a = *reinterpret_cast<const float4*>(s + p0), c = *reinterpret_cast<const float4*>(s + p0 + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = p0 + e < HW ? s[p0 + e] : -1.f;
+        }
+        int cnt = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cnt += v[e] > thr ? 1 : 0;
         int tot;
-        const int pos = count + block_excl_scan_flag(f, wave_tot, tot);
-        if (f) { cs[pos] = v; ci[pos] = p; }
+        int pos = count + block_excl_scan_int(cnt, wave_tot, tot);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (v[e] > thr) { cs[pos] = v[e]; ci[pos] = p0 + e; ++pos; }
         count += tot;
     }
     __syncthreads();  // candidate list visible to the whole workgroup (global writes by this WG)
