@@ -108,6 +108,7 @@ def cpu_baseline(frames, wsp, wlg):
 
 
 def main():
+    global KMAX, FRAMES_PER_GPU
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -115,6 +116,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the short PCIe-inclusive measurement (N=1)")
     ap.add_argument("--gather-desc", action="store_true", help="also gather the 256-d descriptors to rank 0")
+    ap.add_argument("--workload", default="c4", choices=["c2", "c3", "c4"],
+                    help="BASELINE.json configs: c4 (default, the metric's workload) = 33 frames + 32 pairs per GPU; "
+                         "c2 = SuperPoint only, batch 1 (latency); c3 = one 640x480 pair, SuperPoint x2 + LightGlue (latency)")
+    ap.add_argument("--kmax", type=int, default=KMAX, help="keypoint capacity per frame (default 1024)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -144,8 +149,11 @@ def main():
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
 
+    KMAX = args.kmax
+    if args.workload != "c4":
+        FRAMES_PER_GPU = 1                      # latency configurations: batch 1
     shard = sharding.shard_frames(FRAMES_PER_GPU, world, rank)
-    B = shard.frames
+    B = shard.frames if args.workload != "c2" else 1
     # each rank owns frames [32r, 32r+32]: one frame of overlap, no inter-GPU dependency
     frames_np, _ = synth.make_frames(B, H, W, seed=20240314 + 1000 * rank)
     frames = torch.from_numpy(frames_np).to(dev)
@@ -153,12 +161,16 @@ def main():
     kxy = torch.zeros(B, KMAX, 2, dtype=torch.int32, device=dev)
     score = torch.zeros(B, KMAX, dtype=torch.float32, device=dev)
     desc = torch.zeros(B, KMAX, 256, dtype=torch.float32, device=dev)
-    S = torch.zeros(B - 1, dtype=torch.int32, device=dev)
-    pairs = torch.zeros(B - 1, KMAX, 2, dtype=torch.int32, device=dev)
-    ms = torch.zeros(B - 1, KMAX, dtype=torch.float32, device=dev)
+    S = torch.zeros(max(B - 1, 1), dtype=torch.int32, device=dev)
+    pairs = torch.zeros(max(B - 1, 1), KMAX, 2, dtype=torch.int32, device=dev)
+    ms = torch.zeros(max(B - 1, 1), KMAX, dtype=torch.float32, device=dev)
     send = [n, kxy, S, pairs] + ([desc] if args.gather_desc else [])
 
     def step():
+        if args.workload == "c2":
+            ctx._chk(capi.lib.rfe_extract_u8_dev(ctx.h, frames.data_ptr(), H, W, W, 1, KMAX, 0.0005, n.data_ptr(), kxy.data_ptr(),
+                                                 score.data_ptr(), desc.data_ptr()))
+            return
         ctx._chk(capi.lib.rfe_extract_match_stream_dev(
             ctx.h, frames.data_ptr(), H, W, W, B, KMAX, 0.0005, 0.1, n.data_ptr(), kxy.data_ptr(), score.data_ptr(),
             desc.data_ptr(), S.data_ptr(), pairs.data_ptr(), ms.data_ptr()))
@@ -188,6 +200,15 @@ def main():
         dt = float(tmax.item())
 
     pcie = None
+    if args.workload != "c4":      # latency configurations: a short line, no roofline object (not the metric's workload)
+        if rank == 0:
+            unit = "frames/s" if args.workload == "c2" else "pairs/s"
+            print(json.dumps({"metric": f"BASELINE configs[{1 if args.workload == 'c2' else 2}] latency run", "value": round(args.steps / dt, 2),
+                              "unit": unit, "ms_per_step": round(dt / args.steps * 1e3, 4), "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "kmax": KMAX, "mean_keypoints": float(n.float().mean().item()),
+                              "stages_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}))
+        ctx.close()
+        return
     if world == 1 and not args.no_pcie:
         # PCIe-inclusive variant (never the headline `value`): frames start in pinned host memory, results end there
         h_frames = torch.from_numpy(frames_np).pin_memory()

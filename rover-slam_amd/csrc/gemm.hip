@@ -16,14 +16,16 @@
 
 namespace rfe {
 
-constexpr int BM = 128, BK = 32, LDT = BK + 1;
+constexpr int BK = 32, LDT = BK + 1;
 
 // NB = 32-column MFMA blocks per wave: wave tile 64 x (NB*32), workgroup tile 128 x (NB*64).
 // NB = 4 (128x256 tile, 49 KB LDS, 3 workgroups/CU) measured best for N % 256 == 0
 // (tools/kbench/gemm_variants.hip: 119-132 TFLOP/s vs 110-125 for 128x128 double-buffered).
-template <int NB>
+// MB = 32-row MFMA blocks per wave (2 for throughput; 1 gives 64-row tiles for small, latency-bound problems:
+// a single 1024-keypoint pair has only M = 2048 rows, 16 tiles of 128 x 256 would use 16 of the 256 CUs).
+template <int MB, int NB>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
-    constexpr int BN = NB * 64;
+    constexpr int BM = MB * 64, BN = NB * 64;
     __shared__ float lds_ab[(BM + BN) * LDT];   // A tile | B tile; reused for the rotary tables in the epilogue
     float* const As = lds_ab;
     float* const Bs = lds_ab + BM * LDT;
@@ -42,13 +44,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     const float* B = g.B + (size_t)z * g.sB;
     float* C = g.C + (size_t)z * g.sC;
 
-    f32x16 acc[2][NB];
+    f32x16 acc[MB][NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int n = n0 + (wn * NB + nb) * 32 + i;
         const float bv = (g.bias && n < g.N) ? g.bias[n] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[0][nb][r] = bv; acc[1][nb][r] = bv; }
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = bv;
     }
 
     // staging: thread -> (row = tid/8 + 32*it, 4 consecutive k).  Rows past the M / N edge are CLAMPED
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     }
     float* const da = As + lrow * LDT + lkq * 4;
     float* const db = Bs + lrow * LDT + lkq * 4;
-    const float* const ap = As + (wm * 64 + i) * LDT + h;
+    const float* const ap = As + (wm * MB * 32 + i) * LDT + h;
     const float* const bp = Bs + (wn * NB * 32 + i) * LDT + h;
 
     for (int k0 = 0; k0 < g.K; k0 += BK) {
@@ -91,14 +95,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
-            const float a0 = ap[2 * s], a1 = ap[32 * LDT + 2 * s];
-            float b[NB];
+            float a[MB], b[NB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) a[mb] = ap[mb * 32 * LDT + 2 * s];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) b[nb] = bp[nb * 32 * LDT + 2 * s];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[nb], acc[0][nb], 0, 0, 0);
+            for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[nb], acc[1][nb], 0, 0, 0);
+                for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
         }
     }
 
@@ -114,22 +119,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     static_assert(32 * CS + 32 * 64 <= (BM + BN) * LDT, "rotary table staging must fit");
     const bool vec_ok = (g.ldc % 4 == 0) && (g.N % 4 == 0) && (!R || g.ldr % 4 == 0);
 #pragma unroll 1
-    for (int c4 = 0; c4 < 4; ++c4) {           // chunk = rows (c4>>1)*64 + (c4&1)*32 .. +31 of the tile
+    for (int c4 = 0; c4 < 2 * MB; ++c4) {      // chunk = 32 rows: wave row wm = c4 / MB, M-block mb = c4 % MB
         __syncthreads();
-        if (wm == (c4 >> 1)) {
-            const int mb = c4 & 1;
+        if (wm == c4 / MB) {
+            const int mb = c4 % MB;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     // the two M-blocks are distinct registers: select without dynamic indexing
-                    const float v = mb ? acc[1][nb][r] : acc[0][nb][r];
+                    const float v = (MB > 1 && mb) ? acc[MB - 1][nb][r] : acc[0][nb][r];
                     ch[row * CS + (wn * NB + nb) * 32 + i] = v * g.alpha;
                 }
             }
         }
-        const int mbase = m0 + (c4 >> 1) * 64 + (c4 & 1) * 32;
+        const int mbase = m0 + c4 * 32;
         if (rope) {
             for (int idx = tid; idx < 32 * 16; idx += 256) {
                 const int row = idx >> 4, q4 = idx & 15;     // 16 float4 per row: 8 cos + 8 sin
@@ -166,18 +171,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     }
 }
 
-void launch_gemm_nt(hipStream_t s, const GemmArgs& g0) {
-    GemmArgs g = g0;
-    static const bool dbg_nores = getenv("RFE_DBG_GEMM_NORES") != nullptr;     // timing experiments only (wrong results)
-    static const bool nb2_n256 = getenv("RFE_GEMM_NB2_N256") != nullptr;
-    if (dbg_nores) g.R = nullptr;
+void launch_gemm_nt(hipStream_t s, const GemmArgs& g) {
     const int batch = g.batch > 0 ? g.batch : 1;
-    if (g.N % 256 == 0 && !(nb2_n256 && g.N == 256)) {
-        dim3 grid(g.N / 256, (g.M + BM - 1) / BM, batch);
-        hipLaunchKernelGGL(gemm_nt_kernel<4>, grid, dim3(256), 0, s, g);
+    auto tiles = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * batch; };
+    // largest tile that still gives every CU a workgroup; small problems (single-pair latency) fall to 64 x 64
+    if (g.N % 256 == 0 && tiles(128, 256) >= 256) {
+        hipLaunchKernelGGL((gemm_nt_kernel<2, 4>), dim3(g.N / 256, (g.M + 127) / 128, batch), dim3(256), 0, s, g);
+    } else if (tiles(128, 128) >= 256 || g.M > 8192) {
+        hipLaunchKernelGGL((gemm_nt_kernel<2, 2>), dim3((g.N + 127) / 128, (g.M + 127) / 128, batch), dim3(256), 0, s, g);
+    } else if (tiles(64, 128) >= 256) {
+        hipLaunchKernelGGL((gemm_nt_kernel<1, 2>), dim3((g.N + 127) / 128, (g.M + 63) / 64, batch), dim3(256), 0, s, g);
     } else {
-        dim3 grid((g.N + 127) / 128, (g.M + BM - 1) / BM, batch);
-        hipLaunchKernelGGL(gemm_nt_kernel<2>, grid, dim3(256), 0, s, g);
+        hipLaunchKernelGGL((gemm_nt_kernel<1, 1>), dim3((g.N + 63) / 64, (g.M + 63) / 64, batch), dim3(256), 0, s, g);
     }
 }
 

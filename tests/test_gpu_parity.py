@@ -318,3 +318,42 @@ def test_stream_mode_equals_pairwise(ctx, oracle):
         assert S[i] == r["S"] and np.array_equal(pairs[i, :S[i]], r["pairs"])
     for d in (dimg, dn, dk, ds, dd, dS, dp, dm):
         d.free()
+
+
+def test_full_size_640x480_vs_oracle(ctx, oracle):
+    """BASELINE size, directly against the oracle: one 640x480 frame pair through SuperPoint (bit-exact) and
+    LightGlue at K = 1024 (match list identical, scores within 1e-4)."""
+    frames, _ = synth.make_frames(2, 480, 640, seed=640)
+    n, kxy, score, desc = ctx.extract(frames, kmax=1024)
+    w = Wt.make_superpoint(seed=7)
+    for i in range(2):
+        r = oracle.superpoint(w, frames[i], kmax=1024)
+        assert n[i] == r["n"] == 1024
+        assert np.array_equal(kxy[i], r["kxy"]) and np.array_equal(score[i], r["score"]) and np.array_equal(desc[i], r["desc"])
+    k0 = oracle.normalize_keypoints(kxy[0].astype(np.float32), 480, 640)
+    k1 = oracle.normalize_keypoints(kxy[1].astype(np.float32), 480, 640)
+    S, pairs, ms = ctx.match(k0[None], k1[None], desc[0][None], desc[1][None], [1024], [1024])
+    r = oracle.lightglue(Wt.make_lightglue(seed=11), k0, k1, desc[0], desc[1])
+    assert S[0] == r["S"] and np.array_equal(pairs[0, :S[0]], r["pairs"])
+    if S[0]:
+        assert np.abs(ms[0, :S[0]] - r["ms"]).max() < 1e-4
+
+
+def test_lightglue_permutation_equivariance(ctx):
+    """Property: permuting the keypoints of one image permutes the matches and nothing else."""
+    rng = np.random.default_rng(8)
+    n = 200
+    d0 = rng.standard_normal((n, 256)).astype(np.float32); d0 /= np.linalg.norm(d0, axis=1, keepdims=True)
+    perm0 = rng.permutation(n)
+    d1 = d0[perm0] + 0.05 * rng.standard_normal((n, 256)).astype(np.float32)
+    d1 = (d1 / np.linalg.norm(d1, axis=1, keepdims=True)).astype(np.float32)
+    k0 = rng.uniform(-0.9, 0.9, (n, 2)).astype(np.float32)
+    k1 = (k0[perm0] + 0.02 * rng.standard_normal((n, 2))).astype(np.float32)
+    S, pairs, ms = ctx.match(k0[None], k1[None], d0[None], d1[None], [n], [n])
+    base = {(int(i), int(j)): float(s) for (i, j), s in zip(pairs[0, :S[0]], ms[0, :S[0]])}
+    q = rng.permutation(n)                       # shuffle image 1's keypoints
+    S2, pairs2, ms2 = ctx.match(k0[None], k1[q][None], d0[None], d1[q][None], [n], [n])
+    got = {(int(i), int(q[j])): float(s) for (i, j), s in zip(pairs2[0, :S2[0]], ms2[0, :S2[0]])}
+    assert len(base) > 20 and set(base) == set(got)
+    assert max(abs(base[k] - got[k]) for k in base) < 1e-4
+    assert (np.diff(pairs2[0, :S2[0], 0]) > 0).all()   # output stays sorted by the index in image 0
