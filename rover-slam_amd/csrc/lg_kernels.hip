@@ -32,11 +32,14 @@ void launch_lg_posenc(hipStream_t s, const float* kn, const float* wr, int rows,
 //         order of the reduction is permuted to the D-layout order, so P never moves).
 // 64 MFMA (32x32x2 f32) per 32x32 tile, no wasted FLOPs: 4*L*L*64 per head.
 constexpr int AT_Q = 128, AT_K = 64, AT_LDK = 65;
+constexpr float AT_DEFER = 16.0f;   // log2 units
 
-template <bool DBUF>
+// ABL: timing ablations only (wrong results): 1 = no softmax VALU, 2 = stage only the first K/V tile, 3 = both
+template <bool DBUF, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void lg_attention_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld, float* __restrict__ out,
-    int Lq, int Lk, int nqb, const int* __restrict__ qlen, const int* __restrict__ klen, const int* __restrict__ kv_map) {
+    int Lq, int Lk, int nqb, const int* __restrict__ qlen, const int* __restrict__ klen, const int* __restrict__ kv_map,
+    int prio) {
     // K/V tiles double buffered in LDS; the next tile is prefetched global->registers under the MFMAs
     __shared__ float Ks[DBUF ? 2 : 1][AT_K * AT_LDK];
     __shared__ float Vs[DBUF ? 2 : 1][AT_K * 64];
@@ -60,9 +63,10 @@ __global__ __launch_bounds__(256, 2) void lg_attention_kernel(
     const int j = lane & 31, h = lane >> 5;
     const int qrow = qb * AT_Q + wave * 32 + j;  // this lane's query (may be >= nq: computed, stored as 0)
     const float* qp = q + ((size_t)seq * Lq + (qrow < Lq ? qrow : Lq - 1)) * ld + head * 64 + h;
+    constexpr float kScale = 0.125f * 1.44269504088896341f;  // 1/sqrt(64) * log2(e): softmax in base 2, folded into Q
     float qreg[32];
 #pragma unroll
-    for (int s = 0; s < 32; ++s) qreg[s] = qp[2 * s];
+    for (int s = 0; s < 32; ++s) qreg[s] = qp[2 * s] * kScale;
 
     f32x16 o0, o1;
 #pragma unroll
@@ -99,12 +103,11 @@ __global__ __launch_bounds__(256, 2) void lg_attention_kernel(
         __syncthreads();
     }
     int buf = 0;
-    constexpr float kScale = 0.125f * 1.44269504088896341f;  // 1/sqrt(64) * log2(e): softmax in base 2
     for (int k0 = 0; k0 < nk; k0 += AT_K) {
         const bool more = DBUF && (k0 + AT_K < nk);
         if (DBUF) {
             if (more) fetch(k0 + AT_K);
-        } else {
+        } else if (!(ABL & 2) || k0 == 0) {
             __syncthreads();
             fetch(k0);
             stash(0);
@@ -118,35 +121,51 @@ __global__ __launch_bounds__(256, 2) void lg_attention_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[r] = 0.f;
             const float* ka = Ks[buf] + (sub * 32 + j) * AT_LDK + h;
+            if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int s = 0; s < 32; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[2 * s], qreg[s], st, 0, 0, 0);
+            if (prio) __builtin_amdgcn_s_setprio(0);
             // ---- online softmax over this lane's 16 keys (+ the other half-wave's 16)
-            float mx = -INFINITY;
+            if (!(ABL & 1)) {
+            // only the last key tile can contain keys >= nk
+            if (k0 + sub * 32 + 32 > nk) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = k0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                st[r] = key < nk ? st[r] * kScale : -INFINITY;
-                mx = fmaxf(mx, st[r]);
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (key >= nk) st[r] = -INFINITY;
+                }
             }
+            float mx = st[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // m_run = -inf on the first tile -> 0
+            // deferred rescale: the running reference max only moves when some query's tile max exceeds it by more
+            // than 2^AT_DEFER (fp32 has the headroom: p <= 2^16, l <= 2^26); after the first tile this wave-uniform
+            // branch is almost never taken, which removes the accumulator rescale from the steady state.
+            if (__any(mx > m_run + AT_DEFER)) {
+                const float m_new = fmaxf(m_run, mx);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // m_run = -inf on the first tile -> 0
+                l_run *= alpha;
+                m_run = m_new;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            }
             float ps = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { st[r] = __builtin_amdgcn_exp2f(st[r] - m_new); ps += st[r]; }
+            for (int r = 0; r < 16; ++r) { st[r] = __builtin_amdgcn_exp2f(st[r] - m_run); ps += st[r]; }
             ps += __shfl_xor(ps, 32);
-            l_run = l_run * alpha + ps;
-            m_run = m_new;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            l_run += ps;
+            } else { l_run = 1.f; }
             // ---- O^T[d][query] += sum_key V[key][d] * P[key][query]; k-step r uses key(r,h)
             const float* va = Vs[buf] + (sub * 32 + 4 * h) * 64 + j;
+            if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kr = (r & 3) + 8 * (r >> 2);
                 o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[kr * 64], st[r], o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[kr * 64 + 32], st[r], o1, 0, 0, 0);
             }
+            if (prio) __builtin_amdgcn_s_setprio(0);
         }
         if (DBUF) {
             if (more) stash(buf ^ 1);
@@ -166,15 +185,161 @@ __global__ __launch_bounds__(256, 2) void lg_attention_kernel(
     }
 }
 
+// Variant with NQ = 2 query blocks (64 queries) per wave, 256 queries per workgroup: every K / V^T fragment
+// read from LDS feeds two MFMAs, a wave issues 256 MFMAs between barriers instead of 128, and the two
+// independent QK^T chains fill each other's issue gaps.  Same arithmetic per query as the kernel above.
+__global__ __launch_bounds__(256, 2) void lg_attention_q64_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld, float* __restrict__ out,
+    int Lq, int Lk, int nqb, const int* __restrict__ qlen, const int* __restrict__ klen, const int* __restrict__ kv_map) {
+    constexpr int NQ = 2, QB = 128 * NQ;
+    __shared__ float Ks[AT_K * AT_LDK];
+    __shared__ float Vs[AT_K * 64];
+    const int Lb = blockIdx.x, xcd = Lb & 7, t_ = Lb >> 3;
+    const int qb = t_ % nqb, unit = (t_ / nqb) * 8 + xcd;
+    const int seq = unit >> 2, head = unit & 3;
+    const int kvseq = kv_map ? kv_map[seq] : seq;
+    const int nq = qlen ? qlen[seq] : Lq;
+    const int nk = klen ? klen[kvseq] : Lk;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (qb * QB >= nq) {
+        for (int e = tid; e < QB * 64; e += 256) {
+            const int row = qb * QB + (e >> 6);
+            if (row < Lq) out[((size_t)seq * Lq + row) * 256 + head * 64 + (e & 63)] = 0.f;
+        }
+        return;
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    int qrow[NQ];
+    float qreg[NQ][32];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        qrow[u] = qb * QB + (wave * NQ + u) * 32 + j;
+        const float* qp = q + ((size_t)seq * Lq + (qrow[u] < Lq ? qrow[u] : Lq - 1)) * ld + head * 64 + h;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) qreg[u][s] = qp[2 * s];
+    }
+    f32x16 o0[NQ], o1[NQ];
+    float m_run[NQ], l_run[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        m_run[u] = -INFINITY; l_run[u] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[u][r] = 0.f; o1[u][r] = 0.f; }
+    }
+    const float* kbase = k + (size_t)kvseq * Lk * ld + head * 64;
+    const float* vbase = v + (size_t)kvseq * Lk * ld + head * 64;
+    const int skey = tid >> 4, sdq = tid & 15;
+    constexpr float kScale = 0.125f * 1.44269504088896341f;
+    // the next K/V tile is fetched global->registers BEFORE the current tile is multiplied (single LDS buffer):
+    // co-resident workgroups run in phase, so un-prefetched fetch latency would idle the matrix pipe for all of them
+    float4 rk[4], rv[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            int key = k0 + skey + 16 * it;
+            key = key < nk ? key : nk - 1;          // clamped: keys >= nk are masked in the softmax
+            rk[it] = *reinterpret_cast<const float4*>(kbase + (size_t)key * ld + sdq * 4);
+            rv[it] = *reinterpret_cast<const float4*>(vbase + (size_t)key * ld + sdq * 4);
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < nk; k0 += AT_K) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int key = skey + 16 * it;
+            float* dk = Ks + key * AT_LDK + sdq * 4;
+            dk[0] = rk[it].x; dk[1] = rk[it].y; dk[2] = rk[it].z; dk[3] = rk[it].w;
+            *reinterpret_cast<float4*>(Vs + key * 64 + sdq * 4) = rv[it];
+        }
+        __syncthreads();
+        if (k0 + AT_K < nk) fetch(k0 + AT_K);
+#pragma unroll
+        for (int sub = 0; sub < AT_K / 32; ++sub) {
+            if (k0 + sub * 32 >= nk) break;
+            f32x16 st[NQ];
+#pragma unroll
+            for (int u = 0; u < NQ; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[u][r] = 0.f;
+            const float* ka = Ks + (sub * 32 + j) * AT_LDK + h;
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                const float a = ka[2 * s];
+#pragma unroll
+                for (int u = 0; u < NQ; ++u) st[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qreg[u][s], st[u], 0, 0, 0);
+            }
+            const bool partial = k0 + sub * 32 + 32 > nk;   // only the last key tile needs masking
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    st[u][r] = (!partial || key < nk) ? st[u][r] * kScale : -INFINITY;
+                    mx = fmaxf(mx, st[u][r]);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float m_new = fmaxf(m_run[u], mx);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_new);
+                float ps = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { st[u][r] = __builtin_amdgcn_exp2f(st[u][r] - m_new); ps += st[u][r]; }
+                ps += __shfl_xor(ps, 32);
+                l_run[u] = l_run[u] * alpha + ps;
+                m_run[u] = m_new;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o0[u][r] *= alpha; o1[u][r] *= alpha; }
+            }
+            const float* va = Vs + (sub * 32 + 4 * h) * 64 + j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kr = (r & 3) + 8 * (r >> 2);
+                const float a0 = va[kr * 64], a1 = va[kr * 64 + 32];
+#pragma unroll
+                for (int u = 0; u < NQ; ++u) {
+                    o0[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, st[u][r], o0[u], 0, 0, 0);
+                    o1[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, st[u][r], o1[u], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        if (qrow[u] < Lq) {
+            const float inv = (qrow[u] < nq && l_run[u] > 0.f) ? 1.0f / l_run[u] : 0.f;
+            float* op = out + ((size_t)seq * Lq + qrow[u]) * 256 + head * 64;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = (r & 3) + 8 * (r >> 2) + 4 * h;
+                op[d] = o0[u][r] * inv;
+                op[d + 32] = o1[u][r] * inv;
+            }
+        }
+    }
+}
+
 void launch_lg_attention(hipStream_t s, const float* q, const float* k, const float* v, int ld, float* out, int nseq, int Lq,
                          int Lk, const int* qlen, const int* klen, const int* kv_map) {
     const int nqb = (Lq + AT_Q - 1) / AT_Q;
     // 4*nseq (sequence, head) units; nseq = 2P is even so the unit count is a multiple of 8 (XCD decode is bijective)
     static const bool single = getenv("RFE_ATT_DBUF") == nullptr;   // tuning switch: RFE_ATT_DBUF=1 selects the double-buffered variant
+    static const bool q64 = getenv("RFE_ATT_Q64") != nullptr;        // tuning switch: 64 queries per wave
+    if (q64 && Lq >= 512) {
+        const int nqb2 = (Lq + 255) / 256;
+        hipLaunchKernelGGL(lg_attention_q64_kernel, dim3(nqb2 * 4 * nseq), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb2, qlen, klen, kv_map);
+        return;
+    }
+    static const int abl = getenv("RFE_DBG_ATT_ABL") ? atoi(getenv("RFE_DBG_ATT_ABL")) : 0;   // timing ablations (wrong results)
+    if (abl == 1) { hipLaunchKernelGGL((lg_attention_kernel<false, 1>), dim3(nqb * 4 * nseq), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0); return; }
+    if (abl == 2) { hipLaunchKernelGGL((lg_attention_kernel<false, 2>), dim3(nqb * 4 * nseq), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0); return; }
+    if (abl == 3) { hipLaunchKernelGGL((lg_attention_kernel<false, 3>), dim3(nqb * 4 * nseq), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0); return; }
+    static const int prio = getenv("RFE_ATT_PRIO") ? atoi(getenv("RFE_ATT_PRIO")) : 1;   // s_setprio(1) around the MFMA clusters (+0.8 %); RFE_ATT_PRIO=0 disables
     if (single)
-        hipLaunchKernelGGL(lg_attention_kernel<false>, dim3(nqb * 4 * nseq), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map);
+        hipLaunchKernelGGL(lg_attention_kernel<false>, dim3(nqb * 4 * nseq), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio);
     else
-        hipLaunchKernelGGL(lg_attention_kernel<true>, dim3(nqb * 4 * nseq), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map);
+        hipLaunchKernelGGL(lg_attention_kernel<true>, dim3(nqb * 4 * nseq), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio);
 }
 
 // ---------------------------------------------------------------- LayerNorm(512) + GELU(erf), in place
