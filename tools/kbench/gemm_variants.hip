@@ -129,6 +129,119 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_v(const float* __rest
         }
 }
 
+// ---- direct-to-LDS (global_load_lds, 16 B per lane) variant: unpadded 128-B rows, XOR-swizzled 16-B slots
+// (slot' = slot ^ ((row >> 1) & 7)) so that ds_read_b128 fragment reads are bank-conflict free; the swizzle is
+// applied on the per-lane SOURCE address (the LDS destination of an LDS-DMA is lane-linear).
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+template <int MB, int NB, bool DBUF>
+__global__ __launch_bounds__(256, 2) void gemm_glds(const float* __restrict__ A, const float* __restrict__ B,
+                                                    const float* __restrict__ bias, float* __restrict__ C, int M, int N, int K) {
+    constexpr int BMt = 2 * MB * 32, BNt = 2 * NB * 32, NBUF = DBUF ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* As = lds;                         // [NBUF][BMt][32]
+    float* Bs = lds + NBUF * BMt * 32;       // [NBUF][BNt][32]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * BMt, n0 = blockIdx.x * BNt;
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const float bv = bias[n0 + wn * NB * 32 + nb * 32 + i];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = bv;
+    }
+    // DMA: each wave instruction moves 8 rows x 128 B; wave w owns rows [w*R/4, (w+1)*R/4) of each operand tile
+    const int drow = lane >> 3, dp = lane & 7;
+    auto stage = [&](int k0, int buf) {
+#pragma unroll
+        for (int it = 0; it < BMt / 32; ++it) {
+            const int row0 = wave * (BMt / 4) + it * 8, row = row0 + drow;
+            const float* src = A + (size_t)(m0 + row) * K + k0 + ((dp ^ ((row >> 1) & 7)) << 2);
+            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(As + (buf * BMt + row0) * 32), 16, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < BNt / 32; ++it) {
+            const int row0 = wave * (BNt / 4) + it * 8, row = row0 + drow;
+            const float* src = B + (size_t)(n0 + row) * K + k0 + ((dp ^ ((row >> 1) & 7)) << 2);
+            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(Bs + (buf * BNt + row0) * 32), 16, 0, 0);
+        }
+    };
+    auto compute = [&](int buf) {
+        const int sw = (i >> 1) & 7;
+        const float* ap = As + (buf * BMt + wm * MB * 32 + i) * 32;
+        const float* bp = Bs + (buf * BNt + wn * NB * 32 + i) * 32;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float4 a4[MB], b4[NB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) a4[mb] = *reinterpret_cast<const float4*>(ap + mb * 32 * 32 + ((c ^ sw) << 2));
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) b4[nb] = *reinterpret_cast<const float4*>(bp + nb * 32 * 32 + ((c ^ sw) << 2));
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const float av = half ? (h ? a4[mb].w : a4[mb].z) : (h ? a4[mb].y : a4[mb].x);
+                        const float bv = half ? (h ? b4[nb].w : b4[nb].z) : (h ? b4[nb].y : b4[nb].x);
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mb][nb], 0, 0, 0);
+                    }
+        }
+    };
+    if (DBUF) {
+        stage(0, 0);
+        __syncthreads();
+        int buf = 0;
+        for (int k0 = 0; k0 < K; k0 += 32) {
+            if (k0 + 32 < K) stage(k0 + 32, buf ^ 1);
+            compute(buf);
+            __syncthreads();
+            buf ^= 1;
+        }
+    } else {
+        for (int k0 = 0; k0 < K; k0 += 32) {
+            __syncthreads();
+            stage(k0, 0);
+            __syncthreads();
+            compute(0);
+        }
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (wm * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) C[(size_t)m * N + n0 + (wn * NB + nb) * 32 + i] = acc[mb][nb][r];
+        }
+}
+
+template <int MB, int NB, bool DBUF>
+static double run_glds(const char* name, const float* A, const float* B, const float* bias, float* C, int M, int N, int K) {
+    constexpr int BMt = 2 * MB * 32, BNt = 2 * NB * 32;
+    const size_t lds = (size_t)(DBUF ? 2 : 1) * (BMt + BNt) * 32 * 4;
+    if (N % BNt || M % BMt) return 0;
+    auto kern = gemm_glds<MB, NB, DBUF>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid(N / BNt, M / BMt);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, A, B, bias, C, M, N, K);
+    hipEventRecord(e0);
+    const int reps = 20;
+    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, A, B, bias, C, M, N, K);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double tf = 2.0 * M * N * K * reps / (ms * 1e-3) / 1e12;
+    printf("  %-34s M=%d N=%d K=%d lds=%zuKB  %.1f us  %.1f TF\n", name, M, N, K, lds / 1024, ms / reps * 1e3, tf);
+    return tf;
+}
+
 template <int WM, int WN, int MB, int NB, int BK, bool DBUF, int MINW, int PIPE = 0>
 static double run(const char* name, const float* A, const float* B, const float* bias, float* C, int M, int N, int K) {
     constexpr int BMt = WM * MB * 32, BNt = WN * NB * 32, LDT = BK + 1;
@@ -173,6 +286,19 @@ int main() {
     for (auto& s : shapes) {
         const int N = s[0], K = s[1];
         printf("N=%d K=%d\n", N, K);
+        {   // correctness of the glds variant against the reference tiling (bitwise: same k order)
+            std::vector<float> c0((size_t)4096 * N), c1((size_t)4096 * N);
+            run<2, 2, 2, 2, 32, false, 2>("ref", A, B, bias, C, M, N, K);
+            hipMemcpy(c0.data(), C, c0.size() * 4, hipMemcpyDeviceToHost);
+            hipMemset(C, 0, (size_t)4096 * N * 4);
+            run_glds<2, 4, false>("glds 128x256 single", A, B, bias, C, M, N, K);
+            hipMemcpy(c1.data(), C, c1.size() * 4, hipMemcpyDeviceToHost);
+            size_t bad = 0; for (size_t q = 0; q < c0.size(); ++q) bad += c0[q] != c1[q];
+            printf("  glds vs ref mismatches: %zu of %zu\n", bad, c0.size());
+        }
+        run_glds<2, 4, true>("glds 128x256 dbuf", A, B, bias, C, M, N, K);
+        run_glds<2, 2, false>("glds 128x128 single", A, B, bias, C, M, N, K);
+        run_glds<2, 2, true>("glds 128x128 dbuf", A, B, bias, C, M, N, K);
         run<2, 2, 2, 2, 32, false, 2>("2x2w 64x64 BK32 single", A, B, bias, C, M, N, K);
         run<2, 2, 2, 2, 32, false, 2, 1>("2x2w 64x64 BK32 single pipe1", A, B, bias, C, M, N, K);
         run<2, 2, 2, 2, 32, false, 2, 2>("2x2w 64x64 BK32 single pipe2", A, B, bias, C, M, N, K);
