@@ -406,9 +406,10 @@ namespace {
 struct LgBuffers {
     float *x, *kn, *cs, *sn, *qkv, *ctx, *msg, *h, *md, *z, *sim, *rowlse, *collse, *mx0;
     int32_t *a0, *a1, *lens, *kvmap;
+    char* extra;   // caller-sized scratch region carved after the fixed buffers
 };
 
-size_t lg_ws_bytes(int P, int L) {
+size_t lg_ws_bytes(int P, int L, size_t extra_bytes = 0) {
     const size_t rows = (size_t)2 * P * L;
     size_t t = 0;
     t += al(rows * 256 * 4) * 4;  // x ctx msg md
@@ -416,9 +417,9 @@ size_t lg_ws_bytes(int P, int L) {
     t += al((size_t)P * L * L * 4);
     t += al((size_t)P * L * 4) * 5;
     t += al((size_t)2 * P * 4) * 2;
-    return t + 4096;
+    return t + al(extra_bytes) + 4096;
 }
-void lg_carve(void* ws, int P, int L, LgBuffers& b) {
+void lg_carve(void* ws, int P, int L, LgBuffers& b, size_t extra_bytes = 0) {
     const size_t rows = (size_t)2 * P * L;
     Bump a(ws);
     b.x = a.take<float>(rows * 256); b.ctx = a.take<float>(rows * 256); b.msg = a.take<float>(rows * 256);
@@ -429,6 +430,7 @@ void lg_carve(void* ws, int P, int L, LgBuffers& b) {
     b.rowlse = a.take<float>((size_t)P * L); b.collse = a.take<float>((size_t)P * L); b.mx0 = a.take<float>((size_t)P * L);
     b.a0 = a.take<int32_t>((size_t)P * L); b.a1 = a.take<int32_t>((size_t)P * L);
     b.lens = a.take<int32_t>((size_t)2 * P); b.kvmap = a.take<int32_t>((size_t)2 * P);
+    b.extra = a.take<char>(extra_bytes);
 }
 
 // x + ffn([x | msg]) in place on b.x
@@ -614,10 +616,11 @@ extern "C" int rfe_extract_match_stream_dev(rfe_ctx* c, const uint8_t* img, int 
     if ((rc = lg_check(c, B - 1, Kmax, Kmax))) return rc;
     if (!S || !pairs || !ms) return fail(c, RFE_ERR_INVALID, "stream: null match output");
     const int P = B - 1, L = ((Kmax + 3) / 4) * 4;
-    if ((rc = ensure_ws(c, &c->ws_lg, &c->ws_lg_bytes, lg_ws_bytes(P, L) + al((size_t)B * Kmax * 8)))) return rc;
+    const size_t kn_bytes = (size_t)B * Kmax * 8;   // normalised keypoints of all B frames
+    if ((rc = ensure_ws(c, &c->ws_lg, &c->ws_lg_bytes, lg_ws_bytes(P, L, kn_bytes)))) return rc;
     LgBuffers b;
-    lg_carve(c->ws_lg, P, L, b);
-    float* kn_all = (float*)((char*)c->ws_lg + lg_ws_bytes(P, L) - 4096 + 256);
+    lg_carve(c->ws_lg, P, L, b, kn_bytes);
+    float* kn_all = (float*)b.extra;
     hipStream_t s = c->stream;
     static const bool dedup = getenv("RFE_NO_SELF_DEDUP") == nullptr;   // tuning / test switch
     if (!dedup || L != Kmax) {
@@ -823,10 +826,10 @@ extern "C" int rfe_k_lightglue_taps(rfe_ctx* c, const float* k0n, const float* k
     RFE_HIP(c, hipSetDevice(c->device));
     const int L = ((std::max(M, N) + 3) / 4) * 4, cap = std::min(M, N);
     const size_t extra = al((size_t)L * L * 4) + al(64) * 3 + al((size_t)cap * 8) + al((size_t)cap * 4);
-    if ((rc = ensure_ws(c, &c->ws_lg, &c->ws_lg_bytes, lg_ws_bytes(1, L) + extra))) return rc;
+    if ((rc = ensure_ws(c, &c->ws_lg, &c->ws_lg_bytes, lg_ws_bytes(1, L, extra)))) return rc;
     LgBuffers b;
-    lg_carve(c->ws_lg, 1, L, b);
-    char* p = (char*)c->ws_lg + lg_ws_bytes(1, L) - 4096 + 256;
+    lg_carve(c->ws_lg, 1, L, b, extra);
+    char* p = b.extra;
     float* sc = (float*)p; p += al((size_t)L * L * 4);
     int32_t* dm = (int32_t*)p; p += al(64); int32_t* dn = (int32_t*)p; p += al(64); int32_t* dS = (int32_t*)p; p += al(64);
     int32_t* dp = (int32_t*)p; p += al((size_t)cap * 8); float* dms = (float*)p;

@@ -16,8 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="no g++")
-def test_cpp_shims_match_oracle(tmp_path, oracle):
-    H, W = 120, 160
+@pytest.mark.parametrize("H,W", [(120, 160), (480, 752)])   # small case, and the EuRoC stereo size of BASELINE config 5
+def test_cpp_shims_match_oracle(tmp_path, oracle, H, W):
     exe = str(tmp_path / "shim_driver")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "shim_driver.cpp"), "-o", exe,
