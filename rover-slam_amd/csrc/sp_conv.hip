@@ -160,17 +160,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     const float* in_b = in + (size_t)b * H * W * CIN;
     const float* wp_ct = wp + (size_t)ct * (CIN / CK) * KCH * NT;
 
+    // per-thread staging slots (pixel, 4-channel group) are the same for every chunk: hoist the index arithmetic
+    constexpr int S_IT = (IH * IW * (CK / 4) + 255) / 256;
+    int s_goff[S_IT], s_loff[S_IT];   // global element offset (-1: zero padding / unused slot), LDS word offset
+#pragma unroll
+    for (int it = 0; it < S_IT; ++it) {
+        const int idx = tid + it * 256;
+        const int cq = idx % (CK / 4), pix = idx / (CK / 4);
+        const int py = pix / IW, px = pix % IW;
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        const bool slot = idx < IH * IW * (CK / 4);
+        s_loff[it] = slot ? (cq * 4) * PLANE + py * TWS + px : -1;
+        s_goff[it] = (slot && gy >= 0 && gy < H && gx >= 0 && gx < W) ? (gy * W + gx) * CIN + cq * 4 : -1;
+    }
+
     for (int ch = 0; ch < CIN / CK; ++ch) {
         __syncthreads();
         // ---- stage input tile: NHWC global -> channel-planar LDS (zero padding materialised)
-        for (int idx = tid; idx < IH * IW * (CK / 4); idx += 256) {
-            const int cq = idx % (CK / 4), pix = idx / (CK / 4);
-            const int py = pix / IW, px = pix % IW;
-            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+#pragma unroll
+        for (int it = 0; it < S_IT; ++it) {
+            if (s_loff[it] < 0) continue;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-                v = *reinterpret_cast<const float4*>(in_b + ((size_t)gy * W + gx) * CIN + ch * CK + cq * 4);
-            float* d = lds_in + (cq * 4) * PLANE + py * TWS + px;
+            if (s_goff[it] >= 0) v = *reinterpret_cast<const float4*>(in_b + s_goff[it] + ch * CK);
+            float* d = lds_in + s_loff[it];
             d[0] = v.x; d[PLANE] = v.y; d[2 * PLANE] = v.z; d[3 * PLANE] = v.w;
         }
         conv_stage_weights<CK>(lds_w, wp_ct + (size_t)ch * KCH * NT, tid);
@@ -296,23 +308,35 @@ __global__ __launch_bounds__(256, 2) void conv1ab_fused_kernel(
         lds_img[idx] = v;
     }
 
+    // per-thread pixel slots of the haloed tile are the same for every chunk: hoist index arithmetic and the
+    // nine image taps (they only depend on the pixel), leaving 9 fmaf per channel in the chunk loop
+    constexpr int P_IT = (IH * IW + 255) / 256;
+    int p_loff[P_IT]; bool p_inb[P_IT]; float p_iv[P_IT][9];
+    __syncthreads();   // image tile complete
+#pragma unroll
+    for (int it = 0; it < P_IT; ++it) {
+        const int p = tid + it * 256;
+        const int py = p / IW, px = p % IW;
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        p_loff[it] = p < IH * IW ? py * TWS + px : -1;
+        p_inb[it] = gy >= 0 && gy < H && gx >= 0 && gx < W;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) p_iv[it][k] = p < IH * IW ? lds_img[(py + k / 3) * MW + px + k % 3] : 0.f;
+    }
+
     for (int ch = 0; ch < CIN / CK; ++ch) {
         __syncthreads();
         // ---- conv1a for CK channels on the haloed tile; pixels outside the image are conv1b's zero padding
-        for (int p = tid; p < IH * IW; p += 256) {
-            const int py = p / IW, px = p % IW;
-            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-            const bool inb = gy >= 0 && gy < H && gx >= 0 && gx < W;
-            float iv[9];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) iv[k] = lds_img[(py + k / 3) * MW + px + k % 3];
+        for (int it = 0; it < P_IT; ++it) {
+            if (p_loff[it] < 0) continue;
 #pragma unroll
             for (int e = 0; e < CK; ++e) {
                 const int c = ch * CK + e;
                 float a = b1a[c];
 #pragma unroll
-                for (int k = 0; k < 9; ++k) a = fmaf(iv[k], w1a[k * 64 + c], a);
-                lds_in[e * PLANE + py * TWS + px] = inb ? fmaxf(a, 0.f) : 0.f;
+                for (int k = 0; k < 9; ++k) a = fmaf(p_iv[it][k], w1a[k * 64 + c], a);
+                lds_in[e * PLANE + p_loff[it]] = p_inb[it] ? fmaxf(a, 0.f) : 0.f;
             }
         }
         conv_stage_weights<CK>(lds_w, wp + (size_t)ch * KCH * NT, tid);
