@@ -34,7 +34,7 @@ SP_CONV = {"conv1b": (64, 64, 1), "conv2a": (64, 64, 2), "conv2b": (64, 64, 2), 
            "convDa": (128, 256, 8)}
 
 
-def stage_flops(name, B, lens):
+def stage_flops(name, B, lens, launches=None):
     """ALGORITHMIC FLOPs of one launch of a profiled stage (DESIGN.md 'Work per unit')."""
     P = B - 1
     rows = 2 * P * KMAX
@@ -53,8 +53,10 @@ def stage_flops(name, B, lens):
     rows_f = B * KMAX
     if name == "lg_qkv":            # 9 launches: 8 on 2P sequences + 1 on B frames
         return 2.0 * 256 * 768 * (8 * rows + rows_f) / 9
-    if name == "lg_proj":           # 19 launches: 9 self out-proj (one on frames) + 9 cross out-proj + final_proj
-        return 2.0 * 256 * 256 * (18 * rows + rows_f) / 19
+    if name == "lg_proj":
+        if launches == 1:           # default: the attention out-projections are folded into ffn.0 at load time -> final_proj only
+            return 2.0 * 256 * 256 * rows
+        return 2.0 * 256 * 256 * (18 * rows + rows_f) / 19   # RFE_LG_NO_FOLD=1: 9 self (one on frames) + 9 cross + final_proj
     if name == "lg_ffn1":           # 18 launches, one on frames
         return 2.0 * 512 * 512 * (17 * rows + rows_f) / 18
     if name == "lg_ffn2":
@@ -232,13 +234,13 @@ def main():
         # dominant kernel = the profiled stage with the largest accumulated time
         dom = max(prof.items(), key=lambda kv: kv[1][0])
         dom_name, (dom_ms, dom_calls) = dom
-        fl = stage_flops(dom_name, B, lens)
+        fl = stage_flops(dom_name, B, lens, dom_calls // args.steps)
         avg_ms = dom_ms / max(dom_calls, 1)
         achieved = fl / (avg_ms * 1e-3) / 1e12 if fl else None
         traffic, traffic_src = pmc_traffic(dom_name)
         stages = {}
         for k, (msv, calls) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
-            f = stage_flops(k, B, lens)
+            f = stage_flops(k, B, lens, calls // args.steps)
             stages[k] = {"ms_per_step": round(msv / args.steps, 4), "launches_per_step": calls // args.steps,
                          "tflops": round(f / (msv / calls * 1e-3) / 1e12, 2) if f else None}
         out = {

@@ -215,10 +215,51 @@ static int set_lg(rfe_ctx* c, const float* blob) {
     }
     W.wp = take(256 * 256); W.bp = take(256); W.wm = take(256); W.bm = take(1);
     if (p - c->lg.blob != LG_COUNT) return fail(c, RFE_ERR_INVALID, "internal: LightGlue blob layout mismatch");
-    // pack the two cross-attention input projections of every layer into one [512][256] Linear
+    // derived weights, built once at load time:
+    //  * the two cross-attention input projections of every layer packed into one [512][256] Linear;
+    //  * the attention output projection (Wo, bo) folded into the message half of the first FFN Linear:
+    //    the message m = ctx Wo^T + bo only ever feeds ffn.0, so  W1 [x | m] + b1 = [W1a | W1b Wo] [x | ctx] + (b1 + W1b bo).
+    //    The product is formed in double precision on the host; it removes 18 of the 19 256x256 GEMM launches
+    //    per forward (mathematically identical, rounding differs at the 1e-7 level; RFE_LG_NO_FOLD=1 keeps them).
     if (W.extra) { RFE_HIP(c, hipFree(W.extra)); W.extra = nullptr; }
-    const size_t per = 512 * 256 + 512;
+    const size_t per = 512 * 256 + 512 + 2 * (512 * 512 + 512);
     RFE_HIP(c, hipMalloc((void**)&W.extra, per * LG_LAYERS * sizeof(float)));
+    {
+        std::vector<float> w1f(512 * 512), b1f(512);
+        std::vector<double> acc(256);
+        size_t off = 64;   // host blob walk, same order as above (Wr first)
+        for (int l = 0; l < LG_LAYERS; ++l) {
+            LgLayerDev& L = W.L[l];
+            float* base = W.extra + per * l + 512 * 256 + 512;
+            L.w1f = base; L.b1f = base + 512 * 512; L.cw1f = L.b1f + 512; L.cb1f = L.cw1f + 512 * 512;
+            const float* h = blob + off;
+            const float* s_wo = h + 768 * 256 + 768; const float* s_bo = s_wo + 256 * 256;
+            const float* s_w1 = s_bo + 256; const float* s_b1 = s_w1 + 512 * 512;
+            const float* cr = s_b1 + 512 + 512 + 512 + 256 * 512 + 256;           // start of the cross block
+            const float* c_wo = cr + 2 * (256 * 256 + 256); const float* c_bo = c_wo + 256 * 256;
+            const float* c_w1 = c_bo + 256; const float* c_b1 = c_w1 + 512 * 512;
+            off += 1250560;   // floats per layer (self 658176 + cross 592384)
+            for (int blk = 0; blk < 2; ++blk) {
+                const float* wo = blk ? c_wo : s_wo; const float* bo = blk ? c_bo : s_bo;
+                const float* w1 = blk ? c_w1 : s_w1; const float* b1 = blk ? c_b1 : s_b1;
+                for (int i = 0; i < 512; ++i) {
+                    const float* w1row = w1 + (size_t)i * 512;
+                    for (int j = 0; j < 256; ++j) { w1f[(size_t)i * 512 + j] = w1row[j]; acc[j] = 0.0; }
+                    double bacc = b1[i];
+                    for (int k = 0; k < 256; ++k) {
+                        const double wv = w1row[256 + k];
+                        const float* worow = wo + (size_t)k * 256;
+                        for (int j = 0; j < 256; ++j) acc[j] += wv * (double)worow[j];
+                        bacc += wv * (double)bo[k];
+                    }
+                    for (int j = 0; j < 256; ++j) w1f[(size_t)i * 512 + 256 + j] = (float)acc[j];
+                    b1f[i] = (float)bacc;
+                }
+                RFE_HIP(c, hipMemcpy(blk ? L.cw1f : L.w1f, w1f.data(), w1f.size() * 4, hipMemcpyHostToDevice));
+                RFE_HIP(c, hipMemcpy(blk ? L.cb1f : L.b1f, b1f.data(), b1f.size() * 4, hipMemcpyHostToDevice));
+            }
+        }
+    }
     for (int l = 0; l < LG_LAYERS; ++l) {
         LgLayerDev& L = W.L[l];
         L.cwqkv = W.extra + per * l; L.cbqkv = L.cwqkv + 512 * 256;
@@ -433,13 +474,15 @@ void lg_carve(void* ws, int P, int L, LgBuffers& b, size_t extra_bytes = 0) {
     b.extra = a.take<char>(extra_bytes);
 }
 
-// x + ffn([x | msg]) in place on b.x
-void lg_ffn(rfe_ctx* c, LgBuffers& b, float* x, int rows, const float* w1, const float* b1, const float* g, const float* be,
-            const float* w2, const float* b2) {
+bool lg_fold() { static const bool f = getenv("RFE_LG_NO_FOLD") == nullptr; return f; }
+
+// x + ffn([x | msg]) in place on x
+void lg_ffn(rfe_ctx* c, LgBuffers& b, float* x, const float* second, int rows, const float* w1, const float* b1, const float* g,
+            const float* be, const float* w2, const float* b2) {
     hipStream_t s = c->stream;
-    { ProfScope p(c, "lg_ffn1");
+    { ProfScope p(c, "lg_ffn1");   // A = [x | second]: second is the message, or the attention context when Wo is folded into W1
       GemmArgs a = gemm_plain(x, 256, w1, 512, b1, b.h, 512, rows, 512, 512);
-      a.A2 = b.msg; a.lda2 = 256; a.K1 = 256;
+      a.A2 = second; a.lda2 = 256; a.K1 = 256;
       launch_gemm_nt(s, a); }
     { ProfScope p(c, "lg_ln_gelu"); launch_lg_ln_gelu(s, b.h, g, be, rows); }
     { ProfScope p(c, "lg_ffn2");
@@ -458,8 +501,12 @@ void lg_self_block(rfe_ctx* c, LgBuffers& b, const LgLayerDev& Lw, float* x, con
       a.rope_cs = cs; a.rope_sn = sn; a.rope_ncols = 512;
       launch_gemm_nt(s, a); }
     { ProfScope p(c, "lg_attention"); launch_lg_attention(s, b.qkv, b.qkv + 256, b.qkv + 512, 768, b.ctx, nseq, L, L, lens, lens, nullptr); }
-    { ProfScope p(c, "lg_proj"); launch_gemm_nt(s, gemm_plain(b.ctx, 256, Lw.wo, 256, Lw.bo, b.msg, 256, rows, 256, 256)); }
-    lg_ffn(c, b, x, rows, Lw.w1, Lw.b1, Lw.lng, Lw.lnb, Lw.w2, Lw.b2);
+    if (lg_fold()) {
+        lg_ffn(c, b, x, b.ctx, rows, Lw.w1f, Lw.b1f, Lw.lng, Lw.lnb, Lw.w2, Lw.b2);
+    } else {
+        { ProfScope p(c, "lg_proj"); launch_gemm_nt(s, gemm_plain(b.ctx, 256, Lw.wo, 256, Lw.bo, b.msg, 256, rows, 256, 256)); }
+        lg_ffn(c, b, x, b.msg, rows, Lw.w1, Lw.b1, Lw.lng, Lw.lnb, Lw.w2, Lw.b2);
+    }
 }
 
 // runs the 9 layers + assignment on already staged b.x / b.kn / b.lens / b.kvmap.
@@ -477,8 +524,12 @@ int lg_forward(rfe_ctx* c, LgBuffers& b, int P, int L, float thr, int cap, int32
         // ---- cross block
         { ProfScope p(c, "lg_cross_qkv"); launch_gemm_nt(s, gemm_plain(b.x, 256, Lw.cwqkv, 256, Lw.cbqkv, b.qkv, 512, rows, 512, 256)); }
         { ProfScope p(c, "lg_attention"); launch_lg_attention(s, b.qkv, b.qkv, b.qkv + 256, 512, b.ctx, nseq, L, L, b.lens, b.lens, b.kvmap); }
-        { ProfScope p(c, "lg_proj"); launch_gemm_nt(s, gemm_plain(b.ctx, 256, Lw.cwo, 256, Lw.cbo, b.msg, 256, rows, 256, 256)); }
-        lg_ffn(c, b, b.x, rows, Lw.cw1, Lw.cb1, Lw.clng, Lw.clnb, Lw.cw2, Lw.cb2);
+        if (lg_fold()) {
+            lg_ffn(c, b, b.x, b.ctx, rows, Lw.cw1f, Lw.cb1f, Lw.clng, Lw.clnb, Lw.cw2, Lw.cb2);
+        } else {
+            { ProfScope p(c, "lg_proj"); launch_gemm_nt(s, gemm_plain(b.ctx, 256, Lw.cwo, 256, Lw.cbo, b.msg, 256, rows, 256, 256)); }
+            lg_ffn(c, b, b.x, b.msg, rows, Lw.cw1, Lw.cb1, Lw.clng, Lw.clnb, Lw.cw2, Lw.cb2);
+        }
     }
     // ---- assignment
     { ProfScope p(c, "lg_proj");

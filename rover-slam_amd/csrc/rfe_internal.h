@@ -38,6 +38,9 @@ struct LgLayerDev {
     float *wqkv, *bqkv, *wo, *bo, *w1, *b1, *lng, *lnb, *w2, *b2;
     float *cwqk, *cbqk, *cwv, *cbv, *cwo, *cbo, *cw1, *cb1, *clng, *clnb, *cw2, *cb2;
     float *cwqkv, *cbqkv;   // packed [512][256] = [Wqk ; Wv] and [512] bias (device copy made at load time)
+    // attention output projection folded into the first FFN Linear (made at load time, see set_lg):
+    // ffn1([x | ctx Wo^T + bo]) == [x | ctx] [W1a | W1b Wo]^T + (b1 + W1b bo)
+    float *w1f, *b1f, *cw1f, *cb1f;
 };
 struct LgWeightsDev {
     float* blob = nullptr;  // whole canonical blob on device; pointers below index into it
