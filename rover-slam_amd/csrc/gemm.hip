@@ -23,7 +23,8 @@ constexpr int BK = 32, LDT = BK + 1;
 // (tools/kbench/gemm_variants.hip: 119-132 TFLOP/s vs 110-125 for 128x128 double-buffered).
 // MB = 32-row MFMA blocks per wave (2 for throughput; 1 gives 64-row tiles for small, latency-bound problems:
 // a single 1024-keypoint pair has only M = 2048 rows, 16 tiles of 128 x 256 would use 16 of the 256 CUs).
-template <int MB, int NB>
+// TEPI: LDS-transposed whole-row epilogue (needed for the residual / rotary variants); false = per-lane 4-byte stores
+template <int MB, int NB, bool TEPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     constexpr int BM = MB * 64, BN = NB * 64;
     __shared__ float lds_ab[(BM + BN) * LDT];   // A tile | B tile; reused for the rotary tables in the epilogue
@@ -59,17 +60,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     // (their products land in accumulators that are never stored), so the loop has no bounds branches.
     constexpr int A_IT = BM / 32, B_IT = BN / 32;
     const int lrow = tid >> 3, lkq = tid & 7;
-    size_t aoff[A_IT], a2off[A_IT], boff[B_IT];
+    // 32-bit element offsets from wave-uniform tile bases: loads use the SGPR-base + VGPR-offset form
+    // (64-bit per-lane addresses cost 32 VGPRs and ~20 u64 adds per K tile)
+    int mlast = M - 1 - m0; mlast = mlast < BM - 1 ? mlast : BM - 1;          // last valid row of this tile
+    int nlast = g.N - 1 - n0; nlast = nlast < BN - 1 ? nlast : BN - 1;
+    const float* const At = A + (size_t)m0 * g.lda;
+    const float* const A2t = A2 ? A2 + (size_t)m0 * g.lda2 : nullptr;
+    const float* const Bt = B + (size_t)n0 * g.ldb;
+    int aoff[A_IT], a2off[A_IT], boff[B_IT];
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-        int row = m0 + lrow + 32 * it; row = row < M ? row : M - 1;
-        aoff[it] = (size_t)row * g.lda + lkq * 4;
-        a2off[it] = (size_t)row * g.lda2 + lkq * 4;
+        int row = lrow + 32 * it; row = row < mlast ? row : mlast;
+        aoff[it] = row * g.lda + lkq * 4;
+        a2off[it] = row * g.lda2 + lkq * 4;
     }
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-        int row = n0 + lrow + 32 * it; row = row < g.N ? row : g.N - 1;
-        boff[it] = (size_t)row * g.ldb + lkq * 4;
+        int row = lrow + 32 * it; row = row < nlast ? row : nlast;
+        boff[it] = row * g.ldb + lkq * 4;
     }
     float* const da = As + lrow * LDT + lkq * 4;
     float* const db = Bs + lrow * LDT + lkq * 4;
@@ -78,15 +86,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 
     for (int k0 = 0; k0 < g.K; k0 += BK) {
         float4 ra[A_IT], rb[B_IT];
-        if (A2 && k0 >= g.K1) {
+        if (A2t && k0 >= g.K1) {
+            const float* base = A2t + (k0 - g.K1);
 #pragma unroll
-            for (int it = 0; it < A_IT; ++it) ra[it] = *reinterpret_cast<const float4*>(A2 + a2off[it] + (k0 - g.K1));
+            for (int it = 0; it < A_IT; ++it) ra[it] = *reinterpret_cast<const float4*>(base + a2off[it]);
         } else {
+            const float* base = At + k0;
 #pragma unroll
-            for (int it = 0; it < A_IT; ++it) ra[it] = *reinterpret_cast<const float4*>(A + aoff[it] + k0);
+            for (int it = 0; it < A_IT; ++it) ra[it] = *reinterpret_cast<const float4*>(base + aoff[it]);
         }
+        {
+            const float* base = Bt + k0;
 #pragma unroll
-        for (int it = 0; it < B_IT; ++it) rb[it] = *reinterpret_cast<const float4*>(B + boff[it] + k0);
+            for (int it = 0; it < B_IT; ++it) rb[it] = *reinterpret_cast<const float4*>(base + boff[it]);
+        }
         __syncthreads();   // previous tile fully consumed
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) { float* d = da + it * 32 * LDT; d[0] = ra[it].x; d[1] = ra[it].y; d[2] = ra[it].z; d[3] = ra[it].w; }
@@ -107,6 +120,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
         }
     }
 
+    if (!TEPI) {   // plain bias (+alpha, +ReLU) epilogue: 128-B coalesced stores straight from the D layout
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m >= M) continue;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int n = n0 + (wn * NB + nb) * 32 + i;
+                    if (n >= g.N) continue;
+                    float v = acc[mb][nb][r] * g.alpha;
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    C[(size_t)m * g.ldc + n] = v;
+                }
+            }
+        return;
+    }
     // ---- epilogue: accumulators (lane = column) are transposed through the now free A/B LDS space in 32-row
     // chunks so that residual loads and result stores are whole-row float4 accesses (4x fewer memory
     // instructions than per-lane 4-byte accesses; the residual read alone cost 25 % of ffn2 before).
@@ -174,16 +205,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 void launch_gemm_nt(hipStream_t s, const GemmArgs& g) {
     const int batch = g.batch > 0 ? g.batch : 1;
     auto tiles = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * batch; };
+    static const bool force_tepi = getenv("RFE_GEMM_TEPI") != nullptr;   // tuning switch
+    const bool tepi = force_tepi || g.R != nullptr || g.rope_cs != nullptr;
+#define RFE_GEMM_GO(MB_, NB_, GRID)                                                                  \
+    do {                                                                                             \
+        if (tepi) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, true>), GRID, dim3(256), 0, s, g);    \
+        else hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, false>), GRID, dim3(256), 0, s, g);        \
+    } while (0)
     // largest tile that still gives every CU a workgroup; small problems (single-pair latency) fall to 64 x 64
-    if (g.N % 256 == 0 && tiles(128, 256) >= 256) {
-        hipLaunchKernelGGL((gemm_nt_kernel<2, 4>), dim3(g.N / 256, (g.M + 127) / 128, batch), dim3(256), 0, s, g);
-    } else if (tiles(128, 128) >= 256 || g.M > 8192) {
-        hipLaunchKernelGGL((gemm_nt_kernel<2, 2>), dim3((g.N + 127) / 128, (g.M + 127) / 128, batch), dim3(256), 0, s, g);
-    } else if (tiles(64, 128) >= 256) {
-        hipLaunchKernelGGL((gemm_nt_kernel<1, 2>), dim3((g.N + 127) / 128, (g.M + 63) / 64, batch), dim3(256), 0, s, g);
-    } else {
-        hipLaunchKernelGGL((gemm_nt_kernel<1, 1>), dim3((g.N + 63) / 64, (g.M + 63) / 64, batch), dim3(256), 0, s, g);
-    }
+    if (g.N % 256 == 0 && tiles(128, 256) >= 256) RFE_GEMM_GO(2, 4, dim3(g.N / 256, (g.M + 127) / 128, batch));
+    else if (tiles(128, 128) >= 256 || g.M > 8192) RFE_GEMM_GO(2, 2, dim3((g.N + 127) / 128, (g.M + 127) / 128, batch));
+    else if (tiles(64, 128) >= 256) RFE_GEMM_GO(1, 2, dim3((g.N + 127) / 128, (g.M + 63) / 64, batch));
+    else RFE_GEMM_GO(1, 1, dim3((g.N + 63) / 64, (g.M + 63) / 64, batch));
 }
 
 }  // namespace rfe

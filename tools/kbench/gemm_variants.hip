@@ -272,6 +272,11 @@ int main() {
     CK(hipMemcpy(A, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(B, h.data(), (size_t)768 * 512 * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(bias, h.data(), 768 * 4, hipMemcpyHostToDevice));
+    {   // clock / power warm-up: the first ~0.2 s of a process run 10-15 % slower (measured with gemm_bisect: the same
+        // kernel gives 115 TF as the first variant and 131 TF as the last) -- never compare variants without it
+        for (int w = 0; w < 40; ++w) hipLaunchKernelGGL(mfma_peak, dim3(1024), dim3(256), 0, 0, o, 20000);
+        hipDeviceSynchronize();
+    }
     {   // MFMA ceiling
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         const int iters = 20000, blocks = 256 * 4;
