@@ -109,6 +109,73 @@ def cpu_baseline(frames, wsp, wlg):
                       f"OpenMP on {os.cpu_count()} host threads, {dt:.1f} s; {nf - 1} frames counted"}
 
 
+def bench_stereo_stream(args, ctx, capi, synth, torch, dev, rank):
+    """BASELINE configs[4]: a 752x480 stereo stream.  Per stereo frame, all on the device: both views through
+    SuperPoint in one batch of 2 (src/Frame.cc:142-147), Frame::ComputeStereoMatches (src/Frame.cc:1159-1446) and one
+    LightGlue match of the left view against the previous left view (SPmatcher.cc:1050-1080).  Only the two keypoint
+    counts cross PCIe (the caller needs them to size its vectors).  Latency figure, not the metric's workload."""
+    Hs, Ws, K = 480, 752, args.kmax
+    T = 8                                                     # distinct stereo frames, cycled
+    rng = np.random.default_rng(5)
+    scene = synth.make_scene(rng, Hs, Ws + 64 + 8 * T, margin=0)
+    lefts, rights = [], []
+    for t in range(T):
+        disp = 24
+        x0 = 8 * t
+        lefts.append(np.clip(scene[:, x0:x0 + Ws] + rng.integers(0, 8, (Hs, Ws)), 0, 255).astype(np.uint8))
+        rights.append(np.clip(scene[:, x0 + disp:x0 + disp + Ws] + rng.integers(0, 8, (Hs, Ws)), 0, 255).astype(np.uint8))
+    imgs = torch.from_numpy(np.stack([np.stack([l, r]) for l, r in zip(lefts, rights)])).to(dev)      # [T,2,H,W]
+    n = torch.zeros(2, dtype=torch.int32, device=dev)
+    kxy = torch.zeros(2, K, 2, dtype=torch.int32, device=dev)
+    score = torch.zeros(2, K, dtype=torch.float32, device=dev)
+    desc = torch.zeros(2, K, 256, dtype=torch.float32, device=dev)
+    prev_kn = torch.zeros(K, 2, dtype=torch.float32, device=dev)
+    prev_desc = torch.zeros(K, 256, dtype=torch.float32, device=dev)
+    prev_n = torch.zeros(1, dtype=torch.int32, device=dev)
+    S = torch.zeros(1, dtype=torch.int32, device=dev)
+    pairs = torch.zeros(K, 2, dtype=torch.int32, device=dev)
+    ms = torch.zeros(K, dtype=torch.float32, device=dev)
+    u_right = torch.zeros(K, dtype=torch.float32, device=dev)
+    depth = torch.zeros(K, dtype=torch.float32, device=dev)
+    centre = torch.tensor([Ws / 2.0, Hs / 2.0], dtype=torch.float32, device=dev)
+    mb, mbf = 0.11, 0.11 * 435.0
+    stats = {"stereo": 0, "matches": 0, "kp": 0}
+
+    def step(t):
+        im = imgs[t % T]
+        ctx._chk(capi.lib.rfe_extract_u8_dev(ctx.h, im.data_ptr(), Hs, Ws, Ws, 2, K, 0.0005, n.data_ptr(), kxy.data_ptr(),
+                                             score.data_ptr(), desc.data_ptr()))
+        nl, nr = n.tolist()                                   # the only D2H on the path (8 bytes)
+        kf = kxy.to(torch.float32)
+        ctx._chk(capi.lib.rfe_stereo_match_dev(ctx.h, im[0].data_ptr(), im[1].data_ptr(), Hs, Ws, Ws, kf[0].data_ptr(), nl,
+                                               kf[1].data_ptr(), nr, desc[0].data_ptr(), desc[1].data_ptr(), mb, mbf,
+                                               u_right.data_ptr(), depth.data_ptr()))
+        kn = ((kf[0] - centre) / (max(Ws, Hs) / 2.0)).contiguous()       # NormalizeKeypoints, transform.cpp:19-32
+        if t > 0:
+            ctx._chk(capi.lib.rfe_match_dev(ctx.h, prev_kn.data_ptr(), kn.data_ptr(), prev_desc.data_ptr(), desc[0].data_ptr(),
+                                            prev_n.data_ptr(), n.data_ptr(), 1, K, K, 0.1, S.data_ptr(), pairs.data_ptr(),
+                                            ms.data_ptr()))
+        prev_kn.copy_(kn); prev_desc.copy_(desc[0]); prev_n.copy_(n[:1])
+        stats["kp"] = nl
+
+    for t in range(args.warmup + 1):
+        step(t)
+    torch.cuda.synchronize(dev)
+    ctx.profile(True); ctx.profile_reset()
+    t0 = time.perf_counter()
+    for t in range(args.steps):
+        step(args.warmup + 1 + t)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_read(); ctx.profile(False)
+    if rank == 0:
+        print(json.dumps({"metric": "BASELINE configs[4] stereo 752x480 stream, latency run", "value": round(args.steps / dt, 2),
+                          "unit": "stereo frames/s", "ms_per_step": round(dt / args.steps * 1e3, 4), "n_gpus": 1,
+                          "steps": args.steps, "warmup": args.warmup, "kmax": K, "left_keypoints": stats["kp"],
+                          "stereo_matches": int((u_right[:stats["kp"]] >= 0).sum().item()), "temporal_matches": int(S.item()),
+                          "stages_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}))
+
+
 def main():
     global KMAX, FRAMES_PER_GPU
     ap = argparse.ArgumentParser()
@@ -118,9 +185,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the short PCIe-inclusive measurement (N=1)")
     ap.add_argument("--gather-desc", action="store_true", help="also gather the 256-d descriptors to rank 0")
-    ap.add_argument("--workload", default="c4", choices=["c2", "c3", "c4"],
+    ap.add_argument("--workload", default="c4", choices=["c2", "c3", "c4", "c5"],
                     help="BASELINE.json configs: c4 (default, the metric's workload) = 33 frames + 32 pairs per GPU; "
-                         "c2 = SuperPoint only, batch 1 (latency); c3 = one 640x480 pair, SuperPoint x2 + LightGlue (latency)")
+                         "c2 = SuperPoint only, batch 1 (latency); c3 = one 640x480 pair, SuperPoint x2 + LightGlue (latency); "
+                         "c5 = stereo 752x480 stream: per stereo frame 2 extractions + sparse stereo match + 1 LightGlue match "
+                         "of the left image against the previous left image (latency)")
     ap.add_argument("--kmax", type=int, default=KMAX, help="keypoint capacity per frame (default 1024)")
     args = ap.parse_args()
 
@@ -152,6 +221,10 @@ def main():
     ctx.set_stream(stream.cuda_stream)
 
     KMAX = args.kmax
+    if args.workload == "c5":
+        bench_stereo_stream(args, ctx, capi, synth, torch, dev, rank)
+        ctx.close()
+        return
     if args.workload != "c4":
         FRAMES_PER_GPU = 1                      # latency configurations: batch 1
     shard = sharding.shard_frames(FRAMES_PER_GPU, world, rank)
@@ -248,7 +321,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[3] per GPU: 33 synthetic 640x480 u8 frames resident in HBM, SuperPoint extract "
-                                   "(Kmax=1024, thr=0.0005) + LightGlue match of 32 consecutive pairs (9 layers, filter 0.1); "
+                                   f"(Kmax={KMAX}, thr=0.0005) + LightGlue match of 32 consecutive pairs (9 layers, filter 0.1); "
                                    "32 frames counted per GPU per step; seeded synthetic weights",
                        "frames_per_gpu": FRAMES_PER_GPU, "kmax": KMAX, "mean_keypoints": float(lens.mean()),
                        "sharding": f"frames sharded over {world} GPU(s), 1 overlap frame per rank"

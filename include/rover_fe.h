@@ -143,6 +143,21 @@ int rfe_stereo_match_dev(rfe_ctx* ctx, const uint8_t* imgL, const uint8_t* imgR,
 int rfe_l2_distance_matrix(rfe_ctx* ctx, const float* a, int M, const float* b, int N, float* out);
 int rfe_binarize_descriptors(rfe_ctx* ctx, const float* desc, int rows, uint8_t* out);
 
+/* rfe_search_candidates: the best / second-best descriptor scan of SPmatcher::SearchByProjection1
+ *   (src/Matchers/SPmatcher.cc:1218-1248; the same loop in SearchByProjection :755-800 and Fuse :150-200) for Nq
+ *   map-point descriptors q [Nq,256] against the frame descriptors f [Nf,256].  Candidate lists are the caller's
+ *   (Frame::GetFeaturesInArea) in CSR form: cand[offsets[i] .. offsets[i+1]) are the frame features near map point i,
+ *   scanned in that order.  skip [Nf] (may be NULL): non-zero = feature already owns a MapPoint with observations
+ *   (:1226-1228).  Per map point: best_idx (-1 = none), best_dist and second_dist (both start at 256, strict '<').
+ *   The TH_HIGH cut and the greedy assignment (:1253-1262) stay with the caller.
+ * rfe_distinctive_descriptors: MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:438-530) for Np map points at
+ *   once: desc holds the observed descriptors of all points back to back, offsets [Np+1] delimits them (<= 8192 per
+ *   point).  best[p] = index within the point's own list of the descriptor with the least median distance to the
+ *   others (first strict minimum, -1 for an empty point), median[p] = that median. */
+int rfe_search_candidates(rfe_ctx* ctx, const float* q, int Nq, const float* f, int Nf, const int32_t* offsets,
+                          const int32_t* cand, const uint8_t* skip, int32_t* best_idx, float* best_dist, float* second_dist);
+int rfe_distinctive_descriptors(rfe_ctx* ctx, const float* desc, const int32_t* offsets, int Np, int32_t* best, float* median);
+
 /* ---- per-stage timing (hipEvent on the ctx stream), for bench.py's roofline object ----
  * Enable, run, then read back: names is a ';'-separated list of stage names, ms / calls the
  * accumulated time and launch count per stage since the last reset. */

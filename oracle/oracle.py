@@ -51,6 +51,8 @@ def lib():
         L.rfo_postprocess_fused.restype = C.c_int
         L.rfo_postprocess_fused.argtypes = [ip, fp, C.c_int, C.c_float, ip, C.c_int]
         L.rfo_stereo_match.argtypes = [u8p, u8p, C.c_int, C.c_int, fp, C.c_int, fp, C.c_int, fp, fp, C.c_float, C.c_float, fp, fp]
+        L.rfo_search_candidates.argtypes = [fp, C.c_int, fp, ip, ip, u8p, ip, fp, fp]
+        L.rfo_distinctive_descriptors.argtypes = [fp, ip, C.c_int, ip, fp]
         _lib = L
     return _lib
 
@@ -207,3 +209,28 @@ def stereo_match(img_l, img_r, k_l, k_r, d_l, d_r, mb, mbf):
     lib().rfo_stereo_match(il.ctypes.data_as(C.POINTER(C.c_uint8)), ir.ctypes.data_as(C.POINTER(C.c_uint8)), H, W,
                            klp, N, krp, Nr, dlp, drp, mb, mbf, _opt(u), _opt(d))
     return u[:N], d[:N]
+
+
+def search_candidates(q, f, offsets, cand, skip=None):
+    """Best / second-best candidate scan (SPmatcher.cc:1218-1248).  Returns (best_idx, best_dist, second_dist)."""
+    qa, qp = _f(q); fa, fpp = _f(f)
+    off = np.ascontiguousarray(offsets, np.int32); cd = np.ascontiguousarray(cand, np.int32)
+    Nq = qa.shape[0]
+    sk = None if skip is None else np.ascontiguousarray(skip, np.uint8)
+    bi = np.empty((max(Nq, 1),), np.int32); bd = np.empty((max(Nq, 1),), np.float32); sd = np.empty((max(Nq, 1),), np.float32)
+    ip = C.POINTER(C.c_int32)
+    lib().rfo_search_candidates(qp, Nq, fpp, off.ctypes.data_as(ip), cd.ctypes.data_as(ip),
+                                None if sk is None else sk.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                bi.ctypes.data_as(ip), _opt(bd), _opt(sd))
+    return bi[:Nq], bd[:Nq], sd[:Nq]
+
+
+def distinctive_descriptors(desc, offsets):
+    """MapPoint::ComputeDistinctiveDescriptors batched (MapPoint.cc:438-530).  Returns (best[Np], median[Np])."""
+    da, dp = _f(desc)
+    off = np.ascontiguousarray(offsets, np.int32)
+    Np = off.shape[0] - 1
+    b = np.empty((max(Np, 1),), np.int32); m = np.empty((max(Np, 1),), np.float32)
+    ip = C.POINTER(C.c_int32)
+    lib().rfo_distinctive_descriptors(dp, off.ctypes.data_as(ip), Np, b.ctypes.data_as(ip), _opt(m))
+    return b[:Np], m[:Np]

@@ -690,3 +690,59 @@ void rfo_stereo_match(const uint8_t* imgL, const uint8_t* imgR, int H, int W, co
     }
     free(v);
 }
+
+/* ================================================================== */
+/* the descriptor arithmetic of the classic searches.  */
+/* ================================================================== */
+/* Best / second-best scan of SearchByProjection1 (src/Matchers/SPmatcher.cc:1218-1248; the same loop  */
+/* appears in SearchByProjection :755-800 and Fuse :150-200) for Nq query descriptors against the      */
+/* frame's descriptors; candidate lists (CSR: offsets[Nq+1], cand[nnz]) come from the caller's grid    */
+/* (Frame::GetFeaturesInArea). skip[f] != 0 stands for "F.mvpMapPoints[f] already has observations".   */
+/* nLevels == 1 so every octave is 0. bestDist / bestDist2 start at 256 with strict '<' as there.      */
+void rfo_search_candidates(const float* q, int Nq, const float* f, const int32_t* offsets, const int32_t* cand,
+                           const uint8_t* skip, int32_t* best_idx, float* best_dist, float* second_dist) {
+    for (int i = 0; i < Nq; ++i) {
+        float bestDist = 256.f, bestDist2 = 256.f; int bestIdx = -1;
+        for (int c = offsets[i]; c < offsets[i + 1]; ++c) {
+            const int idx = cand[c];
+            if (skip && skip[idx]) continue;
+            const float dist = rfo_desc_dist(q + (size_t)i * 256, f + (size_t)idx * 256);
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx = idx; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        best_idx[i] = bestIdx; best_dist[i] = bestDist; second_dist[i] = bestDist2;
+    }
+}
+
+static int float_cmp(const void* a, const void* b) {
+    const float x = *(const float*)a, y = *(const float*)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:438-530) over Np map points: desc holds the */
+/* observed descriptors of all points back to back, offsets[Np+1] delimits them. Per point: all-pairs   */
+/* distances (symmetric, 0 on the diagonal), per row the median sorted[(int)(0.5*(n-1))], first row     */
+/* with the strictly smallest median wins. Empty points give best = -1.                                 */
+void rfo_distinctive_descriptors(const float* desc, const int32_t* offsets, int Np, int32_t* best, float* median) {
+    for (int p = 0; p < Np; ++p) {
+        const int o = offsets[p], n = offsets[p + 1] - o;
+        if (n <= 0) { best[p] = -1; median[p] = 0.f; continue; }
+        float* D = (float*)malloc((size_t)n * n * sizeof(float));
+        float* row = (float*)malloc((size_t)n * sizeof(float));
+        for (int i = 0; i < n; ++i) {
+            D[(size_t)i * n + i] = 0.f;
+            for (int j = i + 1; j < n; ++j) {
+                const float d = rfo_desc_dist(desc + (size_t)(o + i) * 256, desc + (size_t)(o + j) * 256);
+                D[(size_t)i * n + j] = d; D[(size_t)j * n + i] = d;
+            }
+        }
+        float bestMedian = 2147483647.0f; int bestIdx = 0;
+        for (int i = 0; i < n; ++i) {
+            memcpy(row, D + (size_t)i * n, (size_t)n * sizeof(float));
+            qsort(row, n, sizeof(float), float_cmp);
+            const float med = row[(int)(0.5 * (n - 1))];
+            if (med < bestMedian) { bestMedian = med; bestIdx = i; }
+        }
+        best[p] = bestIdx; median[p] = bestMedian;
+        free(D); free(row);
+    }
+}

@@ -76,6 +76,11 @@ void rfo_stereo_match(const uint8_t* imgL, const uint8_t* imgR, int H, int W, co
                       const float* kR, int Nr, const float* dL, const float* dR, float mb, float mbf,
                       float* uRight, float* depth);
 
+/* classic-search descriptor arithmetic: SPmatcher.cc:1218-1248, MapPoint.cc:438-530 */
+void rfo_search_candidates(const float* q, int Nq, const float* f, const int32_t* offsets, const int32_t* cand,
+                           const uint8_t* skip, int32_t* best_idx, float* best_dist, float* second_dist);
+void rfo_distinctive_descriptors(const float* desc, const int32_t* offsets, int Np, int32_t* best, float* median);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,7 @@ EXPORTS = [
     "rfe_weight_count", "rfe_set_stream", "rfe_synchronize", "rfe_malloc", "rfe_free", "rfe_memcpy_h2d",
     "rfe_memcpy_d2h", "rfe_extract_u8", "rfe_extract_u8_dev", "rfe_match", "rfe_match_dev", "rfe_match_fused",
     "rfe_extract_match_stream_dev", "rfe_stereo_match", "rfe_stereo_match_dev", "rfe_l2_distance_matrix", "rfe_binarize_descriptors",
+    "rfe_search_candidates", "rfe_distinctive_descriptors",
     "rfe_profile_enable", "rfe_profile_reset", "rfe_profile_read",
     "rfe_k_conv3x3", "rfe_k_linear", "rfe_k_scoremap", "rfe_k_lightglue_taps",
 ]
@@ -58,6 +59,8 @@ lib.rfe_stereo_match.argtypes = _st
 lib.rfe_stereo_match_dev.argtypes = _st
 lib.rfe_l2_distance_matrix.argtypes = [C.c_void_p, _fp, C.c_int, _fp, C.c_int, _fp]
 lib.rfe_binarize_descriptors.argtypes = [C.c_void_p, _fp, C.c_int, _u8p]
+lib.rfe_search_candidates.argtypes = [C.c_void_p, _fp, C.c_int, _fp, C.c_int, _ip, _ip, _u8p, _ip, _fp, _fp]
+lib.rfe_distinctive_descriptors.argtypes = [C.c_void_p, _fp, _ip, C.c_int, _ip, _fp]
 lib.rfe_profile_enable.argtypes = [C.c_void_p, C.c_int]
 lib.rfe_profile_reset.argtypes = [C.c_void_p]
 lib.rfe_profile_read.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
@@ -206,6 +209,27 @@ class Context:
         self._chk(lib.rfe_stereo_match(self.h, il.ctypes.data, ir.ctypes.data, H, W, W, kl.ctypes.data, N, kr.ctypes.data, Nr,
                                        dl.ctypes.data, dr.ctypes.data, mb, mbf, u.ctypes.data, z.ctypes.data))
         return u[:N], z[:N]
+
+    def search_candidates(self, q, f, offsets, cand, skip=None):
+        """Best / second-best scan of SearchByProjection1 (SPmatcher.cc:1218-1248) over CSR candidate lists."""
+        qa = np.ascontiguousarray(q, np.float32).reshape(-1, 256); fa = np.ascontiguousarray(f, np.float32).reshape(-1, 256)
+        off = np.ascontiguousarray(offsets, np.int32); cd = np.ascontiguousarray(cand, np.int32)
+        sk = None if skip is None else np.ascontiguousarray(skip, np.uint8)
+        Nq = qa.shape[0]
+        bi = np.empty((max(Nq, 1),), np.int32); bd = np.empty((max(Nq, 1),), np.float32); sd = np.empty((max(Nq, 1),), np.float32)
+        self._chk(lib.rfe_search_candidates(self.h, qa.ctypes.data, Nq, fa.ctypes.data, fa.shape[0], off.ctypes.data,
+                                            cd.ctypes.data, None if sk is None else sk.ctypes.data, bi.ctypes.data,
+                                            bd.ctypes.data, sd.ctypes.data))
+        return bi[:Nq], bd[:Nq], sd[:Nq]
+
+    def distinctive_descriptors(self, desc, offsets):
+        """MapPoint::ComputeDistinctiveDescriptors for many map points (MapPoint.cc:438-530)."""
+        da = np.ascontiguousarray(desc, np.float32).reshape(-1, 256)
+        off = np.ascontiguousarray(offsets, np.int32)
+        Np = off.shape[0] - 1
+        b = np.empty((max(Np, 1),), np.int32); m = np.empty((max(Np, 1),), np.float32)
+        self._chk(lib.rfe_distinctive_descriptors(self.h, da.ctypes.data, off.ctypes.data, Np, b.ctypes.data, m.ctypes.data))
+        return b[:Np], m[:Np]
 
     # ---- profiling
     def profile(self, on=True):

@@ -790,6 +790,94 @@ extern "C" int rfe_binarize_descriptors(rfe_ctx* c, const float* desc, int rows,
     return RFE_OK;
 }
 
+// Classic-search descriptor arithmetic, host pointers.
+extern "C" int rfe_search_candidates(rfe_ctx* c, const float* q, int Nq, const float* f, int Nf, const int32_t* offsets,
+                                     const int32_t* cand, const uint8_t* skip, int32_t* best_idx, float* best_dist,
+                                     float* second_dist) {
+    if (!c) return RFE_ERR_INVALID;
+    if (Nq < 0 || Nf < 0) return fail(c, RFE_ERR_INVALID, "search_candidates: negative count");
+    if (Nq == 0) return RFE_OK;
+    if (!q || !offsets || !best_idx || !best_dist || !second_dist) return fail(c, RFE_ERR_INVALID, "search_candidates: null pointer");
+    if (offsets[0] != 0) return fail(c, RFE_ERR_INVALID, "search_candidates: offsets[0] must be 0");
+    for (int i = 0; i < Nq; ++i)
+        if (offsets[i + 1] < offsets[i]) return fail(c, RFE_ERR_INVALID, "search_candidates: offsets must be non-decreasing");
+    const int nnz = offsets[Nq];
+    if (nnz > 0 && (!cand || !f)) return fail(c, RFE_ERR_INVALID, "search_candidates: null candidate list");
+    for (int k = 0; k < nnz; ++k)
+        if (cand[k] < 0 || cand[k] >= Nf) return fail(c, RFE_ERR_INVALID, "search_candidates: candidate index out of range");
+    RFE_HIP(c, hipSetDevice(c->device));
+    const size_t bq = al((size_t)Nq * 1024), bf = al((size_t)std::max(Nf, 1) * 1024), bo = al((size_t)(Nq + 1) * 4),
+                 bc = al((size_t)std::max(nnz, 1) * 4), bs = al((size_t)std::max(Nf, 1)), br = al((size_t)Nq * 4);
+    int rc = ensure_ws(c, &c->ws_io, &c->ws_io_bytes, bq + bf + bo + bc + bs + 3 * br);
+    if (rc) return rc;
+    char* p = (char*)c->ws_io;
+    float* dq = (float*)p; p += bq; float* df = (float*)p; p += bf; int32_t* doff = (int32_t*)p; p += bo;
+    int32_t* dc = (int32_t*)p; p += bc; uint8_t* dsk = (uint8_t*)p; p += bs;
+    int32_t* dbi = (int32_t*)p; p += br; float* dbd = (float*)p; p += br; float* dsd = (float*)p;
+    hipStream_t s = c->stream;
+    RFE_HIP(c, hipMemcpyAsync(dq, q, (size_t)Nq * 1024, hipMemcpyHostToDevice, s));
+    if (Nf > 0 && f) RFE_HIP(c, hipMemcpyAsync(df, f, (size_t)Nf * 1024, hipMemcpyHostToDevice, s));
+    RFE_HIP(c, hipMemcpyAsync(doff, offsets, (size_t)(Nq + 1) * 4, hipMemcpyHostToDevice, s));
+    if (nnz > 0) RFE_HIP(c, hipMemcpyAsync(dc, cand, (size_t)nnz * 4, hipMemcpyHostToDevice, s));
+    if (skip && Nf > 0) RFE_HIP(c, hipMemcpyAsync(dsk, skip, (size_t)Nf, hipMemcpyHostToDevice, s));
+    {
+        ProfScope ps(c, "search_candidates");
+        launch_search_candidates(s, dq, Nq, df, doff, dc, skip ? dsk : nullptr, dbi, dbd, dsd);
+    }
+    RFE_HIP(c, hipGetLastError());
+    RFE_HIP(c, hipMemcpyAsync(best_idx, dbi, (size_t)Nq * 4, hipMemcpyDeviceToHost, s));
+    RFE_HIP(c, hipMemcpyAsync(best_dist, dbd, (size_t)Nq * 4, hipMemcpyDeviceToHost, s));
+    RFE_HIP(c, hipMemcpyAsync(second_dist, dsd, (size_t)Nq * 4, hipMemcpyDeviceToHost, s));
+    RFE_HIP(c, hipStreamSynchronize(s));
+    prof_collect(c);
+    return RFE_OK;
+}
+
+extern "C" int rfe_distinctive_descriptors(rfe_ctx* c, const float* desc, const int32_t* offsets, int Np, int32_t* best,
+                                           float* median) {
+    if (!c) return RFE_ERR_INVALID;
+    if (Np < 0) return fail(c, RFE_ERR_INVALID, "distinctive_descriptors: negative count");
+    if (Np == 0) return RFE_OK;
+    if (!offsets || !best || !median) return fail(c, RFE_ERR_INVALID, "distinctive_descriptors: null pointer");
+    if (offsets[0] != 0) return fail(c, RFE_ERR_INVALID, "distinctive_descriptors: offsets[0] must be 0");
+    int maxn = 0;
+    for (int p = 0; p < Np; ++p) {
+        const int n = offsets[p + 1] - offsets[p];
+        if (n < 0) return fail(c, RFE_ERR_INVALID, "distinctive_descriptors: offsets must be non-decreasing");
+        maxn = std::max(maxn, n);
+    }
+    if (maxn > 8192) return fail(c, RFE_ERR_INVALID, "distinctive_descriptors: more than 8192 observations of one map point");
+    const int total = offsets[Np];
+    if (total > 0 && !desc) return fail(c, RFE_ERR_INVALID, "distinctive_descriptors: null descriptors");
+    RFE_HIP(c, hipSetDevice(c->device));
+    std::vector<int32_t> point((size_t)std::max(total, 1));
+    for (int p = 0; p < Np; ++p)
+        for (int g = offsets[p]; g < offsets[p + 1]; ++g) point[g] = p;
+    const size_t bd = al((size_t)std::max(total, 1) * 1024), bo = al((size_t)(Np + 1) * 4), bp = al((size_t)std::max(total, 1) * 4),
+                 br = al((size_t)Np * 4);
+    int rc = ensure_ws(c, &c->ws_io, &c->ws_io_bytes, bd + bo + 2 * bp + 2 * br);
+    if (rc) return rc;
+    char* w = (char*)c->ws_io;
+    float* dd = (float*)w; w += bd; int32_t* doff = (int32_t*)w; w += bo; int32_t* dpt = (int32_t*)w; w += bp;
+    float* dmed = (float*)w; w += bp; int32_t* dbest = (int32_t*)w; w += br; float* dmedian = (float*)w;
+    hipStream_t s = c->stream;
+    if (total > 0) {
+        RFE_HIP(c, hipMemcpyAsync(dd, desc, (size_t)total * 1024, hipMemcpyHostToDevice, s));
+        RFE_HIP(c, hipMemcpyAsync(dpt, point.data(), (size_t)total * 4, hipMemcpyHostToDevice, s));
+    }
+    RFE_HIP(c, hipMemcpyAsync(doff, offsets, (size_t)(Np + 1) * 4, hipMemcpyHostToDevice, s));
+    {
+        ProfScope ps(c, "distinctive");
+        launch_distinctive(s, dd, doff, dpt, total, Np, maxn, dmed, dbest, dmedian);
+    }
+    RFE_HIP(c, hipGetLastError());
+    RFE_HIP(c, hipMemcpyAsync(best, dbest, (size_t)Np * 4, hipMemcpyDeviceToHost, s));
+    RFE_HIP(c, hipMemcpyAsync(median, dmedian, (size_t)Np * 4, hipMemcpyDeviceToHost, s));
+    RFE_HIP(c, hipStreamSynchronize(s));   // also keeps `point` alive until its copy is done
+    prof_collect(c);
+    return RFE_OK;
+}
+
 // =====================================================================================
 // profiling
 // =====================================================================================

@@ -83,3 +83,86 @@ def test_distance_matrix_and_binarize():
     ctx._chk(capi.lib.rfe_binarize_descriptors(ctx.h, a.ctypes.data, 37, bits.ctypes.data))
     assert np.array_equal(bits, (a > 0).astype(np.uint8))
     ctx.close()
+
+
+def _search_case(seed, Nq=300, Nf=700, zero_lists=True):
+    rng = np.random.default_rng(seed)
+    f = rng.standard_normal((Nf, 256)).astype(np.float32); f /= np.linalg.norm(f, axis=1, keepdims=True)
+    src = rng.integers(0, Nf, Nq)
+    q = f[src] + 0.05 * rng.standard_normal((Nq, 256)).astype(np.float32)
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    lens = rng.integers(0 if zero_lists else 1, 40, Nq)
+    off = np.zeros(Nq + 1, np.int32); off[1:] = np.cumsum(lens)
+    cand = rng.integers(0, Nf, off[-1]).astype(np.int32)
+    for i in range(Nq):                                   # the true source is usually among the candidates
+        if lens[i] and i % 3: cand[off[i] + rng.integers(0, lens[i])] = src[i]
+    if Nq > 5 and lens[5] >= 2: cand[off[5] + 1] = cand[off[5]]          # duplicate candidate -> exact tie
+    skip = (rng.random(Nf) < 0.2).astype(np.uint8)
+    return q, f, off, cand, skip
+
+
+def test_oracle_search_and_distinctive_against_numpy(oracle):
+    """N3 oracle functions against an independent float64 numpy statement of the same loops."""
+    q, f, off, cand, skip = _search_case(11, Nq=60, Nf=90)
+    bi, bd, sd = oracle.search_candidates(q, f, off, cand, skip)
+    for i in range(60):
+        ids = [c for c in cand[off[i]:off[i + 1]] if not skip[c]]
+        d = [float(np.linalg.norm(q[i].astype(np.float64) - f[c].astype(np.float64))) for c in ids]
+        if not ids:
+            assert bi[i] == -1 and bd[i] == 256 and sd[i] == 256
+            continue
+        k = int(np.argmin(d))
+        assert abs(bd[i] - d[k]) < 1e-6 and abs(np.linalg.norm(q[i] - f[bi[i]]) - d[k]) < 1e-6
+        rest = sorted(d)[1] if len(d) > 1 else 256.0
+        assert abs(sd[i] - rest) < 1e-6
+    rng = np.random.default_rng(2)
+    lens = np.array([1, 2, 3, 0, 7, 20, 33], np.int32)
+    off2 = np.zeros(len(lens) + 1, np.int32); off2[1:] = np.cumsum(lens)
+    desc = rng.standard_normal((off2[-1], 256)).astype(np.float32)
+    best, med = oracle.distinctive_descriptors(desc, off2)
+    for p, n in enumerate(lens):
+        if n == 0:
+            assert best[p] == -1
+            continue
+        d = desc[off2[p]:off2[p + 1]].astype(np.float64)
+        D = np.linalg.norm(d[:, None] - d[None], axis=2)
+        meds = np.sort(D, axis=1)[:, int(0.5 * (n - 1))]
+        assert abs(meds[best[p]] - meds.min()) < 1e-5 and abs(med[p] - meds.min()) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1])
+def test_search_candidates_matches_oracle(oracle, seed):
+    """rfe_search_candidates == the SearchByProjection1 scan restated in the oracle, bit for bit."""
+    from rover_slam_amd import capi
+    ctx = capi.Context(0)
+    q, f, off, cand, skip = _search_case(seed)
+    for sk in (skip, None):
+        bi, bd, sd = ctx.search_candidates(q, f, off, cand, sk)
+        rbi, rbd, rsd = oracle.search_candidates(q, f, off, cand, sk)
+        assert np.array_equal(bi, rbi) and np.array_equal(bd, rbd) and np.array_equal(sd, rsd)
+    assert (bd < 1.4).sum() > 50                                            # not vacuous: many under TH_HIGH
+    # all lists empty, and an out-of-range candidate is refused
+    bi, bd, sd = ctx.search_candidates(q[:4], f, np.zeros(5, np.int32), np.zeros(0, np.int32))
+    assert (bi == -1).all() and (bd == 256).all() and (sd == 256).all()
+    with pytest.raises(Exception):
+        ctx.search_candidates(q[:1], f, np.array([0, 1], np.int32), np.array([f.shape[0]], np.int32))
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_distinctive_descriptors_matches_oracle(oracle):
+    """rfe_distinctive_descriptors == MapPoint::ComputeDistinctiveDescriptors restated in the oracle."""
+    from rover_slam_amd import capi
+    ctx = capi.Context(0)
+    rng = np.random.default_rng(9)
+    lens = np.concatenate([[1, 2, 0, 3, 64, 65, 130], rng.integers(1, 40, 200)]).astype(np.int32)
+    off = np.zeros(len(lens) + 1, np.int32); off[1:] = np.cumsum(lens)
+    centers = rng.standard_normal((len(lens), 256)).astype(np.float32)
+    desc = np.repeat(centers, lens, axis=0) + 0.3 * rng.standard_normal((off[-1], 256)).astype(np.float32)
+    desc = (desc / np.linalg.norm(desc, axis=1, keepdims=True)).astype(np.float32)
+    desc[off[4] + 3] = desc[off[4] + 9]                                     # duplicated observation -> tied rows
+    best, med = ctx.distinctive_descriptors(desc, off)
+    rbest, rmed = oracle.distinctive_descriptors(desc, off)
+    assert np.array_equal(best, rbest) and np.array_equal(med, rmed)
+    ctx.close()
