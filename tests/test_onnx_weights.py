@@ -114,3 +114,15 @@ def test_lightglue_incomplete_file_is_reported(tmp_path):
     p.write_bytes(_model([("posenc.Wr.weight", np.zeros((32, 2), np.float32))], []))
     with pytest.raises(ValueError, match="cannot place LightGlue tensors"):
         OW.convert_lightglue(str(p))
+
+
+def test_ort_parity_tool_reports_missing_prerequisites():
+    """tools/ort_parity.py is a guarded harness: without onnxruntime + the blobs it says so (rc 2)."""
+    import importlib.util, os, subprocess, sys
+    if importlib.util.find_spec("onnxruntime") is not None:
+        import pytest
+        pytest.skip("onnxruntime present: the tool would run for real")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ort_parity.py"), "--superpoint", "missing.onnx"],
+                       capture_output=True, text=True)
+    assert r.returncode == 2 and "unpinned" in r.stderr
