@@ -23,7 +23,8 @@ constexpr int BK = 32, LDT = BK + 1;
 // (tools/kbench/gemm_variants.hip: 119-132 TFLOP/s vs 110-125 for 128x128 double-buffered).
 // MB = 32-row MFMA blocks per wave (2 for throughput; 1 gives 64-row tiles for small, latency-bound problems:
 // a single 1024-keypoint pair has only M = 2048 rows, 16 tiles of 128 x 256 would use 16 of the 256 CUs).
-// TEPI: LDS-transposed whole-row epilogue (needed for the residual / rotary variants); false = per-lane 4-byte stores
+// TEPI: LDS-transposed whole-row epilogue (rotary variant); false = per-lane 4-byte stores.  The residual variant reads
+// R in the D layout (four rows of 128-B segments in flight per step) and adds it after bias / alpha like the oracle.
 template <int MB, int NB, bool TEPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     constexpr int BM = MB * 64, BN = NB * 64;
@@ -120,20 +121,40 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
         }
     }
 
-    if (!TEPI) {   // plain bias (+alpha, +ReLU) epilogue: 128-B coalesced stores straight from the D layout
+    if (!TEPI || (g.rend && g.R && !g.rope_cs)) {   // plain bias (+alpha, +ReLU, +residual) epilogue: 128-B coalesced accesses straight from the D layout
+        const float* Rz = (TEPI && g.R) ? g.R + (size_t)z * g.sR : nullptr;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m >= M) continue;
+            for (int rq = 0; rq < 4; ++rq) {
+                float rv[4][NB];
+                if (Rz) {
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const int n = n0 + (wn * NB + nb) * 32 + i;
-                    if (n >= g.N) continue;
-                    float v = acc[mb][nb][r] * g.alpha;
-                    if (g.relu) v = fmaxf(v, 0.f);
-                    C[(size_t)m * g.ldc + n] = v;
+                    for (int rr = 0; rr < 4; ++rr) {
+                        int m = m0 + (wm * MB + mb) * 32 + rr + 8 * rq + 4 * h;
+                        m = m < M ? m : M - 1;
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            int n = n0 + (wn * NB + nb) * 32 + i;
+                            n = n < g.N ? n : g.N - 1;
+                            rv[rr][nb] = Rz[(size_t)m * g.ldr + n];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int r = rq * 4 + rr;
+                    const int m = m0 + (wm * MB + mb) * 32 + rr + 8 * rq + 4 * h;
+                    if (m >= M) continue;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const int n = n0 + (wn * NB + nb) * 32 + i;
+                        if (n >= g.N) continue;
+                        float v = acc[mb][nb][r] * g.alpha;
+                        if (g.relu) v = fmaxf(v, 0.f);
+                        if (Rz) v = rv[rr][nb] + v;
+                        C[(size_t)m * g.ldc + n] = v;
+                    }
                 }
             }
         return;
@@ -202,7 +223,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     }
 }
 
-void launch_gemm_nt(hipStream_t s, const GemmArgs& g) {
+void launch_gemm_nt(hipStream_t s, const GemmArgs& g_in) {
+    static const int rend_on = getenv("RFE_GEMM_REND") ? atoi(getenv("RFE_GEMM_REND")) : 1;   // A/B switch, see profiles/r01_pmc.md
+    GemmArgs g = g_in;
+    g.rend = rend_on;
     const int batch = g.batch > 0 ? g.batch : 1;
     auto tiles = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * batch; };
     static const bool force_tepi = getenv("RFE_GEMM_TEPI") != nullptr;   // tuning switch

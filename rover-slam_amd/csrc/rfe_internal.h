@@ -68,6 +68,7 @@ struct GemmArgs {
     const float* rope_cs;             // optional fused rotary epilogue: cos/sin tables [M][32], applied to
     const float* rope_sn;             //   columns n < rope_ncols in adjacent pairs (2f, 2f+1), f = (n%64)/2
     int rope_ncols;
+    int rend;                         // residual added in the direct (D-layout) epilogue
 };
 
 }  // namespace rfe
