@@ -1,0 +1,105 @@
+"""CPU: known-answer and property tests of single oracle stages against independent numpy / scipy statements of
+the published algorithms (nms9 incl. ties, softmax65 + depth-to-space, conv / linear, match
+mutuality and uniqueness).  The end-to-end pins are in test_oracle_golden.py."""
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+from scipy.ndimage import maximum_filter
+
+from rover_slam_amd import weights as Wt
+
+
+def _maxpool9(x, r=4):
+    # torch max_pool2d(kernel 2r+1, stride 1, padding r): the padding never wins (-inf)
+    return maximum_filter(x, size=2 * r + 1, mode="constant", cval=-np.inf)
+
+
+def _simple_nms_numpy(s, r=4):
+    """The published simple_nms recurrence (SuperPoint / SuperGlue code), float32 throughout."""
+    zeros = np.zeros_like(s)
+    mask = s == _maxpool9(s, r)
+    for _ in range(2):
+        supp = _maxpool9(mask.astype(np.float32), r) > 0
+        ss = np.where(supp, zeros, s)
+        new = ss == _maxpool9(ss, r)
+        mask = mask | (new & ~supp)
+    return np.where(mask, s, zeros)
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(0, 2 ** 31 - 1), st.integers(9, 40), st.integers(9, 48), st.sampled_from([0, 2, 6]))
+def test_nms_equals_published_recurrence(oracle, seed, H, W, levels):
+    rng = np.random.default_rng(seed)
+    s = rng.random((H, W)).astype(np.float32)
+    if levels:                                     # quantised maps: many exact ties and plateaus
+        s = (np.floor(s * levels) / levels).astype(np.float32)
+    out = oracle.nms(s, 4)
+    assert np.array_equal(out, _simple_nms_numpy(s, 4))
+    ys, xs = np.nonzero(out)
+    for a in range(len(ys)):                       # survivors closer than r only on exact ties
+        near = (np.abs(ys - ys[a]) <= 4) & (np.abs(xs - xs[a]) <= 4)
+        assert (out[ys[near], xs[near]] == out[ys[a], xs[a]]).all()
+
+
+def test_nms_constant_map_keeps_everything(oracle):
+    s = np.full((20, 24), 0.25, np.float32)        # every pixel ties with its window maximum
+    assert np.array_equal(oracle.nms(s, 4), s)
+
+
+def test_softmax65_depth_to_space(oracle):
+    rng = np.random.default_rng(0)
+    Hc, Wc = 5, 7
+    logits = (4 * rng.standard_normal((Hc, Wc, 65))).astype(np.float32)
+    got = oracle.softmax65_d2s(logits, Hc, Wc)
+    e = np.exp(logits.astype(np.float64) - logits.max(axis=2, keepdims=True))
+    p = (e / e.sum(axis=2, keepdims=True))[:, :, :64]                    # dustbin channel dropped
+    ref = p.reshape(Hc, Wc, 8, 8).transpose(0, 2, 1, 3).reshape(Hc * 8, Wc * 8)
+    assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-6
+
+
+def test_conv_and_linear_against_float64(oracle):
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((10, 12, 5)).astype(np.float32)
+    w = (rng.standard_normal((7, 5, 3, 3)) / 6).astype(np.float32)
+    b = rng.standard_normal(7).astype(np.float32)
+    got = oracle.conv3x3(x, w, b, relu=True, pool=True)
+    xp = np.pad(x.astype(np.float64), ((1, 1), (1, 1), (0, 0)))
+    ref = np.zeros((10, 12, 7))
+    for ky in range(3):
+        for kx in range(3):
+            ref += xp[ky:ky + 10, kx:kx + 12, :] @ w[:, :, ky, kx].astype(np.float64).T
+    ref = np.maximum(ref + b, 0).reshape(5, 2, 6, 2, 7).max(axis=(1, 3))
+    assert np.abs(got - ref).max() < 1e-5
+    a = rng.standard_normal((9, 33)).astype(np.float32)
+    wl = rng.standard_normal((4, 33)).astype(np.float32)
+    assert np.abs(oracle.linear(a, wl, b[:4]) - (a.astype(np.float64) @ wl.T.astype(np.float64) + b[:4])).max() < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_matches_are_mutual_unique_and_thresholded(oracle, golden_dir, tag):
+    g = np.load(f"{golden_dir}/lg_{tag}.npz")
+    w = Wt.make_lightglue(seed=int(g["seed"]))
+    r = oracle.lightglue(w, g["k0n"], g["k1n"], g["d0"], g["d1"], debug=True)
+    pairs, ms, sc = r["pairs"], r["ms"], r["scores"]
+    assert len(pairs) > 0
+    assert len(set(pairs[:, 0])) == len(pairs) and len(set(pairs[:, 1])) == len(pairs)       # one-to-one
+    assert (np.diff(pairs[:, 0]) > 0).all()                                                  # ascending i
+    for (i, j), m in zip(pairs, ms):
+        assert sc[i].argmax() == j and sc[:, j].argmax() == i                                # mutual argmax
+        assert m > 0.1 and abs(m - np.exp(sc[i, j])) < 1e-6                                  # exp(max) above the filter
+    # and nothing that qualifies was dropped
+    rows = sc.argmax(1); cols = sc.argmax(0)
+    want = [(i, rows[i]) for i in range(sc.shape[0]) if cols[rows[i]] == i and np.exp(sc[i, rows[i]]) > 0.1]
+    assert [tuple(p) for p in pairs] == [(int(i), int(j)) for i, j in want]
+
+
+def test_descriptors_unit_norm_and_keypoints_inside_border(oracle):
+    from rover_slam_amd import synth
+    img = synth.make_frames(1, 120, 160, seed=3)[0][0]
+    r = oracle.superpoint(Wt.make_superpoint(seed=7), img, kmax=300)
+    n = r["n"]
+    assert n > 20
+    assert np.allclose(np.linalg.norm(r["desc"][:n], axis=1), 1.0, atol=1e-5)
+    k = r["kxy"][:n]
+    assert (k[:, 0] >= 4).all() and (k[:, 0] < 160 - 4).all() and (k[:, 1] >= 4).all() and (k[:, 1] < 120 - 4).all()
+    assert (r["score"][:n] > 0.0005).all()
