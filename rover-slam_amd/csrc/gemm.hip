@@ -85,8 +85,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     const float* const ap = As + (wm * MB * 32 + i) * LDT + h;
     const float* const bp = Bs + (wn * NB * 32 + i) * LDT + h;
 
-    for (int k0 = 0; k0 < g.K; k0 += BK) {
-        float4 ra[A_IT], rb[B_IT];
+    // Small (64-row) tiles serve latency-bound problems (one pair: M = 2048, one workgroup per CU), where every K step
+    // would otherwise expose a full global-memory round trip: there the next tile's loads are issued before the MFMA
+    // loop of the current one (16 VGPRs).  The throughput tiles rely on the other resident workgroups instead
+    // (register prefetch measured slower there).
+    constexpr bool PF = (MB == 1);
+    float4 ra[A_IT], rb[B_IT];
+    auto load_tile = [&](int k0) {
         if (A2t && k0 >= g.K1) {
             const float* base = A2t + (k0 - g.K1);
 #pragma unroll
@@ -96,17 +101,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
             for (int it = 0; it < A_IT; ++it) ra[it] = *reinterpret_cast<const float4*>(base + aoff[it]);
         }
-        {
-            const float* base = Bt + k0;
+        const float* base = Bt + k0;
 #pragma unroll
-            for (int it = 0; it < B_IT; ++it) rb[it] = *reinterpret_cast<const float4*>(base + boff[it]);
-        }
+        for (int it = 0; it < B_IT; ++it) rb[it] = *reinterpret_cast<const float4*>(base + boff[it]);
+    };
+    if (PF) load_tile(0);
+    for (int k0 = 0; k0 < g.K; k0 += BK) {
+        if (!PF) load_tile(k0);
         __syncthreads();   // previous tile fully consumed
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) { float* d = da + it * 32 * LDT; d[0] = ra[it].x; d[1] = ra[it].y; d[2] = ra[it].z; d[3] = ra[it].w; }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) { float* d = db + it * 32 * LDT; d[0] = rb[it].x; d[1] = rb[it].y; d[2] = rb[it].z; d[3] = rb[it].w; }
         __syncthreads();
+        if (PF && k0 + BK < g.K) load_tile(k0 + BK);
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
             float a[MB], b[NB];

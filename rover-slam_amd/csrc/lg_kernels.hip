@@ -33,13 +33,18 @@ void launch_lg_posenc(hipStream_t s, const float* kn, const float* wr, int rows,
 // 64 MFMA (32x32x2 f32) per 32x32 tile, no wasted FLOPs: 4*L*L*64 per head.
 constexpr int AT_Q = 128, AT_K = 64, AT_LDK = 65;
 constexpr float AT_DEFER = 16.0f;   // log2 units
+constexpr int AT_SPLIT_MAX = 8;               // key ranges of the split variant
+constexpr size_t AT_SPLIT_MAX_ROWS = 8192;    // only problems this small are latency-bound enough to split
 
 // ABL: timing ablations only (wrong results): 1 = no softmax VALU, 2 = stage only the first K/V tile, 3 = both
-template <bool DBUF, int ABL = 0>
+// SPLIT: split-key variant for latency-bound problems (one pair = 64 (sequence, head, query block) units for 256 CUs and
+// a 2048-MFMA serial chain per wave): blockIdx.y selects one of gridDim.y key ranges, the workgroup writes its
+// unnormalised accumulators and (reference max, sum) to `part`, and lg_attention_combine_kernel merges the ranges.
+template <bool DBUF, int ABL = 0, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void lg_attention_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld, float* __restrict__ out,
     int Lq, int Lk, int nqb, const int* __restrict__ qlen, const int* __restrict__ klen, const int* __restrict__ kv_map,
-    int prio) {
+    int prio, float* __restrict__ part = nullptr, int nseq_total = 0) {
     // K/V tiles double buffered in LDS; the next tile is prefetched global->registers under the MFMAs
     __shared__ float Ks[DBUF ? 2 : 1][AT_K * AT_LDK];
     __shared__ float Vs[DBUF ? 2 : 1][AT_K * 64];
@@ -53,6 +58,7 @@ __global__ __launch_bounds__(256, 2) void lg_attention_kernel(
     const int nk = klen ? klen[kvseq] : Lk;
     const int tid = threadIdx.x, lane = tid & 63;
     if (qb * AT_Q >= nq) {  // whole block is padding: keep the padded context rows defined (zero)
+        if (SPLIT) return;  // the combine kernel zeroes them
         for (int e = tid; e < AT_Q * 64; e += 256) {
             const int row = qb * AT_Q + (e >> 6);
             if (row < Lq) out[((size_t)seq * Lq + row) * 256 + head * 64 + (e & 63)] = 0.f;
@@ -103,8 +109,14 @@ __global__ __launch_bounds__(256, 2) void lg_attention_kernel(
         __syncthreads();
     }
     int buf = 0;
-    for (int k0 = 0; k0 < nk; k0 += AT_K) {
-        const bool more = DBUF && (k0 + AT_K < nk);
+    int kbeg = 0, kend = nk;
+    if (SPLIT) {   // key range of this split: whole 64-key tiles
+        const int per = ((nk + (int)gridDim.y - 1) / (int)gridDim.y + AT_K - 1) / AT_K * AT_K;
+        kbeg = (int)blockIdx.y * per;
+        kend = kbeg + per < nk ? kbeg + per : nk;
+    }
+    for (int k0 = kbeg; k0 < kend; k0 += AT_K) {
+        const bool more = DBUF && (k0 + AT_K < kend);
         if (DBUF) {
             if (more) fetch(k0 + AT_K);
         } else if (!(ABL & 2) || k0 == 0) {
@@ -172,6 +184,23 @@ __global__ __launch_bounds__(256, 2) void lg_attention_kernel(
             __syncthreads();
             buf ^= 1;
         }
+    }
+    if (SPLIT) {
+        if (qrow < Lq) {
+            const size_t prow = ((size_t)blockIdx.y * nseq_total + seq) * Lq + qrow;
+            float* op = part + prow * 256 + head * 64;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = (r & 3) + 8 * (r >> 2) + 4 * h;
+                op[d] = o0[r];
+                op[d + 32] = o1[r];
+            }
+            if (h == 0) {
+                float* ml = part + (size_t)gridDim.y * nseq_total * Lq * 256 + (prow * 4 + head) * 2;
+                ml[0] = m_run; ml[1] = l_run;
+            }
+        }
+        return;
     }
     if (qrow < Lq) {
         const float inv = (qrow < nq && l_run > 0.f) ? 1.0f / l_run : 0.f;  // padded rows -> 0
@@ -320,9 +349,58 @@ __global__ __launch_bounds__(256, 2) void lg_attention_q64_kernel(
     }
 }
 
+// merges the key ranges of the split variant: out = sum_s o_s 2^(m_s - m) / sum_s l_s 2^(m_s - m), m = max_s m_s
+__global__ __launch_bounds__(256) void lg_attention_combine_kernel(const float* __restrict__ part, int ns, int nseq, int Lq,
+                                                                   const int* __restrict__ qlen, float* __restrict__ out) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;            // (row, head, 16 float4)
+    const int d4 = gid & 15, head = (gid >> 4) & 3;
+    const size_t row = (size_t)(gid >> 6);                       // seq * Lq + qrow
+    if (row >= (size_t)nseq * Lq) return;
+    const int seq = (int)(row / Lq), qrow = (int)(row % Lq);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (qrow < (qlen ? qlen[seq] : Lq)) {
+        const float* ml = part + (size_t)ns * nseq * Lq * 256;
+        float m = -INFINITY;
+        for (int sp = 0; sp < ns; ++sp) m = fmaxf(m, ml[(((size_t)sp * nseq * Lq + row) * 4 + head) * 2]);
+        float l = 0.f;
+        for (int sp = 0; sp < ns; ++sp) {
+            const size_t prow = (size_t)sp * nseq * Lq + row;
+            const float ms = ml[(prow * 4 + head) * 2], ls = ml[(prow * 4 + head) * 2 + 1];
+            if (!(ls > 0.f)) continue;                           // empty key range
+            const float w = __builtin_amdgcn_exp2f(ms - m);
+            l += ls * w;
+            const float4 o = *reinterpret_cast<const float4*>(part + prow * 256 + head * 64 + d4 * 4);
+            acc.x += o.x * w; acc.y += o.y * w; acc.z += o.z * w; acc.w += o.w * w;
+        }
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+    }
+    *reinterpret_cast<float4*>(out + row * 256 + head * 64 + d4 * 4) = acc;
+}
+
+size_t lg_attention_part_bytes(int nseq, int Lq) {   // scratch of the split-key variant (0 when it would never be chosen)
+    const size_t rows = (size_t)nseq * Lq;
+    return rows <= AT_SPLIT_MAX_ROWS ? rows * AT_SPLIT_MAX * (256 + 8) * sizeof(float) : 0;
+}
+
 void launch_lg_attention(hipStream_t s, const float* q, const float* k, const float* v, int ld, float* out, int nseq, int Lq,
-                         int Lk, const int* qlen, const int* klen, const int* kv_map) {
+                         int Lk, const int* qlen, const int* klen, const int* kv_map, float* part) {
     const int nqb = (Lq + AT_Q - 1) / AT_Q;
+    // latency regime: fewer (sequence, head, query block) units than CUs -> split the keys until the chip is covered
+    static const int split_env = getenv("RFE_ATT_SPLIT") ? atoi(getenv("RFE_ATT_SPLIT")) : -1;   // 0/1 = off, n = force n ranges
+    if (part && (size_t)nseq * Lq <= AT_SPLIT_MAX_ROWS && split_env != 0 && split_env != 1) {
+        const int units = nqb * 4 * nseq;
+        int ns = 1;
+        while (ns < AT_SPLIT_MAX && units * ns * 2 <= 256 && Lk / (ns * 2) >= 2 * AT_K) ns *= 2;
+        if (split_env > 1) ns = split_env < AT_SPLIT_MAX ? split_env : AT_SPLIT_MAX;
+        if (ns > 1) {
+            hipLaunchKernelGGL((lg_attention_kernel<false, 0, true>), dim3(nqb * 4 * nseq, ns), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk,
+                               nqb, qlen, klen, kv_map, 1, part, nseq);
+            hipLaunchKernelGGL(lg_attention_combine_kernel, dim3((unsigned)(((size_t)nseq * Lq * 64 + 255) / 256)), dim3(256), 0, s, part,
+                               ns, nseq, Lq, qlen, out);
+            return;
+        }
+    }
     // 4*nseq (sequence, head) units; nseq = 2P is even so the unit count is a multiple of 8 (XCD decode is bijective)
     static const bool single = getenv("RFE_ATT_DBUF") == nullptr;   // tuning switch: RFE_ATT_DBUF=1 selects the double-buffered variant
     static const bool q64 = getenv("RFE_ATT_Q64") != nullptr;        // tuning switch: 64 queries per wave

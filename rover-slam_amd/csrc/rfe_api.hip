@@ -445,7 +445,7 @@ extern "C" int rfe_extract_u8(rfe_ctx* c, const uint8_t* img, int H, int W, int 
 namespace {
 
 struct LgBuffers {
-    float *x, *kn, *cs, *sn, *qkv, *ctx, *msg, *h, *md, *z, *sim, *rowlse, *collse, *mx0;
+    float *x, *kn, *cs, *sn, *qkv, *ctx, *msg, *h, *md, *z, *sim, *rowlse, *collse, *mx0, *apart;
     int32_t *a0, *a1, *lens, *kvmap;
     char* extra;   // caller-sized scratch region carved after the fixed buffers
 };
@@ -458,6 +458,7 @@ size_t lg_ws_bytes(int P, int L, size_t extra_bytes = 0) {
     t += al((size_t)P * L * L * 4);
     t += al((size_t)P * L * 4) * 5;
     t += al((size_t)2 * P * 4) * 2;
+    t += al(lg_attention_part_bytes(2 * P, L));
     return t + al(extra_bytes) + 4096;
 }
 void lg_carve(void* ws, int P, int L, LgBuffers& b, size_t extra_bytes = 0) {
@@ -471,8 +472,13 @@ void lg_carve(void* ws, int P, int L, LgBuffers& b, size_t extra_bytes = 0) {
     b.rowlse = a.take<float>((size_t)P * L); b.collse = a.take<float>((size_t)P * L); b.mx0 = a.take<float>((size_t)P * L);
     b.a0 = a.take<int32_t>((size_t)P * L); b.a1 = a.take<int32_t>((size_t)P * L);
     b.lens = a.take<int32_t>((size_t)2 * P); b.kvmap = a.take<int32_t>((size_t)2 * P);
+    { const size_t pb = lg_attention_part_bytes(2 * P, L); b.apart = pb ? a.take<float>(pb / 4) : nullptr; }
     b.extra = a.take<char>(extra_bytes);
 }
+
+// scratch of the split-key attention: carved for 2P sequences; a call on fewer sequences (stream mode's per-frame self
+// block) may use it whenever its own requirement fits
+float* lg_part(const LgBuffers& b, int nseq, int L) { return (b.apart && lg_attention_part_bytes(nseq, L) > 0) ? b.apart : nullptr; }
 
 bool lg_fold() { static const bool f = getenv("RFE_LG_NO_FOLD") == nullptr; return f; }
 
@@ -500,7 +506,7 @@ void lg_self_block(rfe_ctx* c, LgBuffers& b, const LgLayerDev& Lw, float* x, con
       GemmArgs a = gemm_plain(x, 256, Lw.wqkv, 256, Lw.bqkv, b.qkv, 768, rows, 768, 256);
       a.rope_cs = cs; a.rope_sn = sn; a.rope_ncols = 512;
       launch_gemm_nt(s, a); }
-    { ProfScope p(c, "lg_attention"); launch_lg_attention(s, b.qkv, b.qkv + 256, b.qkv + 512, 768, b.ctx, nseq, L, L, lens, lens, nullptr); }
+    { ProfScope p(c, "lg_attention"); launch_lg_attention(s, b.qkv, b.qkv + 256, b.qkv + 512, 768, b.ctx, nseq, L, L, lens, lens, nullptr, lg_part(b, nseq, L)); }
     if (lg_fold()) {
         lg_ffn(c, b, x, b.ctx, rows, Lw.w1f, Lw.b1f, Lw.lng, Lw.lnb, Lw.w2, Lw.b2);
     } else {
@@ -523,7 +529,7 @@ int lg_forward(rfe_ctx* c, LgBuffers& b, int P, int L, float thr, int cap, int32
         if (l > 0 || !first_self_done) lg_self_block(c, b, Lw, b.x, b.cs, b.sn, b.lens, nseq, L);
         // ---- cross block
         { ProfScope p(c, "lg_cross_qkv"); launch_gemm_nt(s, gemm_plain(b.x, 256, Lw.cwqkv, 256, Lw.cbqkv, b.qkv, 512, rows, 512, 256)); }
-        { ProfScope p(c, "lg_attention"); launch_lg_attention(s, b.qkv, b.qkv, b.qkv + 256, 512, b.ctx, nseq, L, L, b.lens, b.lens, b.kvmap); }
+        { ProfScope p(c, "lg_attention"); launch_lg_attention(s, b.qkv, b.qkv, b.qkv + 256, 512, b.ctx, nseq, L, L, b.lens, b.lens, b.kvmap, lg_part(b, nseq, L)); }
         if (lg_fold()) {
             lg_ffn(c, b, b.x, b.ctx, rows, Lw.cw1f, Lw.cb1f, Lw.clng, Lw.clnb, Lw.cw2, Lw.cb2);
         } else {

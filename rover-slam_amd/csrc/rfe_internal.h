@@ -139,7 +139,9 @@ void launch_desc_sample(hipStream_t s, const float* dmap, int B, int Hc, int Wc,
 void launch_lg_posenc(hipStream_t s, const float* kn, const float* wr, int rows, float* cs, float* sn);
 void launch_lg_attention(hipStream_t s, const float* q, const float* k, const float* v, int ld /*row stride of q,k,v*/,
                          float* out, int nseq, int Lq, int Lk, const int* qlen, const int* klen,
-                         const int* kv_map /*seq -> kv seq index, or null = identity*/);
+                         const int* kv_map /*seq -> kv seq index, or null = identity*/,
+                         float* part /*lg_attention_part_bytes(nseq, Lq) of scratch for the split-key variant, or null*/);
+size_t lg_attention_part_bytes(int nseq, int Lq);
 void launch_lg_ln_gelu(hipStream_t s, float* h, const float* g, const float* b, int64_t rows);
 void launch_lg_assign(hipStream_t s, const float* sim, const float* z0, const float* z1, int P, int L,
                       int cap, const int* m, const int* n, float thr, float* scores_opt, float* rowlse,
