@@ -267,6 +267,91 @@ __global__ __launch_bounds__(WNTHR, 2) void conv3x3_wide_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// Small-tile variant for latency-bound launches (one or two frames: the 60 x 80 layers give the tiles above only
+// 30-60 workgroups for 256 CUs, conv4a at batch 1 ran at 8 TFLOP/s).  Workgroup = 4 waves covering 4 rows x 32 columns
+// x 32 output channels: wave w owns row w (one M-block) and ONE accumulator, so the grid is 4x larger (180-360
+// workgroups on 60 x 80) and each wave's serial MFMA chain is 4x shorter.  Reads the same packed weights (half of each
+// 64-wide row).  Same reduction order (bit-exact); no pooling.
+constexpr int STH = 4, SIH = STH + 2, SPLANE = SIH * TWS, SNT = 32;
+
+template <int CIN, bool RELU, int CK>
+__global__ __launch_bounds__(256, 4) void conv3x3_small_kernel(
+    const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
+    float* __restrict__ out, int H, int W, int COUT) {
+    constexpr int KCH = CK * 9;
+    __shared__ __attribute__((aligned(16))) float lds[CK * SPLANE + KCH * SNT];
+    float* lds_in = lds;
+    float* lds_w = lds + CK * SPLANE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, h = lane >> 5;
+    const int nct = COUT / SNT;
+    const int b = blockIdx.z / nct, ct = blockIdx.z % nct;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * STH;
+    const int co0 = ct * SNT;
+
+    f32x16 acc;
+    {
+        const float b0 = bias[co0 + col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = b0;
+    }
+    int aoff[9];
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+        const int k0 = 2 * s, k1 = 2 * s + 1;
+        const int o0 = (k0 / 9) * SPLANE + ((k0 % 9) / 3) * TWS + (k0 % 9) % 3;
+        const int o1 = (k1 / 9) * SPLANE + ((k1 % 9) / 3) * TWS + (k1 % 9) % 3;
+        aoff[s] = (h ? o1 : o0) + wave * TWS + col;
+    }
+    const int boff = h * SNT + col;
+    const float* in_b = in + (size_t)b * H * W * CIN;
+    // packed layout [Cout/64][Cin/CK][KCH][64]: this workgroup's 32 channels are half (ct & 1) of 64-tile ct >> 1
+    const float* wp_ct = wp + (size_t)(ct >> 1) * (CIN / CK) * KCH * NT + (ct & 1) * SNT;
+
+    for (int ch = 0; ch < CIN / CK; ++ch) {
+        __syncthreads();
+        for (int idx = tid; idx < SIH * IW * (CK / 4); idx += 256) {
+            const int cq = idx % (CK / 4), pix = idx / (CK / 4);
+            const int py = pix / IW, px = pix % IW;
+            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+                v = *reinterpret_cast<const float4*>(in_b + ((size_t)gy * W + gx) * CIN + ch * CK + cq * 4);
+            float* d = lds_in + (cq * 4) * SPLANE + py * TWS + px;
+            d[0] = v.x; d[SPLANE] = v.y; d[2 * SPLANE] = v.z; d[3 * SPLANE] = v.w;
+        }
+        {
+            const float* src = wp_ct + (size_t)ch * KCH * NT;
+            for (int idx = tid; idx < KCH * (SNT / 4); idx += 256) {
+                const int kl = idx / (SNT / 4), q = idx % (SNT / 4);
+                reinterpret_cast<float4*>(lds_w)[idx] = *reinterpret_cast<const float4*>(src + kl * NT + q * 4);
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int cp = 0; cp < CK / 2; ++cp) {
+            const float* ap = lds_in + cp * 2 * SPLANE;
+            const float* bp = lds_w + cp * 18 * SNT + boff;
+#pragma unroll
+            for (int s = 0; s < 9; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[aoff[s]], bp[2 * s * SNT], acc, 0, 0, 0);
+        }
+    }
+    const int y = y0 + wave;
+    if (y < H) {
+        float* out_b = out + (size_t)b * H * W * COUT;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (x >= W) continue;
+            float v = acc[r];
+            if (RELU) v = fmaxf(v, 0.f);
+            out_b[((size_t)y * W + x) * COUT + co0 + col] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // conv1a + conv1b fused: the 64-channel input tile of conv1b is never read from HBM; every staged
 // 8-channel chunk is recomputed in LDS from the u8 image tile (NormalizeImage * 1/255, conv1a 1->64,
 // bias, ReLU -- same fmaf chain as conv1a_u8_kernel / the oracle, so still bit-exact), then conv1b +
@@ -366,6 +451,16 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
                     const float* bias, int cout, bool relu, bool pool, float* out, int tag) {
     dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B * (cout / NT));
     const bool ck8 = conv_ck() == 8;
+    // latency regime: too few 8 x 32 x 64 tiles to occupy the chip -> 4 x 32 x 32 tiles (4x the workgroups)
+    static const int small_thr = getenv("RFE_CONV_SMALL") ? atoi(getenv("RFE_CONV_SMALL")) : 512;   // 0 disables
+    if (ck8 && !pool && (long long)grid.x * grid.y * grid.z < small_thr && (cin == 64 || cin == 128)) {
+        dim3 gs((W + TW - 1) / TW, (H + STH - 1) / STH, B * (cout / SNT));
+        if (cin == 128 && relu) hipLaunchKernelGGL((conv3x3_small_kernel<128, true, 8>), gs, dim3(256), 0, s, in, wp, bias, out, H, W, cout);
+        else if (cin == 128) hipLaunchKernelGGL((conv3x3_small_kernel<128, false, 8>), gs, dim3(256), 0, s, in, wp, bias, out, H, W, cout);
+        else if (relu) hipLaunchKernelGGL((conv3x3_small_kernel<64, true, 8>), gs, dim3(256), 0, s, in, wp, bias, out, H, W, cout);
+        else hipLaunchKernelGGL((conv3x3_small_kernel<64, false, 8>), gs, dim3(256), 0, s, in, wp, bias, out, H, W, cout);
+        return;
+    }
     static const bool no_wide = getenv("RFE_CONV_NO_WIDE") != nullptr;   // tuning / test switch
     // measured on the 60 x 80 grid: +6 % for the 128-output-channel layers (conv4a/4b), -9 % for the 256-channel
     // heads (convPa/Da re-stage the larger input tile four times), so only the former use it
