@@ -160,8 +160,12 @@ int rfe_distinctive_descriptors(rfe_ctx* ctx, const float* desc, const int32_t* 
 
 /* ---- per-stage timing (hipEvent on the ctx stream), for bench.py's roofline object ----
  * Enable, run, then read back: names is a ';'-separated list of stage names, ms / calls the
- * accumulated time and launch count per stage since the last reset. */
+ * accumulated time and launch count per stage since the last reset.
+ * rfe_profile_filter restricts the events to one stage (NULL or "" = all stages): each pair of events keeps
+ * consecutive kernels from overlapping their launch and drain (about 2 % of a batched step when every stage is
+ * instrumented), so a throughput measurement instruments only the kernel it reports. */
 int rfe_profile_enable(rfe_ctx* ctx, int on);
+int rfe_profile_filter(rfe_ctx* ctx, const char* stage);
 int rfe_profile_reset(rfe_ctx* ctx);
 int rfe_profile_read(rfe_ctx* ctx, char* names, size_t names_cap, double* ms, int64_t* calls, int cap);
 

@@ -17,7 +17,7 @@ EXPORTS = [
     "rfe_memcpy_d2h", "rfe_extract_u8", "rfe_extract_u8_dev", "rfe_match", "rfe_match_dev", "rfe_match_fused",
     "rfe_extract_match_stream_dev", "rfe_stereo_match", "rfe_stereo_match_dev", "rfe_l2_distance_matrix", "rfe_binarize_descriptors",
     "rfe_search_candidates", "rfe_distinctive_descriptors",
-    "rfe_profile_enable", "rfe_profile_reset", "rfe_profile_read",
+    "rfe_profile_enable", "rfe_profile_filter", "rfe_profile_reset", "rfe_profile_read",
     "rfe_k_conv3x3", "rfe_k_linear", "rfe_k_scoremap", "rfe_k_lightglue_taps",
 ]
 
@@ -62,6 +62,7 @@ lib.rfe_binarize_descriptors.argtypes = [C.c_void_p, _fp, C.c_int, _u8p]
 lib.rfe_search_candidates.argtypes = [C.c_void_p, _fp, C.c_int, _fp, C.c_int, _ip, _ip, _u8p, _ip, _fp, _fp]
 lib.rfe_distinctive_descriptors.argtypes = [C.c_void_p, _fp, _ip, C.c_int, _ip, _fp]
 lib.rfe_profile_enable.argtypes = [C.c_void_p, C.c_int]
+lib.rfe_profile_filter.argtypes = [C.c_void_p, C.c_char_p]
 lib.rfe_profile_reset.argtypes = [C.c_void_p]
 lib.rfe_profile_read.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
 lib.rfe_k_conv3x3.argtypes = [C.c_void_p, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]
@@ -234,6 +235,10 @@ class Context:
     # ---- profiling
     def profile(self, on=True):
         self._chk(lib.rfe_profile_enable(self.h, int(on)))
+
+    def profile_filter(self, stage=None):
+        """Record events for one stage only (None = all stages)."""
+        self._chk(lib.rfe_profile_filter(self.h, stage.encode() if stage else None))
 
     def profile_reset(self):
         self._chk(lib.rfe_profile_reset(self.h))

@@ -33,6 +33,7 @@ int ensure_ws(rfe_ctx* c, void** p, size_t* cur, size_t need) {
 
 ProfScope::ProfScope(rfe_ctx* ctx, const char* name) : c(ctx), idx(-1) {
     if (!c->prof) return;
+    if (!c->prof_filter.empty() && c->prof_filter != name) return;
     for (size_t i = 0; i < c->stages.size(); ++i) if (c->stages[i].name == name) idx = (int)i;
     if (idx < 0) { c->stages.push_back(Stage{name, 0, 0}); idx = (int)c->stages.size() - 1; }
     auto get = [&]() { hipEvent_t e; if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
@@ -888,6 +889,11 @@ extern "C" int rfe_distinctive_descriptors(rfe_ctx* c, const float* desc, const 
 // profiling
 // =====================================================================================
 extern "C" int rfe_profile_enable(rfe_ctx* c, int on) { if (!c) return RFE_ERR_INVALID; c->prof = on != 0; return RFE_OK; }
+extern "C" int rfe_profile_filter(rfe_ctx* c, const char* stage) {
+    if (!c) return RFE_ERR_INVALID;
+    c->prof_filter = stage ? stage : "";
+    return RFE_OK;
+}
 extern "C" int rfe_profile_reset(rfe_ctx* c) {
     if (!c) return RFE_ERR_INVALID;
     (void)hipStreamSynchronize(c->stream);

@@ -88,6 +88,7 @@ struct rfe_ctx {
     void* ws_tmp = nullptr; size_t ws_tmp_bytes = 0; // test hooks
     // profiling
     bool prof = false;
+    std::string prof_filter;          // non-empty: only this stage records events
     std::vector<rfe::Stage> stages;
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
     std::vector<hipEvent_t> ev_pool;
