@@ -22,6 +22,29 @@ def build(force=False):
 _lib = None
 
 
+def usable_cpus():
+    """CPUs this process can really run on: min(logical CPUs, affinity mask, cgroup v2/v1 CPU quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, p = int(f.read()), int(g.read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -51,6 +74,10 @@ def lib():
         L.rfo_postprocess_fused.restype = C.c_int
         L.rfo_postprocess_fused.argtypes = [ip, fp, C.c_int, C.c_float, ip, C.c_int]
         L.rfo_stereo_match.argtypes = [u8p, u8p, C.c_int, C.c_int, fp, C.c_int, fp, C.c_int, fp, fp, C.c_float, C.c_float, fp, fp]
+        L.rfo_set_num_threads.argtypes = [C.c_int]
+        L.rfo_get_max_threads.restype = C.c_int
+        if "OMP_NUM_THREADS" not in os.environ:
+            L.rfo_set_num_threads(usable_cpus())
         L.rfo_search_candidates.argtypes = [fp, C.c_int, fp, ip, ip, u8p, ip, fp, fp]
         L.rfo_distinctive_descriptors.argtypes = [fp, ip, C.c_int, ip, fp]
         _lib = L
@@ -234,3 +261,8 @@ def distinctive_descriptors(desc, offsets):
     ip = C.POINTER(C.c_int32)
     lib().rfo_distinctive_descriptors(dp, off.ctypes.data_as(ip), Np, b.ctypes.data_as(ip), _opt(m))
     return b[:Np], m[:Np]
+
+
+def threads():
+    """OpenMP threads the oracle runs on."""
+    return int(lib().rfo_get_max_threads())

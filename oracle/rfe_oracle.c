@@ -746,3 +746,14 @@ void rfo_distinctive_descriptors(const float* desc, const int32_t* offsets, int 
         free(D); free(row);
     }
 }
+
+/* ---- threading control for the OpenMP loops above (test infrastructure): a container may expose 256 logical CPUs */
+/* with a cgroup quota of 16, and 256 spinning libgomp threads on 16 CPUs run 100x slower than 16 threads.           */
+#ifdef _OPENMP
+#include <omp.h>
+void rfo_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int rfo_get_max_threads(void) { return omp_get_max_threads(); }
+#else
+void rfo_set_num_threads(int n) { (void)n; }
+int rfo_get_max_threads(void) { return 1; }
+#endif

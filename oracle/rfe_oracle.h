@@ -81,6 +81,10 @@ void rfo_search_candidates(const float* q, int Nq, const float* f, const int32_t
                            const uint8_t* skip, int32_t* best_idx, float* best_dist, float* second_dist);
 void rfo_distinctive_descriptors(const float* desc, const int32_t* offsets, int Np, int32_t* best, float* median);
 
+/* OpenMP thread count of the loops above (oracle.py sets it to the CPUs the process may actually use) */
+void rfo_set_num_threads(int n);
+int rfo_get_max_threads(void);
+
 #ifdef __cplusplus
 }
 #endif

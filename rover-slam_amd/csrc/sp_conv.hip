@@ -198,23 +198,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
 // 80 = 2.5 x 32).  Here a workgroup is 5 waves covering 4 rows x 80 columns exactly: an M-block is
 // 2 rows x 16 columns, wave w owns columns 16w..16w+15 of rows 0-1 (block 0) and 2-3 (block 1).
 // Same reduction order (bit-exact), no pooling (none of these layers pools).
-constexpr int WTH = 4, WTW = 80, WIH = WTH + 2, WIW = WTW + 2, WTWS = WIW, WPLANE = WIH * WTWS, WNTHR = 320;
-
-template <int CIN, bool RELU, int TAG, int CK>
-__global__ __launch_bounds__(WNTHR, 2) void conv3x3_wide_kernel(
+// Generalised: M-blocks of 2 rows x 16 columns, NW waves of two vertically stacked blocks each, laid out column-major
+// over a TROWS x TCOLS tile.  <5, 4, 80> is the wide tile above (10 waves on 4 SIMDs at 2 workgroups/CU: 3,3,2,2 ->
+// measured only +6 %); <3, 12, 16> tiles 60 x 80 exactly with 3-wave workgroups (4 per CU = 3 waves on every SIMD).
+template <int CIN, bool RELU, int TAG, int CK, int NW, int TROWS, int TCOLS>
+__global__ __launch_bounds__(NW * 64, NW == 3 ? 4 : 2) void conv3x3_blk16_kernel(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ out, int H, int W, int COUT) {
-    constexpr int KCH = CK * 9;
-    __shared__ __attribute__((aligned(16))) float lds[CK * WPLANE + KCH * NT];
+    constexpr int KCH = CK * 9, NTHR = NW * 64;
+    constexpr int WIH_ = TROWS + 2, WIW_ = TCOLS + 2, WTWS_ = WIW_, WPLANE_ = WIH_ * WTWS_, WCOLS = TCOLS / 16;
+    static_assert(NW * 4 * 16 == TROWS * TCOLS, "NW waves x (4 rows x 16 columns) must cover the tile");
+    __shared__ __attribute__((aligned(16))) float lds[CK * WPLANE_ + KCH * NT];
     float* lds_in = lds;
-    float* lds_w = lds + CK * WPLANE;
+    float* lds_w = lds + CK * WPLANE_;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, h = lane >> 5;
     const int nct = COUT / NT;
     const int b = blockIdx.z / nct, ct = blockIdx.z % nct;
-    const int x0 = blockIdx.x * WTW, y0 = blockIdx.y * WTH;
+    const int x0 = blockIdx.x * TCOLS, y0 = blockIdx.y * TROWS;
     const int co0 = ct * NT;
+    const int wr0 = (wave / WCOLS) * 4, wc0 = (wave % WCOLS) * 16;   // this wave's 4 x 16 pixel patch inside the tile
 
     f32x16 acc[2][2];
     {
@@ -226,9 +230,9 @@ __global__ __launch_bounds__(WNTHR, 2) void conv3x3_wide_kernel(
 #pragma unroll
     for (int s = 0; s < 9; ++s) {
         const int k0 = 2 * s, k1 = 2 * s + 1;
-        const int o0 = (k0 / 9) * WPLANE + ((k0 % 9) / 3) * WTWS + (k0 % 9) % 3;
-        const int o1 = (k1 / 9) * WPLANE + ((k1 % 9) / 3) * WTWS + (k1 % 9) % 3;
-        aoff[s] = (h ? o1 : o0) + (col >> 4) * WTWS + wave * 16 + (col & 15);
+        const int o0 = (k0 / 9) * WPLANE_ + ((k0 % 9) / 3) * WTWS_ + (k0 % 9) % 3;
+        const int o1 = (k1 / 9) * WPLANE_ + ((k1 % 9) / 3) * WTWS_ + (k1 % 9) % 3;
+        aoff[s] = (h ? o1 : o0) + (wr0 + (col >> 4)) * WTWS_ + wc0 + (col & 15);
     }
     const int boff = h * NT + col;
     const float* in_b = in + (size_t)b * H * W * CIN;
@@ -236,28 +240,28 @@ __global__ __launch_bounds__(WNTHR, 2) void conv3x3_wide_kernel(
 
     for (int ch = 0; ch < CIN / CK; ++ch) {
         __syncthreads();
-        for (int idx = tid; idx < WIH * WIW * (CK / 4); idx += WNTHR) {
+        for (int idx = tid; idx < WIH_ * WIW_ * (CK / 4); idx += NTHR) {
             const int cq = idx % (CK / 4), pix = idx / (CK / 4);
-            const int py = pix / WIW, px = pix % WIW;
+            const int py = pix / WIW_, px = pix % WIW_;
             const int gy = y0 - 1 + py, gx = x0 - 1 + px;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gy >= 0 && gy < H && gx >= 0 && gx < W)
                 v = *reinterpret_cast<const float4*>(in_b + ((size_t)gy * W + gx) * CIN + ch * CK + cq * 4);
-            float* d = lds_in + (cq * 4) * WPLANE + py * WTWS + px;
-            d[0] = v.x; d[WPLANE] = v.y; d[2 * WPLANE] = v.z; d[3 * WPLANE] = v.w;
+            float* d = lds_in + (cq * 4) * WPLANE_ + py * WTWS_ + px;
+            d[0] = v.x; d[WPLANE_] = v.y; d[2 * WPLANE_] = v.z; d[3 * WPLANE_] = v.w;
         }
-        conv_stage_weights<CK, WNTHR>(lds_w, wp_ct + (size_t)ch * KCH * NT, tid);
+        conv_stage_weights<CK, NTHR>(lds_w, wp_ct + (size_t)ch * KCH * NT, tid);
         __syncthreads();
-        conv_chunk_mma<CK, WPLANE, 2 * WTWS>(lds_in, lds_w, aoff, boff, acc);
+        conv_chunk_mma<CK, WPLANE_, 2 * WTWS_>(lds_in, lds_w, aoff, boff, acc);
     }
-    // D row m = (r&3)+8*(r>>2)+4h of block mb -> pixel (y0 + 2*mb + (m>>4), x0 + 16*wave + (m&15))
+    // D row m = (r&3)+8*(r>>2)+4h of block mb -> pixel (y0 + wr0 + 2*mb + (m>>4), x0 + wc0 + (m&15))
     float* out_b = out + (size_t)b * H * W * COUT;
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int y = y0 + 2 * mb + (m >> 4), x = x0 + 16 * wave + (m & 15);
+            const int y = y0 + wr0 + 2 * mb + (m >> 4), x = x0 + wc0 + (m & 15);
             if (y >= H || x >= W) continue;
             float v0 = acc[mb][0][r], v1 = acc[mb][1][r];
             if (RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
@@ -464,11 +468,23 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
     static const bool no_wide = getenv("RFE_CONV_NO_WIDE") != nullptr;   // tuning / test switch
     // measured on the 60 x 80 grid: +6 % for the 128-output-channel layers (conv4a/4b), -9 % for the 256-channel
     // heads (convPa/Da re-stage the larger input tile four times), so only the former use it
-    if (!no_wide && ck8 && !pool && relu && cin == 128 && W % WTW == 0 && (tag == L_4A || tag == L_4B)) {
-        dim3 gw(W / WTW, (H + WTH - 1) / WTH, B * (cout / NT));
-        switch (tag) {
-            case L_4A: hipLaunchKernelGGL((conv3x3_wide_kernel<128, true, L_4A, 8>), gw, dim3(WNTHR), 0, s, in, wp, bias, out, H, W, cout); return;
-            default: hipLaunchKernelGGL((conv3x3_wide_kernel<128, true, L_4B, 8>), gw, dim3(WNTHR), 0, s, in, wp, bias, out, H, W, cout); return;
+    // 60 x 80 grid (W % 16 == 0, H % 12 == 0): the 12 x 16 tile of 3-wave workgroups covers it exactly
+    static const int tall = getenv("RFE_CONV_TALL") ? atoi(getenv("RFE_CONV_TALL")) : 1;   // 0: 8x32 tile, 2: wide 4x80 tile (conv4 only)
+    if (!no_wide && ck8 && !pool && relu && cin == 128 && (tag == L_4A || tag == L_4B || tag == L_PA || tag == L_DA)) {
+        if (tall == 1 && W % 16 == 0 && H % 12 == 0) {
+            dim3 gt(W / 16, H / 12, B * (cout / NT));
+            switch (tag) {
+                case L_4A: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4A, 8, 3, 12, 16>), gt, dim3(192), 0, s, in, wp, bias, out, H, W, cout); return;
+                case L_4B: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4B, 8, 3, 12, 16>), gt, dim3(192), 0, s, in, wp, bias, out, H, W, cout); return;
+                case L_PA: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_PA, 8, 3, 12, 16>), gt, dim3(192), 0, s, in, wp, bias, out, H, W, cout); return;
+                default: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_DA, 8, 3, 12, 16>), gt, dim3(192), 0, s, in, wp, bias, out, H, W, cout); return;
+            }
+        }
+        if (tall == 2 && W % 80 == 0 && (tag == L_4A || tag == L_4B)) {
+            dim3 gw(W / 80, (H + 3) / 4, B * (cout / NT));
+            if (tag == L_4A) hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4A, 8, 5, 4, 80>), gw, dim3(320), 0, s, in, wp, bias, out, H, W, cout);
+            else hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4B, 8, 5, 4, 80>), gw, dim3(320), 0, s, in, wp, bias, out, H, W, cout);
+            return;
         }
     }
     switch (tag) {
