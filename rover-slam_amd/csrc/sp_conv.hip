@@ -466,12 +466,13 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
         return;
     }
     static const bool no_wide = getenv("RFE_CONV_NO_WIDE") != nullptr;   // tuning / test switch
-    // measured on the 60 x 80 grid: +6 % for the 128-output-channel layers (conv4a/4b), -9 % for the 256-channel
-    // heads (convPa/Da re-stage the larger input tile four times), so only the former use it
-    // 60 x 80 grid (W % 16 == 0, H % 12 == 0): the 12 x 16 tile of 3-wave workgroups covers it exactly
-    static const int tall = getenv("RFE_CONV_TALL") ? atoi(getenv("RFE_CONV_TALL")) : 1;   // 0: 8x32 tile, 2: wide 4x80 tile (conv4 only)
+    // 60 x 80 grid, measured (TFLOP/s, batch 33): 8x32 tile 94 (conv4) / 103 (heads); wide 4x80 tile 97 / 94 (the 256-channel
+    // heads re-stage the larger input tile four times); 12x16 tile of 3-wave workgroups 83 / 108.
+    // -> conv4a/4b take the wide tile, convPa/Da the 12x16 tile.  RFE_CONV_TALL: 0 = 8x32 everywhere, 1 = 12x16 everywhere, 2 = wide for conv4 only
+    static const int tall = getenv("RFE_CONV_TALL") ? atoi(getenv("RFE_CONV_TALL")) : -1;
     if (!no_wide && ck8 && !pool && relu && cin == 128 && (tag == L_4A || tag == L_4B || tag == L_PA || tag == L_DA)) {
-        if (tall == 1 && W % 16 == 0 && H % 12 == 0) {
+        const bool heads = tag == L_PA || tag == L_DA;
+        if ((tall == 1 || (tall == -1 && heads)) && W % 16 == 0 && H % 12 == 0) {
             dim3 gt(W / 16, H / 12, B * (cout / NT));
             switch (tag) {
                 case L_4A: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4A, 8, 3, 12, 16>), gt, dim3(192), 0, s, in, wp, bias, out, H, W, cout); return;
@@ -480,7 +481,7 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
                 default: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_DA, 8, 3, 12, 16>), gt, dim3(192), 0, s, in, wp, bias, out, H, W, cout); return;
             }
         }
-        if (tall == 2 && W % 80 == 0 && (tag == L_4A || tag == L_4B)) {
+        if ((tall == 2 || tall == -1) && W % 80 == 0 && !heads) {
             dim3 gw(W / 80, (H + 3) / 4, B * (cout / NT));
             if (tag == L_4A) hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4A, 8, 5, 4, 80>), gw, dim3(320), 0, s, in, wp, bias, out, H, W, cout);
             else hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4B, 8, 5, 4, 80>), gw, dim3(320), 0, s, in, wp, bias, out, H, W, cout);
