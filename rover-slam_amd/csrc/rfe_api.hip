@@ -400,7 +400,7 @@ int sp_forward(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, int B, 
     int rc = sp_forward_maps(c, img, H, W, stride, B, b);
     if (rc) return rc;
     { ProfScope p(c, "sp_select");
-      launch_select(c->stream, b.nmap, B, H, W, Kmax, thr, b.cand_score, b.cand_idx, n, kxy, score);
+      launch_select(c->stream, b.nmap, B, H, W, Kmax, thr, b.cand_score, b.cand_idx, n, kxy, score, (int32_t*)b.ss /*NMS scratch, free by now*/);
       launch_desc_sample(c->stream, b.dmap, B, H / 8, W / 8, H, W, n, kxy, Kmax, desc); }
     RFE_HIP(c, hipGetLastError());
     return RFE_OK;

@@ -132,7 +132,8 @@ void launch_softmax65_d2s(hipStream_t s, const float* logits, int ld, int B, int
 void launch_nms(hipStream_t s, const float* score, int B, int H, int W, int border, float* tmp_ss,
                 uint8_t* tmp_mask, uint8_t* tmp_supp, float* out);
 void launch_select(hipStream_t s, const float* nms, int B, int H, int W, int Kmax, float thr,
-                   float* cand_score, int32_t* cand_idx, int32_t* n_out, int32_t* kxy, float* score);
+                   float* cand_score, int32_t* cand_idx, int32_t* n_out, int32_t* kxy, float* score,
+                   int32_t* chunk_cnt /*B * ceil(H*W/4096) ints of scratch*/);
 void launch_descmap_norm(hipStream_t s, float* dmap, int64_t cells);
 void launch_desc_sample(hipStream_t s, const float* dmap, int B, int Hc, int Wc, int H, int W,
                         const int32_t* n, const int32_t* kxy, int Kmax, float* desc);

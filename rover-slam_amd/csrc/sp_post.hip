@@ -143,8 +143,8 @@ void launch_nms(hipStream_t st, const float* score, int B, int H, int W, int bor
 }
 
 // ---------------------------------------------------------------- threshold + top-k selection
-// One 1024-thread workgroup per frame.  (1) ordered (row-major) compaction of pixels with
-// nms > thr; (2) if more than Kmax candidates: 4-pass radix select on the score bits for the
+// (1) ordered (row-major) compaction of pixels with nms > thr (count + compact kernels over 4096-pixel chunks);
+// (2) one 1024-thread workgroup per frame: if more than Kmax candidates: 4-pass radix select on the score bits for the
 // Kmax-th largest score, ties resolved by ascending pixel index (candidate order), then a bitonic
 // sort of the selected 64-bit keys (score bits << 32 | ~index) in LDS -> score-descending output.
 constexpr int SEL_T = 1024;
@@ -179,10 +179,80 @@ __device__ __forceinline__ int block_excl_scan_int(int v, int* wave_tot /*[16]*/
     return off + x - v;
 }
 
+// Ordered compaction spread over the chip (one 1024-thread workgroup scanning a 640 x 480 map alone took 95 us of the
+// 105 us of this stage at batch 1): workgroup (chunk, frame) handles SEL_CHUNK consecutive pixels, 16 per thread.
+// Pass 1 counts the candidates of every chunk, pass 2 writes them at (sum of the earlier chunks' counts) + block scan.
+constexpr int SEL_CHUNK = 4096;
+
+__device__ __forceinline__ int sel_load16(const float* __restrict__ s, int HW, int p0, float thr, float (&v)[16]) {
+    int cnt = 0;
+    if (p0 + 15 < HW) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 a = *reinterpret_cast<const float4*>(s + p0 + 4 * q);
+            v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = p0 + e < HW ? s[p0 + e] : -1.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cnt += v[e] > thr ? 1 : 0;
+    return cnt;
+}
+
+__global__ __launch_bounds__(256) void select_count_kernel(const float* __restrict__ nms, int HW, int nch, float thr,
+                                                           int32_t* __restrict__ chunk_cnt) {
+    __shared__ int wtot[4];
+    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    float v[16];
+    int cnt = sel_load16(nms + (size_t)b * HW, HW, chunk * SEL_CHUNK + tid * 16, thr, v);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if ((tid & 63) == 0) wtot[tid >> 6] = cnt;
+    __syncthreads();
+    if (tid == 0) chunk_cnt[b * nch + chunk] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+}
+
+__global__ __launch_bounds__(256) void select_compact_kernel(const float* __restrict__ nms, int HW, int nch, float thr,
+                                                             const int32_t* __restrict__ chunk_cnt,
+                                                             float* __restrict__ cand_score, int32_t* __restrict__ cand_idx) {
+    __shared__ int wtot[4];
+    __shared__ int sbase;
+    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // base = candidates in the earlier chunks of this frame
+    int part = 0;
+    for (int c = tid; c < chunk; c += 256) part += chunk_cnt[b * nch + c];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
+    if (lane == 0) wtot[wv] = part;
+    __syncthreads();
+    if (tid == 0) sbase = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    __syncthreads();
+    const int base = sbase;
+    const int p0 = chunk * SEL_CHUNK + tid * 16;
+    float v[16];
+    const int cnt = sel_load16(nms + (size_t)b * HW, HW, p0, thr, v);
+    int x = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(x, off); if (lane >= off) x += y; }
+    __syncthreads();
+    if (lane == 63) wtot[wv] = x;
+    __syncthreads();
+    int pos = base + x - cnt;
+    for (int w = 0; w < wv; ++w) pos += wtot[w];
+    float* cs = cand_score + (size_t)b * HW;
+    int32_t* ci = cand_idx + (size_t)b * HW;
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+        if (v[e] > thr) { cs[pos] = v[e]; ci[pos] = p0 + e; ++pos; }
+}
+
 __global__ __launch_bounds__(SEL_T) void select_kernel(const float* __restrict__ nms, int H, int W, int Kmax,
                                                        int P2, float thr, float* __restrict__ cand_score,
                                                        int32_t* __restrict__ cand_idx, int32_t* __restrict__ n_out,
-                                                       int32_t* __restrict__ kxy, float* __restrict__ score) {
+                                                       int32_t* __restrict__ kxy, float* __restrict__ score,
+                                                       const int32_t* __restrict__ chunk_cnt, int nch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);  // [P2]
     __shared__ int wave_tot[SEL_T / 64];
@@ -191,34 +261,13 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(const float* __restrict__
     __shared__ int sh_remaining;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int HW = H * W;
-    const float* s = nms + (size_t)b * HW;
+    (void)nms;
     float* cs = cand_score + (size_t)b * HW;
     int32_t* ci = cand_idx + (size_t)b * HW;
 
-    // ordered (row-major) compaction, 8 consecutive pixels per thread and iteration: one block scan per 8192 pixels
+    // candidates were compacted in row-major order by select_count_kernel / select_compact_kernel
     int count = 0;
-    for (int base = 0; base < HW; base += SEL_T * 8) {
-        const int p0 = base + tid * 8;
-        float v[8];
-        if (p0 + 7 < HW) {
-            const float4 a = *reinterpret_cast<const float4*>(s + p0), c = *reinterpret_cast<const float4*>(s + p0 + 4);
-            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = p0 + e < HW ? s[p0 + e] : -1.f;
-        }
-        int cnt = 0;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) cnt += v[e] > thr ? 1 : 0;
-        int tot;
-        int pos = count + block_excl_scan_int(cnt, wave_tot, tot);
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-            if (v[e] > thr) { cs[pos] = v[e]; ci[pos] = p0 + e; ++pos; }
-        count += tot;
-    }
-    __syncthreads();  // candidate list visible to the whole workgroup (global writes by this WG)
-    __threadfence_block();
+    for (int c = 0; c < nch; ++c) count += chunk_cnt[b * nch + c];
 
     int32_t* okxy = kxy + (size_t)b * Kmax * 2;
     float* osc = score + (size_t)b * Kmax;
@@ -248,11 +297,15 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(const float* __restrict__
             if ((bits & pmask) == prefix) atomicAdd(&hist[(bits >> shift) & 255], 1);
         }
         __syncthreads();
-        if (tid == 0) {
-            int rem = sh_remaining, bin = 255;
-            for (; bin > 0; --bin) { if (hist[bin] >= rem) break; rem -= hist[bin]; }
-            sh_prefix = prefix | ((unsigned int)bin << shift);
-            sh_remaining = rem;
+        {   // bin holding the rem-th largest: scan the histogram from the top bin down, in parallel
+            const int rem = sh_remaining;
+            const int v = tid < 256 ? hist[255 - tid] : 0;
+            int tot;
+            const int above = block_excl_scan_int(v, wave_tot, tot);   // candidates in higher bins
+            if (tid < 256 && above < rem && above + v >= rem) {
+                sh_prefix = prefix | ((unsigned int)(255 - tid) << shift);
+                sh_remaining = rem - above;
+            }
         }
         __syncthreads();
     }
@@ -275,34 +328,28 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(const float* __restrict__
         eq_seen += tot_eq; sel_seen += tot_sel;
     }
     __syncthreads();
-    // ---- bitonic sort, descending
-    for (int kk = 2; kk <= P2; kk <<= 1)
-        for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < P2; t += SEL_T) {
-                const int ixj = t ^ j;
-                if (ixj > t) {
-                    const unsigned long long a = keys[t], c = keys[ixj];
-                    const bool desc = (t & kk) == 0;
-                    if (desc ? (a < c) : (a > c)) { keys[t] = c; keys[ixj] = a; }
-                }
-            }
-            __syncthreads();
-        }
+    // ---- rank sort, descending: keys are distinct (the pixel index is part of the key), so the number of larger keys
+    // is the output position.  Kmax broadcast LDS reads per key instead of the 55 barrier-separated bitonic stages.
     if (tid == 0) n_out[b] = Kmax;
-    for (int k = tid; k < Kmax; k += SEL_T) {
-        const unsigned long long key = keys[k];
+    for (int t = tid; t < Kmax; t += SEL_T) {
+        const unsigned long long key = keys[t];
+        int rank = 0;
+        for (int j = 0; j < Kmax; ++j) rank += keys[j] > key ? 1 : 0;
         const int idx = (int)(0xFFFFFFFFu - (unsigned int)(key & 0xFFFFFFFFull));
-        okxy[2 * k] = idx % W; okxy[2 * k + 1] = idx / W;
-        osc[k] = __uint_as_float((unsigned int)(key >> 32));
+        okxy[2 * rank] = idx % W; okxy[2 * rank + 1] = idx / W;
+        osc[rank] = __uint_as_float((unsigned int)(key >> 32));
     }
 }
 
 void launch_select(hipStream_t s, const float* nms, int B, int H, int W, int Kmax, float thr, float* cand_score,
-                   int32_t* cand_idx, int32_t* n_out, int32_t* kxy, float* score) {
+                   int32_t* cand_idx, int32_t* n_out, int32_t* kxy, float* score, int32_t* chunk_cnt) {
     int P2 = 1;
     while (P2 < Kmax) P2 <<= 1;
+    const int HW = H * W, nch = (HW + SEL_CHUNK - 1) / SEL_CHUNK;   // chunk_cnt: B * nch ints of scratch
+    hipLaunchKernelGGL(select_count_kernel, dim3(nch, B), dim3(256), 0, s, nms, HW, nch, thr, chunk_cnt);
+    hipLaunchKernelGGL(select_compact_kernel, dim3(nch, B), dim3(256), 0, s, nms, HW, nch, thr, chunk_cnt, cand_score, cand_idx);
     hipLaunchKernelGGL(select_kernel, dim3(B), dim3(SEL_T), (size_t)P2 * 8, s, nms, H, W, Kmax, P2, thr,
-                       cand_score, cand_idx, n_out, kxy, score);
+                       cand_score, cand_idx, n_out, kxy, score, chunk_cnt, nch);
 }
 
 // ---------------------------------------------------------------- 256-d L2 normalisation
