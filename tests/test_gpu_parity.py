@@ -133,6 +133,18 @@ def test_extract_batch_equals_single(ctx):
         assert n1[0] == nb[i] and np.array_equal(k1[0], kb[i]) and np.array_equal(s1[0], sb[i]) and np.array_equal(d1[0], db[i])
 
 
+def test_full_size_batch_equals_single(ctx):
+    """640x480, batch of 12: the throughput tilings (8x32 conv tile, wide 4x80 and 12x16 tiles on the 60x80 layers,
+    128x256 GEMM tiles) against the latency tilings a single frame takes (4x32x32 conv tile, 64-row GEMM tiles) --
+    different tile shapes, same reduction order, so every output must be bit-identical (and the single-frame path is
+    the one test_full_size_640x480_vs_oracle pins to the oracle)."""
+    frames, _ = synth.make_frames(12, 480, 640, seed=77)
+    nb, kb, sb, db = ctx.extract(frames, kmax=1024)
+    for i in (0, 5, 11):
+        n1, k1, s1, d1 = ctx.extract(frames[i], kmax=1024)
+        assert n1[0] == nb[i] and np.array_equal(k1[0], kb[i]) and np.array_equal(s1[0], sb[i]) and np.array_equal(d1[0], db[i])
+
+
 # ------------------------------------------------------------------ LightGlue
 def _pair_from_golden(g):
     return g["k0n"], g["k1n"], g["d0"], g["d1"]
@@ -185,6 +197,31 @@ def test_lightglue_ragged_batch(ctx, oracle):
         assert S[p] == r["S"]
         assert np.array_equal(pairs[p, :S[p]], r["pairs"])
         assert np.abs(ms[p, :S[p]] - r["ms"]).max() < 1e-4 if S[p] else True
+
+
+def test_lightglue_k1024_batch_equals_single(ctx):
+    """K = 1024: six pairs in one call (128x256 GEMM tiles, one attention workgroup per query block) against the same
+    pairs one at a time (64-row GEMM tiles, split-key attention + combine).  Same GEMM reduction order; the attention
+    merges its key ranges in a different order, so scores agree to the stated 5e-4 and the match lists exactly."""
+    rng = np.random.default_rng(33)
+    P, K = 6, 1024
+    lens0 = [1024, 1024, 700, 1024, 333, 1024]; lens1 = [1024, 900, 1024, 257, 1024, 1024]
+    k0 = np.zeros((P, K, 2), np.float32); k1 = np.zeros((P, K, 2), np.float32)
+    d0 = np.zeros((P, K, 256), np.float32); d1 = np.zeros((P, K, 256), np.float32)
+    for p in range(P):
+        a = rng.standard_normal((K, 256)).astype(np.float32); a /= np.linalg.norm(a, axis=1, keepdims=True)
+        kk = rng.uniform(-0.9, 0.9, (K, 2)).astype(np.float32)
+        perm = rng.permutation(K)
+        m, n = lens0[p], lens1[p]
+        d0[p, :m] = a[:m]; k0[p, :m] = kk[:m]
+        bb = a[perm][:n] + 0.05 * rng.standard_normal((n, 256)).astype(np.float32)
+        d1[p, :n] = bb / np.linalg.norm(bb, axis=1, keepdims=True); k1[p, :n] = (kk[perm][:n] + 0.002).astype(np.float32)
+    S, pairs, ms = ctx.match(k0, k1, d0, d1, lens0, lens1)
+    assert (S > 50).all()
+    for p in range(P):
+        S1, p1, m1 = ctx.match(k0[p:p + 1], k1[p:p + 1], d0[p:p + 1], d1[p:p + 1], lens0[p:p + 1], lens1[p:p + 1])
+        assert S1[0] == S[p] and np.array_equal(p1[0, :S1[0]], pairs[p, :S[p]])
+        assert np.abs(m1[0, :S1[0]] - ms[p, :S[p]]).max() < 5e-4
 
 
 def test_match_fused_semantics(ctx, oracle):
