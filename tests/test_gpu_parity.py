@@ -397,3 +397,30 @@ def test_lightglue_permutation_equivariance(ctx):
     assert len(base) > 20 and set(base) == set(got)
     assert max(abs(base[k] - got[k]) for k in base) < 5e-4   # same stated score tolerance as against the oracle (reduction orders change with the permutation)
     assert (np.diff(pairs2[0, :S2[0], 0]) > 0).all()   # output stays sorted by the index in image 0
+
+
+@pytest.mark.parametrize("sp_seed,lg_seed,dustbin,batch", [(21, 5, 0.0, 1), (9, 13, 10.5, 7)])
+def test_full_size_other_weights_vs_oracle(oracle, sp_seed, lg_seed, dustbin, batch):
+    """640x480 against the oracle with other weight sets: a saturated one (K = Kmax) and one with a dustbin bias
+    (K < Kmax, different per frame -> ragged LightGlue lengths), extracted alone (latency tilings) and inside a batch
+    (throughput tilings).  SuperPoint bit-exact; LightGlue match lists identical, scores within the stated 5e-4."""
+    from rover_slam_amd import capi
+    c = capi.Context(0)
+    wsp = Wt.make_superpoint(seed=sp_seed, dustbin_bias=dustbin)
+    wlg = Wt.make_lightglue(seed=lg_seed)
+    c.set_weights(capi.KIND_SUPERPOINT, wsp); c.set_weights(capi.KIND_LIGHTGLUE, wlg)
+    frames, _ = synth.make_frames(batch + 1, 480, 640, seed=1000 + sp_seed)
+    n, kxy, score, desc = c.extract(frames, kmax=1024)
+    refs = []
+    for i in (0, 1):
+        r = oracle.superpoint(wsp, frames[i], kmax=1024)
+        assert n[i] == r["n"] and (n[i] < 1024) == (dustbin > 0)
+        assert np.array_equal(kxy[i], r["kxy"]) and np.array_equal(score[i], r["score"]) and np.array_equal(desc[i], r["desc"])
+        refs.append(r)
+    k0 = oracle.normalize_keypoints(kxy[0, :n[0]].astype(np.float32), 480, 640)
+    k1 = oracle.normalize_keypoints(kxy[1, :n[1]].astype(np.float32), 480, 640)
+    size, vn = c.match_fused(kxy[0, :n[0]].astype(np.float32), kxy[1, :n[1]].astype(np.float32), desc[0, :n[0]], desc[1, :n[1]], 480, 640)
+    r = oracle.lightglue(wlg, k0, k1, desc[0, :n[0]], desc[1, :n[1]])
+    size_ref, vn_ref = oracle.postprocess_fused(r["pairs"], r["ms"], 0.0, int(n[0]))
+    assert size == size_ref and np.array_equal(vn, vn_ref)
+    c.close()
