@@ -31,18 +31,18 @@ int ensure_ws(rfe_ctx* c, void** p, size_t* cur, size_t need) {
     return RFE_OK;
 }
 
-ProfScope::ProfScope(rfe_ctx* ctx, const char* name) : c(ctx), idx(-1) {
+ProfScope::ProfScope(rfe_ctx* ctx, const char* name, hipStream_t on) : c(ctx), idx(-1), st(on ? on : ctx->stream) {
     if (!c->prof) return;
     if (!c->prof_filter.empty() && c->prof_filter != name) return;
     for (size_t i = 0; i < c->stages.size(); ++i) if (c->stages[i].name == name) idx = (int)i;
     if (idx < 0) { c->stages.push_back(Stage{name, 0, 0}); idx = (int)c->stages.size() - 1; }
     auto get = [&]() { hipEvent_t e; if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
     e0 = get(); e1 = get();
-    (void)hipEventRecord(e0, c->stream);
+    (void)hipEventRecord(e0, st);
 }
 ProfScope::~ProfScope() {
     if (idx < 0) return;
-    (void)hipEventRecord(e1, c->stream);
+    (void)hipEventRecord(e1, st);
     c->pending.push_back({idx, {e0, e1}});
 }
 void prof_collect(rfe_ctx* c) {
@@ -98,6 +98,12 @@ extern "C" int rfe_init(int device, rfe_ctx** out) {
         return fail(nullptr, RFE_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
     c->stream = c->own_stream;
+    if ((e = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) {
+        rfe_destroy(c);
+        return fail(nullptr, RFE_ERR_HIP, std::string("hipStreamCreate/hipEventCreate: ") + hipGetErrorString(e));
+    }
     *out = c;
     return RFE_OK;
 }
@@ -113,6 +119,9 @@ extern "C" void rfe_destroy(rfe_ctx* c) {
     for (int l = 0; l < 12; ++l) { fr(c->sp.packed[l]); fr(c->sp.bias[l]); }
     fr(c->lg.blob); fr(c->lg.extra);
     fr(c->ws_sp); fr(c->ws_lg); fr(c->ws_io); fr(c->ws_tmp);
+    if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -361,7 +370,10 @@ int sp_check(rfe_ctx* c, int H, int W, int B, int Kmax) {
 }
 
 // backbone + heads up to the NMS'ed score map and the normalised descriptor map
-int sp_forward_maps(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, int B, SpBuffers& b) {
+// join = false: the caller still has detector-only work to enqueue and joins the descriptor stream itself
+// (hipStreamWaitEvent(c->stream, c->ev_join)) when `forked` comes back true
+int sp_forward_maps(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, int B, SpBuffers& b, bool join, bool& forked) {
+    forked = false;
     int rc = ensure_ws(c, &c->ws_sp, &c->ws_sp_bytes, sp_ws_bytes(B, H, W));
     if (rc) return rc;
     sp_carve(c->ws_sp, B, H, W, b);
@@ -382,14 +394,25 @@ int sp_forward_maps(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, in
     { ProfScope p(c, "conv3b"); launch_conv3x3(s, b.a3, B, H / 4, W / 4, 128, w.packed[L_3B], w.bias[L_3B], 128, true, true, b.p3, L_3B); }
     { ProfScope p(c, "conv4a"); launch_conv3x3(s, b.p3, B, Hc, Wc, 128, w.packed[L_4A], w.bias[L_4A], 128, true, false, b.a4, L_4A); }
     { ProfScope p(c, "conv4b"); launch_conv3x3(s, b.a4, B, Hc, Wc, 128, w.packed[L_4B], w.bias[L_4B], 128, true, false, b.f4, L_4B); }
+    // The two heads only share their input f4.  The descriptor head (convDa, convDb, L2 norm: MFMA work) runs on the
+    // side stream while the detector head continues on the main one with its tail of small bandwidth / latency-bound
+    // kernels (convPb, softmax, 5 NMS passes, selection), which would otherwise leave most of the chip idle.
+    // With events around every stage (full profiling pass) the heads stay serial so that the stage times are clean.
+    static const bool fork_env = getenv("RFE_SP_NO_FORK") == nullptr;
+    const bool fork = fork_env && !(c->prof && c->prof_filter.empty());
+    hipStream_t sd = fork ? c->side_stream : s;
+    if (fork) { RFE_HIP(c, hipEventRecord(c->ev_fork, s)); RFE_HIP(c, hipStreamWaitEvent(sd, c->ev_fork, 0)); }
+    { ProfScope p(c, "convDa", sd); launch_conv3x3(sd, b.f4, B, Hc, Wc, 128, w.packed[L_DA], w.bias[L_DA], 256, true, false, b.da, L_DA); }
+    { ProfScope p(c, "convDb", sd); launch_gemm_nt(sd, gemm_plain(b.da, 256, w.packed[L_DB], 256, w.bias[L_DB], b.dmap, 256, cells, 256, 256)); }
+    { ProfScope p(c, "sp_post", sd); launch_descmap_norm(sd, b.dmap, cells); }
+    if (fork) RFE_HIP(c, hipEventRecord(c->ev_join, sd));
     { ProfScope p(c, "convPa"); launch_conv3x3(s, b.f4, B, Hc, Wc, 128, w.packed[L_PA], w.bias[L_PA], 256, true, false, b.pa, L_PA); }
-    { ProfScope p(c, "convDa"); launch_conv3x3(s, b.f4, B, Hc, Wc, 128, w.packed[L_DA], w.bias[L_DA], 256, true, false, b.da, L_DA); }
     { ProfScope p(c, "convPb"); launch_gemm_nt(s, gemm_plain(b.pa, 256, w.packed[L_PB], 256, w.bias[L_PB], b.logits, 65, cells, 65, 256)); }
-    { ProfScope p(c, "convDb"); launch_gemm_nt(s, gemm_plain(b.da, 256, w.packed[L_DB], 256, w.bias[L_DB], b.dmap, 256, cells, 256, 256)); }
     { ProfScope p(c, "sp_post");
       launch_softmax65_d2s(s, b.logits, 65, B, Hc, Wc, b.smap);
-      launch_nms(s, b.smap, B, H, W, 4, b.ss, b.mask, b.supp, b.nmap);
-      launch_descmap_norm(s, b.dmap, cells); }
+      launch_nms(s, b.smap, B, H, W, 4, b.ss, b.mask, b.supp, b.nmap); }
+    if (fork && join) RFE_HIP(c, hipStreamWaitEvent(s, c->ev_join, 0));
+    forked = fork && !join;
     RFE_HIP(c, hipGetLastError());
     return RFE_OK;
 }
@@ -397,10 +420,12 @@ int sp_forward_maps(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, in
 int sp_forward(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, int B, int Kmax, float thr,
                int32_t* n, int32_t* kxy, float* score, float* desc) {
     SpBuffers b;
-    int rc = sp_forward_maps(c, img, H, W, stride, B, b);
+    bool forked;
+    int rc = sp_forward_maps(c, img, H, W, stride, B, b, false, forked);
     if (rc) return rc;
     { ProfScope p(c, "sp_select");
       launch_select(c->stream, b.nmap, B, H, W, Kmax, thr, b.cand_score, b.cand_idx, n, kxy, score, (int32_t*)b.ss /*NMS scratch, free by now*/);
+      if (forked) RFE_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));   // descriptor map ready
       launch_desc_sample(c->stream, b.dmap, B, H / 8, W / 8, H, W, n, kxy, Kmax, desc); }
     RFE_HIP(c, hipGetLastError());
     return RFE_OK;
@@ -961,7 +986,8 @@ extern "C" int rfe_k_scoremap(rfe_ctx* c, const uint8_t* img, int H, int W, int 
     if (rc) return rc;
     RFE_HIP(c, hipSetDevice(c->device));
     SpBuffers b;
-    if ((rc = sp_forward_maps(c, img, H, W, stride, B, b))) return rc;
+    bool forked;
+    if ((rc = sp_forward_maps(c, img, H, W, stride, B, b, true, forked))) return rc;
     const size_t hw = (size_t)B * H * W;
     if (scoremap) RFE_HIP(c, hipMemcpyAsync(scoremap, b.smap, hw * 4, hipMemcpyDeviceToDevice, c->stream));
     if (nms) RFE_HIP(c, hipMemcpyAsync(nms, b.nmap, hw * 4, hipMemcpyDeviceToDevice, c->stream));

@@ -77,6 +77,8 @@ struct rfe_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr;   // descriptor head of SuperPoint runs here, concurrently with the detector head
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     bool has_sp = false, has_lg = false;
     rfe::SpWeightsDev sp;
@@ -107,7 +109,8 @@ int fail(rfe_ctx* c, int code, const std::string& msg);
 // profiling scope: records two events around a stage when ctx->prof is on
 struct ProfScope {
     rfe_ctx* c; int idx; hipEvent_t e0 = nullptr, e1 = nullptr;
-    ProfScope(rfe_ctx* ctx, const char* name);
+    hipStream_t st;
+    ProfScope(rfe_ctx* ctx, const char* name, hipStream_t on = nullptr);
     ~ProfScope();
 };
 void prof_collect(rfe_ctx* c);
