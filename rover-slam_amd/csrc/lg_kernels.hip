@@ -44,7 +44,7 @@ template <bool DBUF, int ABL = 0, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void lg_attention_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld, float* __restrict__ out,
     int Lq, int Lk, int nqb, const int* __restrict__ qlen, const int* __restrict__ klen, const int* __restrict__ kv_map,
-    int prio, float* __restrict__ part = nullptr, int nseq_total = 0) {
+    int prio, float* __restrict__ part, int nseq_total) {
     // K/V tiles double buffered in LDS; the next tile is prefetched global->registers under the MFMAs
     __shared__ float Ks[DBUF ? 2 : 1][AT_K * AT_LDK];
     __shared__ float Vs[DBUF ? 2 : 1][AT_K * 64];
@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256, 2) void lg_attention_kernel(
     // (sequence, head) run on the same XCD so its K/V (512 KB) is fetched into one L2 only.
     const int Lb = blockIdx.x, xcd = Lb & 7, t_ = Lb >> 3;
     const int qb = t_ % nqb, unit = (t_ / nqb) * 8 + xcd;
+    if (unit >= 4 * nseq_total) return;   // the grid is padded to a multiple of 8 (sequence, head) units so that the decode stays bijective
     const int seq = unit >> 2, head = unit & 3;
     const int kvseq = kv_map ? kv_map[seq] : seq;
     const int nq = qlen ? qlen[seq] : Lq;
@@ -219,12 +220,13 @@ __global__ __launch_bounds__(256, 2) void lg_attention_kernel(
 // independent QK^T chains fill each other's issue gaps.  Same arithmetic per query as the kernel above.
 __global__ __launch_bounds__(256, 2) void lg_attention_q64_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld, float* __restrict__ out,
-    int Lq, int Lk, int nqb, const int* __restrict__ qlen, const int* __restrict__ klen, const int* __restrict__ kv_map) {
+    int Lq, int Lk, int nqb, const int* __restrict__ qlen, const int* __restrict__ klen, const int* __restrict__ kv_map, int nseq_total) {
     constexpr int NQ = 2, QB = 128 * NQ;
     __shared__ float Ks[AT_K * AT_LDK];
     __shared__ float Vs[AT_K * 64];
     const int Lb = blockIdx.x, xcd = Lb & 7, t_ = Lb >> 3;
     const int qb = t_ % nqb, unit = (t_ / nqb) * 8 + xcd;
+    if (unit >= 4 * nseq_total) return;
     const int seq = unit >> 2, head = unit & 3;
     const int kvseq = kv_map ? kv_map[seq] : seq;
     const int nq = qlen ? qlen[seq] : Lq;
@@ -386,6 +388,10 @@ size_t lg_attention_part_bytes(int nseq, int Lq) {   // scratch of the split-key
 void launch_lg_attention(hipStream_t s, const float* q, const float* k, const float* v, int ld, float* out, int nseq, int Lq,
                          int Lk, const int* qlen, const int* klen, const int* kv_map, float* part) {
     const int nqb = (Lq + AT_Q - 1) / AT_Q;
+    // (sequence, head) units, padded to a multiple of 8: the kernels deal their blocks round-robin over the 8 XCDs and map
+    // block -> (unit, query block) by unit = (t / nqb) * 8 + xcd, which is a bijection only for a multiple of 8 units
+    // (2P sequences always are; the per-frame self block of the stream mode runs on B sequences, e.g. 33)
+    const int units8 = (4 * nseq + 7) / 8 * 8;
     // latency regime: fewer (sequence, head, query block) units than CUs -> split the keys until the chip is covered
     static const int split_env = getenv("RFE_ATT_SPLIT") ? atoi(getenv("RFE_ATT_SPLIT")) : -1;   // 0/1 = off, n = force n ranges
     if (part && (size_t)nseq * Lq <= AT_SPLIT_MAX_ROWS && split_env != 0 && split_env != 1) {
@@ -394,30 +400,29 @@ void launch_lg_attention(hipStream_t s, const float* q, const float* k, const fl
         while (ns < AT_SPLIT_MAX && units * ns * 2 <= 256 && Lk / (ns * 2) >= 2 * AT_K) ns *= 2;
         if (split_env > 1) ns = split_env < AT_SPLIT_MAX ? split_env : AT_SPLIT_MAX;
         if (ns > 1) {
-            hipLaunchKernelGGL((lg_attention_kernel<false, 0, true>), dim3(nqb * 4 * nseq, ns), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk,
+            hipLaunchKernelGGL((lg_attention_kernel<false, 0, true>), dim3(nqb * units8, ns), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk,
                                nqb, qlen, klen, kv_map, 1, part, nseq);
             hipLaunchKernelGGL(lg_attention_combine_kernel, dim3((unsigned)(((size_t)nseq * Lq * 64 + 255) / 256)), dim3(256), 0, s, part,
                                ns, nseq, Lq, qlen, out);
             return;
         }
     }
-    // 4*nseq (sequence, head) units; nseq = 2P is even so the unit count is a multiple of 8 (XCD decode is bijective)
     static const bool single = getenv("RFE_ATT_DBUF") == nullptr;   // tuning switch: RFE_ATT_DBUF=1 selects the double-buffered variant
     static const bool q64 = getenv("RFE_ATT_Q64") != nullptr;        // tuning switch: 64 queries per wave
     if (q64 && Lq >= 512) {
         const int nqb2 = (Lq + 255) / 256;
-        hipLaunchKernelGGL(lg_attention_q64_kernel, dim3(nqb2 * 4 * nseq), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb2, qlen, klen, kv_map);
+        hipLaunchKernelGGL(lg_attention_q64_kernel, dim3(nqb2 * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb2, qlen, klen, kv_map, nseq);
         return;
     }
     static const int abl = getenv("RFE_DBG_ATT_ABL") ? atoi(getenv("RFE_DBG_ATT_ABL")) : 0;   // timing ablations (wrong results)
-    if (abl == 1) { hipLaunchKernelGGL((lg_attention_kernel<false, 1>), dim3(nqb * 4 * nseq), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0); return; }
-    if (abl == 2) { hipLaunchKernelGGL((lg_attention_kernel<false, 2>), dim3(nqb * 4 * nseq), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0); return; }
-    if (abl == 3) { hipLaunchKernelGGL((lg_attention_kernel<false, 3>), dim3(nqb * 4 * nseq), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0); return; }
+    if (abl == 1) { hipLaunchKernelGGL((lg_attention_kernel<false, 1>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0, nullptr, nseq); return; }
+    if (abl == 2) { hipLaunchKernelGGL((lg_attention_kernel<false, 2>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0, nullptr, nseq); return; }
+    if (abl == 3) { hipLaunchKernelGGL((lg_attention_kernel<false, 3>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0, nullptr, nseq); return; }
     static const int prio = getenv("RFE_ATT_PRIO") ? atoi(getenv("RFE_ATT_PRIO")) : 1;   // s_setprio(1) around the MFMA clusters (+0.8 %); RFE_ATT_PRIO=0 disables
     if (single)
-        hipLaunchKernelGGL(lg_attention_kernel<false>, dim3(nqb * 4 * nseq), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio);
+        hipLaunchKernelGGL(lg_attention_kernel<false>, dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nullptr, nseq);
     else
-        hipLaunchKernelGGL(lg_attention_kernel<true>, dim3(nqb * 4 * nseq), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio);
+        hipLaunchKernelGGL(lg_attention_kernel<true>, dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nullptr, nseq);
 }
 
 // ---------------------------------------------------------------- LayerNorm(512) + GELU(erf), in place

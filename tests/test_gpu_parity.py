@@ -328,11 +328,13 @@ def test_constant_image_no_crash(ctx, oracle):
     assert n[0] == r["n"] and np.array_equal(kxy[0], r["kxy"]) and np.array_equal(score[0], r["score"])
 
 
-def test_stream_mode_equals_pairwise(ctx, oracle):
+@pytest.mark.parametrize("B,H,W,K", [(5, 120, 160, 128), (3, 240, 320, 512), (7, 240, 320, 384)])
+def test_stream_mode_equals_pairwise(ctx, oracle, B, H, W, K):
     """rfe_extract_match_stream_dev (B frames, matches (i,i+1), first self block shared per frame) gives the same
-    features as rfe_extract_u8 and the same matches as one rfe_match call per pair -- and as the oracle."""
+    features as rfe_extract_u8 and the same matches as one rfe_match call per pair -- and as the oracle.
+    The per-frame self block runs on B sequences: odd B with several query blocks (K >= 256) makes 4*B (sequence, head)
+    units that are not a multiple of the 8 XCDs (regression: the attention block decode skipped part of the last frame)."""
     from rover_slam_amd import capi
-    B, H, W, K = 5, 120, 160, 128
     frames, _ = synth.make_frames(B, H, W, seed=11)
     dimg = _dev(ctx, frames)
     dn, dk, ds, dd = ctx.alloc(B * 4), ctx.alloc(B * K * 8), ctx.alloc(B * K * 4), ctx.alloc(B * K * 1024)
@@ -350,7 +352,7 @@ def test_stream_mode_equals_pairwise(ctx, oracle):
         k1 = oracle.normalize_keypoints(kxy[i + 1].astype(np.float32), H, W)
         S1, p1, m1 = ctx.match(k0[None], k1[None], desc[i][None], desc[i + 1][None], [n[i]], [n[i + 1]])
         assert S[i] == S1[0] and np.array_equal(pairs[i, :S[i]], p1[0, :S1[0]])
-        assert np.abs(ms[i, :S[i]] - m1[0, :S1[0]]).max() < 1e-5 if S[i] else True
+        assert np.abs(ms[i, :S[i]] - m1[0, :S1[0]]).max() < (1e-5 if K <= 128 else 5e-4) if S[i] else True   # K > 128: split-key attention in the single-pair call
         r = oracle.lightglue(wlg, k0[:n[i]], k1[:n[i + 1]], desc[i, :n[i]], desc[i + 1, :n[i + 1]])
         assert S[i] == r["S"] and np.array_equal(pairs[i, :S[i]], r["pairs"])
     for d in (dimg, dn, dk, ds, dd, dS, dp, dm):
@@ -424,3 +426,34 @@ def test_full_size_other_weights_vs_oracle(oracle, sp_seed, lg_seed, dustbin, ba
     size_ref, vn_ref = oracle.postprocess_fused(r["pairs"], r["ms"], 0.0, int(n[0]))
     assert size == size_ref and np.array_equal(vn, vn_ref)
     c.close()
+
+
+def test_stream_mode_repeatable_full_size(ctx):
+    """The bench configuration in small: 640x480, B = 5 frames (20 (sequence, head) units, 8 query blocks each) twice into
+    fresh buffers -- every output byte identical (a block-decode bug once left half of the last frame's first self block
+    uncomputed, which showed as run-to-run differences in the last pair and out-of-bounds reads)."""
+    from rover_slam_amd import capi
+    B, H, W, K = 5, 480, 640, 1024
+    frames, _ = synth.make_frames(B, H, W, seed=4242)
+    dimg = _dev(ctx, frames)
+    outs = []
+    for rep in range(2):
+        d = [ctx.alloc(B * 4), ctx.alloc(B * K * 8), ctx.alloc(B * K * 4), ctx.alloc(B * K * 1024),
+             ctx.alloc((B - 1) * 4), ctx.alloc((B - 1) * K * 8), ctx.alloc((B - 1) * K * 4)]
+        for x, nbytes in zip(d, (B * 4, B * K * 8, B * K * 4, B * K * 1024, (B - 1) * 4, (B - 1) * K * 8, (B - 1) * K * 4)):
+            x.upload(np.zeros(nbytes, np.uint8))
+        ctx._chk(capi.lib.rfe_extract_match_stream_dev(ctx.h, dimg.ptr, H, W, W, B, K, 0.0005, 0.1, *[x.ptr for x in d]))
+        ctx.synchronize()
+        outs.append([x.download((nb,), np.uint8) for x, nb in zip(d, (B * 4, B * K * 8, B * K * 4, B * K * 1024, (B - 1) * 4, (B - 1) * K * 8, (B - 1) * K * 4))])
+        for x in d:
+            x.free()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    # and the last pair agrees with a stand-alone match of the same two frames
+    n = outs[0][0].view(np.int32); kxy = outs[0][1].view(np.int32).reshape(B, K, 2); desc = outs[0][3].view(np.float32).reshape(B, K, 256)
+    S = outs[0][4].view(np.int32); pairs = outs[0][5].view(np.int32).reshape(B - 1, K, 2)
+    i = B - 2
+    size, vn = ctx.match_fused(kxy[i, :n[i]].astype(np.float32), kxy[i + 1, :n[i + 1]].astype(np.float32), desc[i, :n[i]], desc[i + 1, :n[i + 1]], H, W)
+    want = np.full(n[i], -1, np.int32); want[pairs[i, :S[i], 0]] = pairs[i, :S[i], 1]
+    assert size == S[i] and np.array_equal(vn, want)
+    dimg.free()
