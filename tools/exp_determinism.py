@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from rover_slam_amd import capi, weights as Wt, synth
 
-H, W, K, B = 480, 640, 1024, 33
+H, W, K, B = [int(v) for v in os.environ.get("CFG", "480,640,1024,33").split(",")]
 dev = torch.device("cuda", 0)
 c = capi.Context(0)
 c.set_weights(capi.KIND_SUPERPOINT, Wt.make_superpoint(seed=7)); c.set_weights(capi.KIND_LIGHTGLUE, Wt.make_lightglue(seed=11))
