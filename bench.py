@@ -91,7 +91,7 @@ def pmc_traffic(stage):
     return None, None
 
 
-def cpu_baseline(frames, wsp, wlg):
+def cpu_baseline(frames, wsp, wlg, gpu=None):
     """The CPU oracle (a port, not the reference's ONNXRuntime path -- that cannot run here: no
     onnxruntime, no .onnx blobs) on a bounded sample of the bench frames (about 12 s of CPU work)."""
     from oracle import oracle as O
@@ -99,15 +99,37 @@ def cpu_baseline(frames, wsp, wlg):
     # bounded sample: frames are extracted and matched to their predecessor one by one until ~12 s of CPU work are spent
     t0 = time.perf_counter()
     prev, nf = None, 0
+    sp_ok, lg_ok = True, True
     while nf < len(frames) and (nf < 4 or time.perf_counter() - t0 < 12.0):
         cur = O.superpoint(wsp, frames[nf], kmax=KMAX)
+        lg = None
         if prev is not None:
-            O.lightglue(wlg, O.normalize_keypoints(prev["kxy"][:prev["n"]].astype(np.float32), H, W),
-                        O.normalize_keypoints(cur["kxy"][:cur["n"]].astype(np.float32), H, W), prev["desc"][:prev["n"]], cur["desc"][:cur["n"]])
+            lg = O.lightglue(wlg, O.normalize_keypoints(prev["kxy"][:prev["n"]].astype(np.float32), H, W),
+                             O.normalize_keypoints(cur["kxy"][:cur["n"]].astype(np.float32), H, W), prev["desc"][:prev["n"]], cur["desc"][:cur["n"]])
+        if gpu is not None:   # the oracle doubles as the checker of what the timed loop produced (not timed here: numpy compares are cheap)
+            sp_ok &= bool(gpu["n"][nf] == cur["n"] and np.array_equal(gpu["kxy"][nf], cur["kxy"]) and np.array_equal(gpu["score"][nf], cur["score"])
+                          and np.array_equal(gpu["desc"][nf], cur["desc"]))
+            if lg is not None:
+                Sg = int(gpu["S"][nf - 1])
+                lg_ok &= bool(Sg == lg["S"] and np.array_equal(gpu["pairs"][nf - 1, :Sg], lg["pairs"]))
         prev = cur
         nf += 1
     dt = time.perf_counter() - t0
-    return {"value": round((nf - 1) / dt, 4), "unit": "frames/s", "cores": O.threads(), "kind": "port",
+    verified = None
+    if gpu is not None:
+        extra = 0
+        if nf < len(frames):   # untimed: the last pair of the batch too (the batch edges are where indexing slips show)
+            a, b = O.superpoint(wsp, frames[-2], kmax=KMAX), O.superpoint(wsp, frames[-1], kmax=KMAX)
+            lg = O.lightglue(wlg, O.normalize_keypoints(a["kxy"][:a["n"]].astype(np.float32), H, W),
+                             O.normalize_keypoints(b["kxy"][:b["n"]].astype(np.float32), H, W), a["desc"][:a["n"]], b["desc"][:b["n"]])
+            sp_ok &= bool(np.array_equal(gpu["kxy"][-1], b["kxy"]) and np.array_equal(gpu["desc"][-1], b["desc"]))
+            Sg = int(gpu["S"][-1])
+            lg_ok &= bool(Sg == lg["S"] and np.array_equal(gpu["pairs"][-1, :Sg], lg["pairs"]))
+            extra = 1
+        verified = {"frames": nf + 2 * extra, "pairs": nf - 1 + extra, "superpoint_bit_exact": sp_ok, "match_lists_identical": lg_ok}
+        if not (sp_ok and lg_ok):
+            print(f"bench.py: GPU results of the timed loop differ from the oracle: {verified}", file=sys.stderr)
+    return {"value": round((nf - 1) / dt, 4), "unit": "frames/s", "cores": O.threads(), "kind": "port", "verified_against_gpu": verified,
             "sample": f"{nf} frames 640x480 extracted + {nf - 1} consecutive pairs matched (K<=1024) by oracle/rfe_oracle.c, "
                       f"OpenMP on {O.threads()} threads (= the CPUs this process may use: {os.cpu_count()} logical CPUs, affinity and "
                       f"cgroup quota applied), {dt:.1f} s; {nf - 1} frames counted"}
@@ -409,7 +431,8 @@ def main():
             out["pcie_inclusive"] = {"value": round(pcie, 2), "unit": "frames/s",
                                      "note": "same step with H2D of the 33 u8 frames and D2H of all results (descriptors included) per step, pinned host memory, double buffered on a copy stream; not the headline value"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frames_np, wsp, wlg)
+            gpu = {k: v.cpu().numpy() for k, v in (("n", n), ("kxy", kxy), ("score", score), ("desc", desc), ("S", S), ("pairs", pairs))}
+            out["cpu_baseline"] = cpu_baseline(frames_np, wsp, wlg, gpu)
         print(json.dumps(out))
     ctx.close()
     if world > 1:
