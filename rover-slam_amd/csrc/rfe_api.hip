@@ -699,10 +699,12 @@ extern "C" int rfe_extract_match_stream_dev(rfe_ctx* c, const uint8_t* img, int 
     if ((rc = lg_check(c, B - 1, Kmax, Kmax))) return rc;
     if (!S || !pairs || !ms) return fail(c, RFE_ERR_INVALID, "stream: null match output");
     const int P = B - 1, L = ((Kmax + 3) / 4) * 4;
-    const size_t kn_bytes = (size_t)B * Kmax * 8;   // normalised keypoints of all B frames
-    if ((rc = ensure_ws(c, &c->ws_lg, &c->ws_lg_bytes, lg_ws_bytes(P, L, kn_bytes)))) return rc;
+    const size_t kn_bytes = al((size_t)B * Kmax * 8);        // normalised keypoints of all B frames
+    const size_t rot_bytes = al((size_t)B * L * 32 * 4);      // per-FRAME rotary tables (cos, sin)
+    const size_t extra_bytes = kn_bytes + 2 * rot_bytes;
+    if ((rc = ensure_ws(c, &c->ws_lg, &c->ws_lg_bytes, lg_ws_bytes(P, L, extra_bytes)))) return rc;
     LgBuffers b;
-    lg_carve(c->ws_lg, P, L, b, kn_bytes);
+    lg_carve(c->ws_lg, P, L, b, extra_bytes);
     float* kn_all = (float*)b.extra;
     hipStream_t s = c->stream;
     static const bool dedup = getenv("RFE_NO_SELF_DEDUP") == nullptr;   // tuning / test switch
@@ -714,9 +716,9 @@ extern "C" int rfe_extract_match_stream_dev(rfe_ctx* c, const uint8_t* img, int 
     }
     // Every interior frame is side 1 of pair i-1 and side 0 of pair i, and layer 0's self block depends on
     // the frame alone: run it (and the positional encoding) once per FRAME, then scatter into the pair layout.
-    float* xf = b.md;                        // [B, L, 256]   (md / sim are only used by the assignment at the end)
-    float* csf = b.sim;                      // [B*L, 32]
-    float* snf = b.sim + (size_t)B * L * 32;
+    float* xf = b.md;                        // [B, L, 256]: md ([2P, L, 256], B <= 2P) is only used by the assignment at the end
+    float* csf = (float*)(b.extra + kn_bytes);              // [B*L, 32] each, own scratch (the similarity buffer
+    float* snf = (float*)(b.extra + kn_bytes + rot_bytes);  //  [P, L, L] is too small for them when L < 64 (P+1)/P)
     { ProfScope p(c, "lg_misc");
       launch_normalize_kpts(s, kxy, (int64_t)B * Kmax, H, W, kn_all);
       launch_lg_posenc(s, kn_all, c->lg.wr, B * L, csf, snf);

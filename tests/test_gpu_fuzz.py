@@ -1,0 +1,18 @@
+"""GPU: a short run of the randomised shape sweep (tools/fuzz_parity.py): random image sizes, batches, keypoint budgets,
+ragged LightGlue batches and stream-mode shapes against the oracle.  SuperPoint bit-exact, match lists identical
+(flips are tolerated only for matches within 2e-4 of the 0.1 filter or of an argmax tie), scores within 5e-4."""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [3, 4])
+def test_fuzz_parity_short(seed):
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(ROOT, "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    assert fz.main(seconds=12.0, seed=seed) == 0

@@ -328,12 +328,13 @@ def test_constant_image_no_crash(ctx, oracle):
     assert n[0] == r["n"] and np.array_equal(kxy[0], r["kxy"]) and np.array_equal(score[0], r["score"])
 
 
-@pytest.mark.parametrize("B,H,W,K", [(5, 120, 160, 128), (3, 240, 320, 512), (7, 240, 320, 384)])
+@pytest.mark.parametrize("B,H,W,K", [(5, 120, 160, 128), (3, 240, 320, 512), (7, 240, 320, 384), (6, 208, 232, 32), (3, 200, 152, 48)])
 def test_stream_mode_equals_pairwise(ctx, oracle, B, H, W, K):
     """rfe_extract_match_stream_dev (B frames, matches (i,i+1), first self block shared per frame) gives the same
     features as rfe_extract_u8 and the same matches as one rfe_match call per pair -- and as the oracle.
     The per-frame self block runs on B sequences: odd B with several query blocks (K >= 256) makes 4*B (sequence, head)
-    units that are not a multiple of the 8 XCDs (regression: the attention block decode skipped part of the last frame)."""
+    units that are not a multiple of the 8 XCDs (regression: the attention block decode skipped part of the last frame);
+    K < 64 (P+1)/P once overflowed the per-frame rotary tables, which lived in the [P, L, L] similarity buffer."""
     from rover_slam_amd import capi
     frames, _ = synth.make_frames(B, H, W, seed=11)
     dimg = _dev(ctx, frames)
