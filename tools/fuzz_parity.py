@@ -24,10 +24,11 @@ def main(seconds=60.0, seed=0):
     t0, it, fails = time.time(), 0, 0
     while time.time() - t0 < seconds:
         it += 1
-        kind = it % 3
+        kind = it % 5
         if kind == 0:                                             # ---- SuperPoint
-            H, W = 8 * int(rng.integers(6, 33)), 8 * int(rng.integers(6, 41))
-            B, K = int(rng.integers(1, 6)), int(rng.choice([1, 7, 64, 100, 333, 512, 1024]))
+            big = rng.random() < 0.08
+            H, W = (480, int(rng.choice([640, 752]))) if big else (8 * int(rng.integers(6, 33)), 8 * int(rng.integers(6, 41)))
+            B, K = int(rng.integers(1, 6)), int(rng.choice([1, 7, 64, 100, 333, 512, 1024, 4096]))
             w = wsp if rng.random() < 0.6 else wsp2
             c.set_weights(capi.KIND_SUPERPOINT, w)
             frames, _ = synth.make_frames(B, H, W, seed=int(rng.integers(1 << 30)))
@@ -39,7 +40,8 @@ def main(seconds=60.0, seed=0):
             tag = f"sp H={H} W={W} B={B} K={K}"
         elif kind == 1:                                           # ---- LightGlue, ragged batch
             P = int(rng.integers(1, 5))
-            Mmax, Nmax = int(rng.integers(1, 400)), int(rng.integers(1, 400))
+            hi = 1025 if rng.random() < 0.1 else 400
+            Mmax, Nmax = int(rng.integers(1, hi)), int(rng.integers(1, hi))
             ms_, ns_ = [int(rng.integers(0, Mmax + 1)) for _ in range(P)], [int(rng.integers(0, Nmax + 1)) for _ in range(P)]
             ms_[0], ns_[0] = Mmax, Nmax
             k0 = rng.uniform(-0.9, 0.9, (P, Mmax, 2)).astype(np.float32); k1 = rng.uniform(-0.9, 0.9, (P, Nmax, 2)).astype(np.float32)
@@ -71,9 +73,39 @@ def main(seconds=60.0, seed=0):
                     good = near and dmax < 5e-4
                 ok &= good
             tag = f"lg P={P} Mmax={Mmax} Nmax={Nmax} m={ms_} n={ns_}"
+        elif kind == 3:                                           # ---- sparse stereo matching on extracted features
+            H, W = 8 * int(rng.integers(12, 40)), 8 * int(rng.integers(16, 60))
+            disp = int(rng.integers(0, 30))
+            scene = synth.make_scene(rng, H, W + disp, margin=0)
+            left = np.ascontiguousarray(np.clip(scene[:, :W] + rng.integers(0, 8, (H, W)), 0, 255).astype(np.uint8))
+            right = np.ascontiguousarray(np.clip(scene[:, disp:disp + W] + rng.integers(0, 8, (H, W)), 0, 255).astype(np.uint8))
+            c.set_weights(capi.KIND_SUPERPOINT, wsp)
+            K = int(rng.choice([50, 200, 500]))
+            n, kxy, score, desc = c.extract(np.stack([left, right]), kmax=K)
+            kl, kr = kxy[0, :n[0]].astype(np.float32), kxy[1, :n[1]].astype(np.float32)
+            mb = float(rng.uniform(0.05, 0.5)); mbf = mb * float(rng.uniform(200, 600))
+            u, z = c.stereo_match(left, right, kl, kr, desc[0, :n[0]], desc[1, :n[1]], mb, mbf)
+            ur, zr = O.stereo_match(left, right, kl, kr, desc[0, :n[0]], desc[1, :n[1]], mb, mbf)
+            ok = bool(np.array_equal(u, ur) and np.array_equal(z, zr))
+            tag = f"stereo H={H} W={W} disp={disp} n={n.tolist()}"
+        elif kind == 4:                                           # ---- classic-search helpers
+            Nq, Nf = int(rng.integers(1, 300)), int(rng.integers(1, 700))
+            f = rng.standard_normal((Nf, 256)).astype(np.float32); f /= np.linalg.norm(f, axis=1, keepdims=True)
+            q = f[rng.integers(0, Nf, Nq)] + 0.05 * rng.standard_normal((Nq, 256)).astype(np.float32)
+            lens = rng.integers(0, 30, Nq); off = np.zeros(Nq + 1, np.int32); off[1:] = np.cumsum(lens)
+            cand = rng.integers(0, Nf, off[-1]).astype(np.int32)
+            skip = (rng.random(Nf) < 0.2).astype(np.uint8) if rng.random() < 0.7 else None
+            got = c.search_candidates(q, f, off, cand, skip); ref = O.search_candidates(q, f, off, cand, skip)
+            ok = all(np.array_equal(a, b) for a, b in zip(got, ref))
+            plens = rng.integers(0, 40, int(rng.integers(1, 60))).astype(np.int32); poff = np.zeros(len(plens) + 1, np.int32); poff[1:] = np.cumsum(plens)
+            dd = rng.standard_normal((max(int(poff[-1]), 1), 256)).astype(np.float32)
+            got = c.distinctive_descriptors(dd, poff); ref = O.distinctive_descriptors(dd, poff)
+            ok &= all(np.array_equal(a, b) for a, b in zip(got, ref))
+            tag = f"search Nq={Nq} Nf={Nf} / distinctive Np={len(plens)}"
         else:                                                     # ---- stream mode vs extract + oracle matches
-            H, W = 8 * int(rng.integers(10, 31)), 8 * int(rng.integers(10, 41))
-            B, K = int(rng.integers(2, 8)), int(rng.choice([32, 32, 48, 100, 128, 256, 300, 512]))
+            big = rng.random() < 0.08
+            H, W = (480, 640) if big else (8 * int(rng.integers(10, 31)), 8 * int(rng.integers(10, 41)))
+            B, K = int(rng.integers(2, 8)), int(rng.choice([32, 32, 48, 100, 128, 256, 300, 512, 1024] if big else [32, 32, 48, 100, 128, 256, 300, 512]))
             c.set_weights(capi.KIND_SUPERPOINT, wsp)
             frames, _ = synth.make_frames(B, H, W, seed=int(rng.integers(1 << 30)))
             dimg = c.alloc(frames.nbytes).upload(frames)
