@@ -160,17 +160,23 @@ class Context:
         return DevBuf(self, nbytes)
 
     # ---- host-buffer entry points
-    def extract(self, img_u8, kmax=1024, thr=0.0005):
-        """img_u8: [B,H,W] or [H,W] uint8 (host).  Returns n[B], kxy[B,Kmax,2], score[B,Kmax], desc[B,Kmax,256]."""
+    def extract(self, img_u8, kmax=1024, thr=0.0005, pad_cols=0):
+        """img_u8: [B,H,W] or [H,W] uint8 (host).  Returns n[B], kxy[B,Kmax,2], score[B,Kmax], desc[B,Kmax,256].
+        pad_cols > 0 passes the frames with a row stride of W + pad_cols bytes (like a cv::Mat ROI)."""
         img = np.ascontiguousarray(img_u8, np.uint8)
         if img.ndim == 2:
             img = img[None]
         B, H, W = img.shape
+        stride = W + pad_cols
+        if pad_cols:
+            wide = np.full((B, H, stride), 255, np.uint8)
+            wide[:, :, :W] = img
+            img = wide
         n = np.zeros((B,), np.int32)
         kxy = np.zeros((B, kmax, 2), np.int32)
         score = np.zeros((B, kmax), np.float32)
         desc = np.zeros((B, kmax, 256), np.float32)
-        self._chk(lib.rfe_extract_u8(self.h, img.ctypes.data, H, W, W, B, kmax, thr, n.ctypes.data, kxy.ctypes.data,
+        self._chk(lib.rfe_extract_u8(self.h, img.ctypes.data, H, W, stride, B, kmax, thr, n.ctypes.data, kxy.ctypes.data,
                                      score.ctypes.data, desc.ctypes.data))
         return n, kxy, score, desc
 

@@ -32,12 +32,13 @@ def main(seconds=60.0, seed=0):
             w = wsp if rng.random() < 0.6 else wsp2
             c.set_weights(capi.KIND_SUPERPOINT, w)
             frames, _ = synth.make_frames(B, H, W, seed=int(rng.integers(1 << 30)))
-            n, kxy, score, desc = c.extract(frames, kmax=K)
+            pad = int(rng.choice([0, 0, 3, 8, 40]))
+            n, kxy, score, desc = c.extract(frames, kmax=K, pad_cols=pad)
             ok = True
             for i in range(B):
                 r = O.superpoint(w, frames[i], kmax=K)
                 ok &= bool(n[i] == r["n"] and np.array_equal(kxy[i], r["kxy"]) and np.array_equal(score[i], r["score"]) and np.array_equal(desc[i], r["desc"]))
-            tag = f"sp H={H} W={W} B={B} K={K}"
+            tag = f"sp H={H} W={W} B={B} K={K} pad={pad}"
         elif kind == 1:                                           # ---- LightGlue, ragged batch
             P = int(rng.integers(1, 5))
             hi = 1025 if rng.random() < 0.1 else 400
@@ -105,7 +106,7 @@ def main(seconds=60.0, seed=0):
         else:                                                     # ---- stream mode vs extract + oracle matches
             big = rng.random() < 0.08
             H, W = (480, 640) if big else (8 * int(rng.integers(10, 31)), 8 * int(rng.integers(10, 41)))
-            B, K = int(rng.integers(2, 8)), int(rng.choice([32, 32, 48, 100, 128, 256, 300, 512, 1024] if big else [32, 32, 48, 100, 128, 256, 300, 512]))
+            B, K = int(rng.integers(2, 8)), int(rng.choice([32, 48, 100, 128, 256, 300, 512, 1024] if big else [1, 5, 32, 33, 48, 100, 101, 128, 256, 300, 512]))
             c.set_weights(capi.KIND_SUPERPOINT, wsp)
             frames, _ = synth.make_frames(B, H, W, seed=int(rng.integers(1 << 30)))
             dimg = c.alloc(frames.nbytes).upload(frames)
