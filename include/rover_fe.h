@@ -67,6 +67,11 @@ const char* rfe_version(void);
 int rfe_load_weights(rfe_ctx* ctx, const char* sp_path, const char* lg_path); /* either may be NULL */
 int rfe_set_weights(rfe_ctx* ctx, int kind, const float* blob, int64_t count);
 int64_t rfe_weight_count(int kind);
+/* Read-only weights are shared inside a process: every ctx that loads the same blob on the same device uses one device
+ * copy (the reference keeps 2-3 extractors and 3 matchers per process, each with a private session: src/Tracking.cc:645-651,
+ * :70, src/LocalMapping.cc:45, src/LoopClosing.cc:46).  rfe_weights_id: opaque id of the copy a ctx uses (0 = none);
+ * equal ids = shared copy. */
+uint64_t rfe_weights_id(rfe_ctx* ctx, int kind);
 
 /* ---- stream / sync / device memory helpers (so a pure-C caller needs no HIP headers) ---- */
 int rfe_set_stream(rfe_ctx* ctx, void* hip_stream); /* NULL -> ctx's own stream */

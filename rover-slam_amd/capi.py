@@ -13,7 +13,7 @@ KIND_SUPERPOINT, KIND_LIGHTGLUE = 1, 2
 
 EXPORTS = [
     "rfe_init", "rfe_destroy", "rfe_last_error", "rfe_version", "rfe_load_weights", "rfe_set_weights",
-    "rfe_weight_count", "rfe_set_stream", "rfe_synchronize", "rfe_malloc", "rfe_free", "rfe_memcpy_h2d",
+    "rfe_weight_count", "rfe_weights_id", "rfe_set_stream", "rfe_synchronize", "rfe_malloc", "rfe_free", "rfe_memcpy_h2d",
     "rfe_memcpy_d2h", "rfe_extract_u8", "rfe_extract_u8_dev", "rfe_match", "rfe_match_dev", "rfe_match_fused",
     "rfe_extract_match_stream_dev", "rfe_stereo_match", "rfe_stereo_match_dev", "rfe_l2_distance_matrix", "rfe_binarize_descriptors",
     "rfe_search_candidates", "rfe_distinctive_descriptors",
@@ -38,6 +38,8 @@ lib.rfe_load_weights.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
 lib.rfe_set_weights.argtypes = [C.c_void_p, C.c_int, _fp, C.c_int64]
 lib.rfe_weight_count.argtypes = [C.c_int]
 lib.rfe_weight_count.restype = C.c_int64
+lib.rfe_weights_id.restype = C.c_uint64
+lib.rfe_weights_id.argtypes = [C.c_void_p, C.c_int]
 lib.rfe_set_stream.argtypes = [C.c_void_p, C.c_void_p]
 lib.rfe_synchronize.argtypes = [C.c_void_p]
 lib.rfe_malloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]

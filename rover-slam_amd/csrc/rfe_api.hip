@@ -5,7 +5,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <map>
 #include <mutex>
+#include <tuple>
 #include "rfe_internal.h"
 
 using namespace rfe;
@@ -115,9 +117,7 @@ extern "C" void rfe_destroy(rfe_ctx* c) {
     prof_collect(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
-    fr(c->sp.conv1a_w);
-    for (int l = 0; l < 12; ++l) { fr(c->sp.packed[l]); fr(c->sp.bias[l]); }
-    fr(c->lg.blob); fr(c->lg.extra);
+    c->sp_hold.reset(); c->lg_hold.reset();   // the last ctx holding a device copy frees it
     fr(c->ws_sp); fr(c->ws_lg); fr(c->ws_io); fr(c->ws_tmp);
     if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -173,6 +173,34 @@ extern "C" int64_t rfe_weight_count(int kind) {
     return kind == RFE_KIND_SUPERPOINT ? SP_COUNT : kind == RFE_KIND_LIGHTGLUE ? LG_COUNT : -1;
 }
 
+// Read-only weights are shared: Rover-SLAM keeps 2-3 extractors and 3 matchers per process, each with a private runner
+// (src/Tracking.cc:645-651, :70; LocalMapping.cc:45; LoopClosing.cc:46).  Every ctx that loads the same blob on the same
+// device points at ONE device copy (keyed by device, kind and a 64-bit FNV-1a hash of the floats); the copy is freed
+// when the last ctx holding it is destroyed or loads something else.
+namespace {
+struct SpShared {
+    rfe::SpWeightsDev w; int device = 0;
+    ~SpShared() {
+        (void)hipSetDevice(device);
+        if (w.conv1a_w) (void)hipFree(w.conv1a_w);
+        for (int l = 0; l < 12; ++l) { if (w.packed[l]) (void)hipFree(w.packed[l]); if (w.bias[l]) (void)hipFree(w.bias[l]); }
+    }
+};
+struct LgShared {
+    rfe::LgWeightsDev w; int device = 0;
+    ~LgShared() { (void)hipSetDevice(device); if (w.blob) (void)hipFree(w.blob); if (w.extra) (void)hipFree(w.extra); }
+};
+std::mutex g_weights_mu;
+std::map<std::tuple<int, int, uint64_t>, std::weak_ptr<void>> g_weights;   // (device, kind, hash) -> device copy
+
+uint64_t fnv1a64(const float* p, size_t n) {
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(p);
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n * sizeof(float); ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+}
+}  // namespace
+
 static int upload(rfe_ctx* c, float** dst, const float* src, size_t n) {
     if (*dst) { RFE_HIP(c, hipFree(*dst)); *dst = nullptr; }
     RFE_HIP(c, hipMalloc((void**)dst, n * sizeof(float)));
@@ -180,7 +208,44 @@ static int upload(rfe_ctx* c, float** dst, const float* src, size_t n) {
     return RFE_OK;
 }
 
+static int set_sp_upload(rfe_ctx* c, const float* blob);
+static int set_lg_upload(rfe_ctx* c, const float* blob);
+
 static int set_sp(rfe_ctx* c, const float* blob) {
+    const auto key = std::make_tuple(c->device, (int)RFE_KIND_SUPERPOINT, fnv1a64(blob, (size_t)SP_COUNT) ^ (uint64_t)conv_ck());
+    std::lock_guard<std::mutex> lk(g_weights_mu);
+    if (auto it = g_weights.find(key); it != g_weights.end())
+        if (auto sp = it->second.lock()) {
+            c->sp_hold = sp; c->sp = static_cast<SpShared*>(sp.get())->w; c->has_sp = true;
+            return RFE_OK;
+        }
+    c->has_sp = false; c->sp_hold.reset(); c->sp = SpWeightsDev();
+    int rc = set_sp_upload(c, blob);
+    auto sp = std::make_shared<SpShared>();
+    sp->w = c->sp; sp->device = c->device;      // takes ownership of whatever was allocated, also after a partial failure
+    if (rc) { c->sp = SpWeightsDev(); return rc; }
+    c->sp_hold = sp; g_weights[key] = sp;
+    return RFE_OK;
+}
+
+static int set_lg(rfe_ctx* c, const float* blob) {
+    const auto key = std::make_tuple(c->device, (int)RFE_KIND_LIGHTGLUE, fnv1a64(blob, (size_t)LG_COUNT));
+    std::lock_guard<std::mutex> lk(g_weights_mu);
+    if (auto it = g_weights.find(key); it != g_weights.end())
+        if (auto lg = it->second.lock()) {
+            c->lg_hold = lg; c->lg = static_cast<LgShared*>(lg.get())->w; c->has_lg = true;
+            return RFE_OK;
+        }
+    c->has_lg = false; c->lg_hold.reset(); c->lg = LgWeightsDev();
+    int rc = set_lg_upload(c, blob);
+    auto lg = std::make_shared<LgShared>();
+    lg->w = c->lg; lg->device = c->device;
+    if (rc) { c->lg = LgWeightsDev(); return rc; }
+    c->lg_hold = lg; g_weights[key] = lg;
+    return RFE_OK;
+}
+
+static int set_sp_upload(rfe_ctx* c, const float* blob) {
     size_t off = 0;
     for (int l = 0; l < 12; ++l) {
         const SpLayer& L = kSpLayers[l];
@@ -206,7 +271,7 @@ static int set_sp(rfe_ctx* c, const float* blob) {
     return RFE_OK;
 }
 
-static int set_lg(rfe_ctx* c, const float* blob) {
+static int set_lg_upload(rfe_ctx* c, const float* blob) {
     int rc = upload(c, &c->lg.blob, blob, (size_t)LG_COUNT);
     if (rc) return rc;
     float* p = c->lg.blob;
@@ -288,6 +353,12 @@ extern "C" int rfe_set_weights(rfe_ctx* c, int kind, const float* blob, int64_t 
     if (count != rfe_weight_count(kind)) return fail(c, RFE_ERR_INVALID, "rfe_set_weights: wrong float count for this model kind");
     RFE_HIP(c, hipStreamSynchronize(c->stream));
     return kind == RFE_KIND_SUPERPOINT ? set_sp(c, blob) : set_lg(c, blob);
+}
+
+extern "C" uint64_t rfe_weights_id(rfe_ctx* c, int kind) {
+    if (!c) return 0;
+    const void* p = kind == RFE_KIND_SUPERPOINT ? c->sp_hold.get() : kind == RFE_KIND_LIGHTGLUE ? c->lg_hold.get() : nullptr;
+    return (uint64_t)(uintptr_t)p;
 }
 
 static int load_rfew(rfe_ctx* c, const char* path, int want_kind) {

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <memory>
 #include <string>
 #include <vector>
 #include "../../include/rover_fe.h"
@@ -81,8 +82,9 @@ struct rfe_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     bool has_sp = false, has_lg = false;
-    rfe::SpWeightsDev sp;
+    rfe::SpWeightsDev sp;                // views into *sp_hold / *lg_hold
     rfe::LgWeightsDev lg;
+    std::shared_ptr<void> sp_hold, lg_hold;   // device copies, shared by every ctx of the process that loaded the same blob on the same device
     // grow-only workspaces
     void* ws_sp = nullptr; size_t ws_sp_bytes = 0;
     void* ws_lg = nullptr; size_t ws_lg_bytes = 0;
@@ -121,6 +123,7 @@ int ensure_ws(rfe_ctx* c, void** p, size_t* cur, size_t need);
 // sp_conv.hip
 void pack_conv3x3_weights(const float* w_oihw, int cin, int cout, std::vector<float>& out);
 size_t packed_conv3x3_count(int cin, int cout);
+int conv_ck();   // input channels per LDS chunk the 3x3 weights are packed for (8; RFE_CONV_CK=16 for A/B)
 void launch_conv1a_u8(hipStream_t s, const uint8_t* img, int stride, int B, int H, int W,
                       const float* w9x64, const float* bias, float* out);
 void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin,

@@ -458,3 +458,26 @@ def test_stream_mode_repeatable_full_size(ctx):
     want = np.full(n[i], -1, np.int32); want[pairs[i, :S[i], 0]] = pairs[i, :S[i], 1]
     assert size == S[i] and np.array_equal(vn, want)
     dimg.free()
+
+
+def test_contexts_share_device_weights(oracle):
+    """SURVEY 8(b) threading row: several ctxs on one device share the read-only weights.  Same blob -> same device copy
+    (rfe_weights_id), other blob -> other copy; a copy outlives the ctx that uploaded it while someone still uses it."""
+    from rover_slam_amd import capi
+    w7, w9 = Wt.make_superpoint(seed=7), Wt.make_superpoint(seed=9)
+    a, b, c3 = capi.Context(0), capi.Context(0), capi.Context(0)
+    a.set_weights(capi.KIND_SUPERPOINT, w7); b.set_weights(capi.KIND_SUPERPOINT, w7.copy()); c3.set_weights(capi.KIND_SUPERPOINT, w9)
+    ida, idb, idc = (capi.lib.rfe_weights_id(x.h, capi.KIND_SUPERPOINT) for x in (a, b, c3))
+    assert ida != 0 and ida == idb and idc != ida
+    assert capi.lib.rfe_weights_id(a.h, capi.KIND_LIGHTGLUE) == 0
+    a.close()                                                   # b keeps the shared copy alive
+    img = synth.make_frames(1, 120, 160, seed=12)[0][0]
+    n, kxy, score, desc = b.extract(img, kmax=200)
+    r = oracle.superpoint(w7, img, kmax=200)
+    assert n[0] == r["n"] and np.array_equal(kxy[0], r["kxy"]) and np.array_equal(desc[0], r["desc"])
+    b.set_weights(capi.KIND_SUPERPOINT, w9)                     # switching blobs: now shares c3's copy
+    assert capi.lib.rfe_weights_id(b.h, capi.KIND_SUPERPOINT) == idc
+    n, kxy, score, desc = b.extract(img, kmax=200)
+    r = oracle.superpoint(w9, img, kmax=200)
+    assert n[0] == r["n"] and np.array_equal(kxy[0], r["kxy"]) and np.array_equal(desc[0], r["desc"])
+    b.close(); c3.close()
