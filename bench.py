@@ -91,6 +91,40 @@ def pmc_traffic(stage):
     return None, None
 
 
+def ort_reference_baseline(frames):
+    """if onnxruntime AND the reference's two model files are available (RFE_ONNX_DIR, default
+    /root/reference/onnxmodel is NOT consulted: nothing here may read the reference checkout), time the true reference
+    arithmetic on the CPU execution provider.  Neither exists in the build image, so this returns None there
+    (never exercised; kept so that a site which has both gets kind = "reference")."""
+    d = os.environ.get("RFE_ONNX_DIR")
+    if not d:
+        return None
+    sp_path, lg_path = os.path.join(d, "superpoint.onnx"), os.path.join(d, "lightglue_sim.onnx")
+    if not (os.path.exists(sp_path) and os.path.exists(lg_path)):
+        return None
+    try:
+        import onnxruntime as ort
+    except ImportError:
+        return None
+    so = ort.SessionOptions()
+    so.intra_op_num_threads = len(os.sched_getaffinity(0))
+    sp = ort.InferenceSession(sp_path, so, providers=["CPUExecutionProvider"])
+    lg = ort.InferenceSession(lg_path, so, providers=["CPUExecutionProvider"])
+    t0 = time.perf_counter()
+    prev, nf = None, 0
+    while nf < len(frames) and (nf < 4 or time.perf_counter() - t0 < 12.0):
+        k, sc, de = sp.run(["keypoints", "scores", "descriptors"], {"image": (frames[nf].astype(np.float32) / 255.0)[None, None]})
+        kn = ((k[0].astype(np.float32) - np.array([W / 2, H / 2], np.float32)) / (max(W, H) / 2)).astype(np.float32)
+        if prev is not None:
+            lg.run(["matches0", "mscores0"], {"kpts0": prev[0][None], "kpts1": kn[None], "desc0": prev[1][None], "desc1": de[0][None]})
+        prev = (kn, de[0])
+        nf += 1
+    dt = time.perf_counter() - t0
+    return {"value": round((nf - 1) / dt, 4), "unit": "frames/s", "cores": so.intra_op_num_threads, "kind": "reference",
+            "sample": f"{nf} frames + {nf - 1} pairs through onnxruntime {ort.__version__} CPUExecutionProvider with the reference's "
+                      f"superpoint.onnx / lightglue_sim.onnx from RFE_ONNX_DIR, {dt:.1f} s"}
+
+
 def cpu_baseline(frames, wsp, wlg, gpu=None):
     """The CPU oracle (a port, not the reference's ONNXRuntime path -- that cannot run here: no
     onnxruntime, no .onnx blobs) on a bounded sample of the bench frames (about 12 s of CPU work)."""
@@ -433,6 +467,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             gpu = {k: v.cpu().numpy() for k, v in (("n", n), ("kxy", kxy), ("score", score), ("desc", desc), ("S", S), ("pairs", pairs))}
             out["cpu_baseline"] = cpu_baseline(frames_np, wsp, wlg, gpu)
+            ref = ort_reference_baseline(frames_np)          # only where onnxruntime + the real blobs exist (not in this image)
+            if ref is not None:
+                out["cpu_baseline_port"] = out["cpu_baseline"]
+                out["cpu_baseline"] = ref
         print(json.dumps(out))
     ctx.close()
     if world > 1:
