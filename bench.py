@@ -259,6 +259,8 @@ def main():
                          "c5 = stereo 752x480 stream: per stereo frame 2 extractions + sparse stereo match + 1 LightGlue match "
                          "of the left image against the previous left image (latency)")
     ap.add_argument("--kmax", type=int, default=KMAX, help="keypoint capacity per frame (default 1024)")
+    ap.add_argument("--frames-per-gpu", type=int, default=FRAMES_PER_GPU,
+                    help="frames (= pairs) each GPU owns per step; 32 = BASELINE configs[3] (256 frames over 8 GPUs), other values are exploratory")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -289,6 +291,7 @@ def main():
     ctx.set_stream(stream.cuda_stream)
 
     KMAX = args.kmax
+    FRAMES_PER_GPU = args.frames_per_gpu
     if args.workload == "c5":
         bench_stereo_stream(args, ctx, capi, synth, torch, dev, rank)
         ctx.close()
@@ -446,9 +449,9 @@ def main():
             "metric": "frames/s SuperPoint+LightGlue 640x480", "value": round(value, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[3] per GPU: 33 synthetic 640x480 u8 frames resident in HBM, SuperPoint extract "
-                                   f"(Kmax={KMAX}, thr=0.0005) + LightGlue match of 32 consecutive pairs (9 layers, filter 0.1); "
-                                   "32 frames counted per GPU per step; seeded synthetic weights",
+            "config": {"workload": f"configs[3] per GPU: {FRAMES_PER_GPU + 1} synthetic 640x480 u8 frames resident in HBM, SuperPoint extract "
+                                   f"(Kmax={KMAX}, thr=0.0005) + LightGlue match of {FRAMES_PER_GPU} consecutive pairs (9 layers, filter 0.1); "
+                                   f"{FRAMES_PER_GPU} frames counted per GPU per step; seeded synthetic weights",
                        "frames_per_gpu": FRAMES_PER_GPU, "kmax": KMAX, "mean_keypoints": float(lens.mean()),
                        "sharding": f"frames sharded over {world} GPU(s), 1 overlap frame per rank"
                                    + ("; gather of counts/keypoints/matches to rank 0 over RCCL" if world > 1 else "")},
