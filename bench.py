@@ -5,16 +5,25 @@ Workload (BASELINE.json configs[3], per GPU): 33 device-resident u8 frames are e
 matched with frame i+1 (32 pairs) through rfe_extract_match_stream_dev; 32 frames are counted per
 GPU per step (the 33rd is the one-frame overlap that makes the ranks independent).
 Kmax = 1024, detection threshold 0.0005, match filter 0.1, seeded synthetic weights.
-Multi-GPU: one process per GPU (torch.distributed / RCCL), frames sharded, no data-path collective
-except the trivial gather of the compact results (counts, keypoints, matches) to rank 0.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
-timed with HIP events on the library's stream inside the timed region) and `cpu_baseline`
-(the CPU oracle, rank 0, N=1 only, bounded sample).
+Multi-GPU: one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI), frames sharded, no data-path
+collective except ONE gather per step of the compact results (counts, keypoints, matches) to rank 0.
+  * under torchrun (WORLD_SIZE set) this process is one rank;
+  * `python bench.py --gpus N` with N > 1 and no WORLD_SIZE spawns the N ranks itself -- as child processes, before
+    anything in this process touches the GPU -- and exits with their status;
+  * `--gpus` that disagrees with WORLD_SIZE, or more ranks than visible GPUs (nccl), is an error, never a silent
+    1-GPU number.
+`--scaling weak` (default): 32 frames per GPU per step.  `--scaling strong`: 256 frames per step in all, 256/N per GPU.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, timed with HIP events
+on the library's stream inside the timed region), `cpu_baseline` (the CPU oracle, rank 0, N=1 only, bounded sample),
+`sustained` (>= 200 further steps: per-step spread, clocks) and, for N > 1, `ranks` / `rccl` (what the process group saw).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,7 +34,8 @@ sys.path.insert(0, ROOT)
 
 H, W, KMAX = 480, 640, 1024
 FRAMES_PER_GPU = 32
-PEAK_F32_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
+STRONG_TOTAL_FRAMES = 256   # BASELINE configs[3]: 256 frames over the node
+PEAK_F32_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
 PEAK_HBM_GBS = 8000.0
 
 # SuperPoint 3x3 layers: (stage, Cin, Cout, downscale)
@@ -54,9 +64,9 @@ def stage_flops(name, B, lens, launches=None):
     if name == "lg_qkv":            # 9 launches: 8 on 2P sequences + 1 on B frames
         return 2.0 * 256 * 768 * (8 * rows + rows_f) / 9
     if name == "lg_proj":
-        if launches == 1:           # default: the attention out-projections are folded into ffn.0 at load time -> final_proj only
+        if launches == 1:           # RFE_OPT_LG_FOLD_WO: the attention out-projections are folded into ffn.0 -> final_proj only
             return 2.0 * 256 * 256 * rows
-        return 2.0 * 256 * 256 * (18 * rows + rows_f) / 19   # RFE_LG_NO_FOLD=1: 9 self (one on frames) + 9 cross + final_proj
+        return 2.0 * 256 * 256 * (18 * rows + rows_f) / 19   # 9 self (one on frames) + 9 cross + final_proj
     if name == "lg_ffn1":           # 18 launches, one on frames
         return 2.0 * 512 * 512 * (17 * rows + rows_f) / 18
     if name == "lg_ffn2":
@@ -73,29 +83,44 @@ def stage_flops(name, B, lens, launches=None):
     return None
 
 
-STAGE_KERNEL = {"lg_attention": "lg_attention_kernel", "conv1ab": "conv1ab_fused_kernel", "conv1b": "true, true, 1,",
-                "conv2a": "false, true, 2,", "conv2b": "true, true, 3,", "conv3a": "false, true, 4,", "conv3b": "true, true, 5,"}
+STAGE_KERNEL = {"lg_attention": "lg_attention_kernel", "conv1ab": "conv1ab_fused_kernel"}
 
 
 def pmc_traffic(stage):
     """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes of this same
-    bench command (profiles/r01_pmc_traffic.json, made by tools/profile_round.sh + tools/rocpd_pmc.py):
+    bench command (profiles/rNN_pmc_traffic.json, made by tools/profile_round.sh + tools/rocpd_pmc.py):
     (2*FETCH_SIZE + WRITE_SIZE)*1024 as the MI355X guide prescribes.  None when no PMC pass covers it."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     key = STAGE_KERNEL.get(stage)
-    if not key or not os.path.exists(path):
-        return None, None
-    for name, v in json.load(open(path))["kernels"].items():
-        if key in name:
-            return v["traffic_bytes"], "profiles/r01_pmc_traffic.json:" + name
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
+        if not key or not os.path.exists(path):
+            continue
+        for name, v in json.load(open(path))["kernels"].items():
+            if key in name:
+                return v["traffic_bytes"], f"profiles/{rnd}_pmc_traffic.json:" + name
     return None, None
 
 
+def gpu_clocks(dev_index):
+    """Current shader / memory clock from sysfs when the (unprivileged) process may read it; None otherwise."""
+    out = {}
+    try:
+        cards = sorted(d for d in os.listdir("/sys/class/drm") if d.startswith("card") and d[4:].isdigit())
+        card = cards[dev_index] if dev_index < len(cards) else cards[0]
+        for key, fn in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk")):
+            with open(f"/sys/class/drm/{card}/device/{fn}") as f:
+                for line in f:
+                    if "*" in line:
+                        out[key] = int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
+    except (OSError, ValueError, IndexError):
+        pass
+    return out or None
+
+
 def ort_reference_baseline(frames):
-    """if onnxruntime AND the reference's two model files are available (RFE_ONNX_DIR, default
-    /root/reference/onnxmodel is NOT consulted: nothing here may read the reference checkout), time the true reference
-    arithmetic on the CPU execution provider.  Neither exists in the build image, so this returns None there
-    (never exercised; kept so that a site which has both gets kind = "reference")."""
+    """if onnxruntime AND the reference's two model files are available (RFE_ONNX_DIR; the reference
+    checkout itself is never consulted), time the true reference arithmetic on the CPU execution provider.  Neither
+    exists in the build image, so this returns None there (kept so that a site which has both gets kind = "reference")."""
     d = os.environ.get("RFE_ONNX_DIR")
     if not d:
         return None
@@ -125,6 +150,36 @@ def ort_reference_baseline(frames):
                       f"superpoint.onnx / lightglue_sim.onnx from RFE_ONNX_DIR, {dt:.1f} s"}
 
 
+def torch_cpu_baseline(frames, wsp, wlg, budget_s=10.0):
+    """SURVEY 8(d) also asks for a torch-CPU leg: the same two networks as HuggingFace `transformers` modules (the
+    independent implementation behind tests/golden, tools/gen_golden.py) on torch-CPU / oneDNN with all usable cores.
+    A port like the oracle, only with a vendor-tuned convolution / GEMM back end -- closer to what ONNXRuntime-CPU does."""
+    try:
+        import torch
+        from oracle import oracle as O
+        from tools import gen_golden as G
+        sp = G.hf_superpoint(wsp, KMAX)
+        mods = G.hf_lightglue_modules(wlg)
+    except Exception as e:   # transformers missing / incompatible: report why instead of failing the bench
+        return {"value": None, "kind": "port", "error": f"{type(e).__name__}: {e}"[:200]}
+    nthr = O.usable_cpus()
+    torch.set_num_threads(nthr)
+    t0 = time.perf_counter()
+    prev, nf = None, 0
+    while nf < len(frames) and (nf < 3 or time.perf_counter() - t0 < budget_s):
+        r = G.run_hf_superpoint(sp, frames[nf])
+        kn = ((r["kxy"].astype(np.float32) - np.array([W / 2, H / 2], np.float32)) / (max(W, H) / 2)).astype(np.float32)
+        if prev is not None:
+            m = min(len(kn), len(prev[0]))     # the HF layer stack is driven without masks: equal lengths
+            G.run_hf_lightglue(mods, prev[0][:m], kn[:m], prev[1][:m], r["desc"][:m])
+        prev = (kn, r["desc"])
+        nf += 1
+    dt = time.perf_counter() - t0
+    return {"value": round((nf - 1) / dt, 4), "unit": "frames/s", "cores": nthr, "kind": "port",
+            "sample": f"{nf} frames + {nf - 1} pairs through HuggingFace transformers SuperPoint / LightGlue modules on torch-CPU "
+                      f"({torch.__version__}, {nthr} threads), same synthetic weights and frames, {dt:.1f} s"}
+
+
 def cpu_baseline(frames, wsp, wlg, gpu=None):
     """The CPU oracle (a port, not the reference's ONNXRuntime path -- that cannot run here: no
     onnxruntime, no .onnx blobs) on a bounded sample of the bench frames (about 12 s of CPU work)."""
@@ -134,6 +189,16 @@ def cpu_baseline(frames, wsp, wlg, gpu=None):
     t0 = time.perf_counter()
     prev, nf = None, 0
     sp_ok, lg_ok = True, True
+    ms_dev = 0.0
+
+    def check_pair(idx, lg):
+        nonlocal lg_ok, ms_dev
+        Sg = int(gpu["S"][idx])
+        same = bool(Sg == lg["S"] and np.array_equal(gpu["pairs"][idx, :Sg], lg["pairs"]))
+        lg_ok &= same
+        if same and Sg:
+            ms_dev = max(ms_dev, float(np.abs(gpu["ms"][idx, :Sg] - lg["ms"]).max()))
+
     while nf < len(frames) and (nf < 4 or time.perf_counter() - t0 < 12.0):
         cur = O.superpoint(wsp, frames[nf], kmax=KMAX)
         lg = None
@@ -144,8 +209,7 @@ def cpu_baseline(frames, wsp, wlg, gpu=None):
             sp_ok &= bool(gpu["n"][nf] == cur["n"] and np.array_equal(gpu["kxy"][nf], cur["kxy"]) and np.array_equal(gpu["score"][nf], cur["score"])
                           and np.array_equal(gpu["desc"][nf], cur["desc"]))
             if lg is not None:
-                Sg = int(gpu["S"][nf - 1])
-                lg_ok &= bool(Sg == lg["S"] and np.array_equal(gpu["pairs"][nf - 1, :Sg], lg["pairs"]))
+                check_pair(nf - 1, lg)
         prev = cur
         nf += 1
     dt = time.perf_counter() - t0
@@ -157,10 +221,10 @@ def cpu_baseline(frames, wsp, wlg, gpu=None):
             lg = O.lightglue(wlg, O.normalize_keypoints(a["kxy"][:a["n"]].astype(np.float32), H, W),
                              O.normalize_keypoints(b["kxy"][:b["n"]].astype(np.float32), H, W), a["desc"][:a["n"]], b["desc"][:b["n"]])
             sp_ok &= bool(np.array_equal(gpu["kxy"][-1], b["kxy"]) and np.array_equal(gpu["desc"][-1], b["desc"]))
-            Sg = int(gpu["S"][-1])
-            lg_ok &= bool(Sg == lg["S"] and np.array_equal(gpu["pairs"][-1, :Sg], lg["pairs"]))
+            check_pair(len(gpu["S"]) - 1, lg)
             extra = 1
-        verified = {"frames": nf + 2 * extra, "pairs": nf - 1 + extra, "superpoint_bit_exact": sp_ok, "match_lists_identical": lg_ok}
+        verified = {"frames": nf + 2 * extra, "pairs": nf - 1 + extra, "superpoint_bit_exact": sp_ok, "match_lists_identical": lg_ok,
+                    "match_score_max_dev": ms_dev, "match_score_tolerance": 1e-4, "lg_fold_wo": gpu.get("fold")}
         if not (sp_ok and lg_ok):
             print(f"bench.py: GPU results of the timed loop differ from the oracle: {verified}", file=sys.stderr)
     return {"value": round((nf - 1) / dt, 4), "unit": "frames/s", "cores": O.threads(), "kind": "port", "verified_against_gpu": verified,
@@ -170,10 +234,10 @@ def cpu_baseline(frames, wsp, wlg, gpu=None):
 
 
 def bench_stereo_stream(args, ctx, capi, synth, torch, dev, rank):
-    """BASELINE configs[4]: a 752x480 stereo stream.  Per stereo frame, all on the device: both views through
-    SuperPoint in one batch of 2 (src/Frame.cc:142-147), Frame::ComputeStereoMatches (src/Frame.cc:1159-1446) and one
-    LightGlue match of the left view against the previous left view (SPmatcher.cc:1050-1080).  Only the two keypoint
-    counts cross PCIe (the caller needs them to size its vectors).  Latency figure, not the metric's workload."""
+    """BASELINE configs[4]: a 752x480 stereo stream through ONE device-resident entry point per stereo frame,
+    rfe_stereo_frame_dev: both views through SuperPoint as a batch of 2 (src/Frame.cc:142-147), Frame::ComputeStereoMatches
+    (src/Frame.cc:1159-1446) and one LightGlue match of the left view against the previous left view
+    (SPmatcher.cc:1050-1080).  Nothing crosses PCIe inside the loop.  Latency figure, not the metric's workload."""
     Hs, Ws, K = 480, 752, args.kmax
     T = 8                                                     # distinct stereo frames, cycled
     rng = np.random.default_rng(5)
@@ -185,38 +249,11 @@ def bench_stereo_stream(args, ctx, capi, synth, torch, dev, rank):
         lefts.append(np.clip(scene[:, x0:x0 + Ws] + rng.integers(0, 8, (Hs, Ws)), 0, 255).astype(np.uint8))
         rights.append(np.clip(scene[:, x0 + disp:x0 + disp + Ws] + rng.integers(0, 8, (Hs, Ws)), 0, 255).astype(np.uint8))
     imgs = torch.from_numpy(np.stack([np.stack([l, r]) for l, r in zip(lefts, rights)])).to(dev)      # [T,2,H,W]
-    n = torch.zeros(2, dtype=torch.int32, device=dev)
-    kxy = torch.zeros(2, K, 2, dtype=torch.int32, device=dev)
-    score = torch.zeros(2, K, dtype=torch.float32, device=dev)
-    desc = torch.zeros(2, K, 256, dtype=torch.float32, device=dev)
-    prev_kn = torch.zeros(K, 2, dtype=torch.float32, device=dev)
-    prev_desc = torch.zeros(K, 256, dtype=torch.float32, device=dev)
-    prev_n = torch.zeros(1, dtype=torch.int32, device=dev)
-    S = torch.zeros(1, dtype=torch.int32, device=dev)
-    pairs = torch.zeros(K, 2, dtype=torch.int32, device=dev)
-    ms = torch.zeros(K, dtype=torch.float32, device=dev)
-    u_right = torch.zeros(K, dtype=torch.float32, device=dev)
-    depth = torch.zeros(K, dtype=torch.float32, device=dev)
-    centre = torch.tensor([Ws / 2.0, Hs / 2.0], dtype=torch.float32, device=dev)
-    mb, mbf = 0.11, 0.11 * 435.0
-    stats = {"stereo": 0, "matches": 0, "kp": 0}
+    st = capi.StereoStream(ctx, Hs, Ws, K, mb=0.11, mbf=0.11 * 435.0)
 
     def step(t):
         im = imgs[t % T]
-        ctx._chk(capi.lib.rfe_extract_u8_dev(ctx.h, im.data_ptr(), Hs, Ws, Ws, 2, K, 0.0005, n.data_ptr(), kxy.data_ptr(),
-                                             score.data_ptr(), desc.data_ptr()))
-        nl, nr = n.tolist()                                   # the only D2H on the path (8 bytes)
-        kf = kxy.to(torch.float32)
-        ctx._chk(capi.lib.rfe_stereo_match_dev(ctx.h, im[0].data_ptr(), im[1].data_ptr(), Hs, Ws, Ws, kf[0].data_ptr(), nl,
-                                               kf[1].data_ptr(), nr, desc[0].data_ptr(), desc[1].data_ptr(), mb, mbf,
-                                               u_right.data_ptr(), depth.data_ptr()))
-        kn = ((kf[0] - centre) / (max(Ws, Hs) / 2.0)).contiguous()       # NormalizeKeypoints, transform.cpp:19-32
-        if t > 0:
-            ctx._chk(capi.lib.rfe_match_dev(ctx.h, prev_kn.data_ptr(), kn.data_ptr(), prev_desc.data_ptr(), desc[0].data_ptr(),
-                                            prev_n.data_ptr(), n.data_ptr(), 1, K, K, 0.1, S.data_ptr(), pairs.data_ptr(),
-                                            ms.data_ptr()))
-        prev_kn.copy_(kn); prev_desc.copy_(desc[0]); prev_n.copy_(n[:1])
-        stats["kp"] = nl
+        st.push(im[0].data_ptr(), im[1].data_ptr(), Ws)
 
     for t in range(args.warmup + 1):
         step(t)
@@ -226,22 +263,111 @@ def bench_stereo_stream(args, ctx, capi, synth, torch, dev, rank):
     for t in range(args.steps):
         step(args.warmup + 1 + t)
     torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
+    dt_prof = time.perf_counter() - t0
     prof = ctx.profile_read(); ctx.profile(False)
-    dt_prof = dt
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()                                   # headline: the same loop without the per-stage events
     for t in range(args.steps):
         step(args.warmup + 1 + args.steps + t)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    res = st.results()
     if rank == 0:
         print(json.dumps({"metric": "BASELINE configs[4] stereo 752x480 stream, latency run", "value": round(args.steps / dt, 2),
                           "unit": "stereo frames/s", "ms_per_step": round(dt / args.steps * 1e3, 4), "n_gpus": 1,
-                          "steps": args.steps, "warmup": args.warmup, "kmax": K, "left_keypoints": stats["kp"],
-                          "stereo_matches": int((u_right[:stats["kp"]] >= 0).sum().item()), "temporal_matches": int(S.item()),
+                          "steps": args.steps, "warmup": args.warmup, "kmax": K, "left_keypoints": int(res["n"][0]),
+                          "stereo_matches": int((res["u_right"][:int(res["n"][0])] >= 0).sum()), "temporal_matches": int(res["S"]),
+                          "entry_point": "rfe_stereo_frame_dev (no host synchronisation inside the loop)",
                           "ms_per_step_with_stage_events": round(dt_prof / args.steps * 1e3, 4),
                           "stages_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}))
+    st.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# multi-rank plumbing
+# ------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(args, argv):
+    """`bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (never exec: a process that has
+    initialised the GPU must not be replaced, and this one initialises nothing -- torch.cuda.device_count() does not on
+    ROCm) and exit with their status.  Rank 0's JSON line goes straight to our stdout."""
+    backend = os.environ.get("RFE_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and not args.check_launch:
+        import torch
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) are visible; refusing to report a {args.gpus}-GPU number "
+                  "(RFE_BENCH_BACKEND=gloo runs the N-rank flow on fewer GPUs as a functional check)", file=sys.stderr)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), RFE_BENCH_LAUNCHER="bench.py --gpus (child processes)")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    deadline = None
+    while any(p.poll() is None for p in procs):
+        for p in procs:
+            if p.poll() is not None and p.returncode != 0 and deadline is None:
+                rc = p.returncode
+                deadline = time.time() + 20.0          # a rank died: give the others a moment, then stop them
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                            # exact PIDs we started
+        time.sleep(0.05)
+    for p in procs:
+        rc = rc or p.returncode
+    return rc
+
+
+def rank_identity(torch, dev, dev_index):
+    info = {"rank": int(os.environ.get("RANK", "0")), "pid": os.getpid(), "host": socket.gethostname(), "device_index": dev_index}
+    if dev.type == "cuda":
+        p = torch.cuda.get_device_properties(dev)
+        info.update(name=p.name, arch=getattr(p, "gcnArchName", None), total_memory_gb=round(p.total_memory / 2 ** 30, 1))
+        for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"):
+            if hasattr(p, k):
+                info[k] = int(getattr(p, k))
+        if hasattr(p, "uuid"):
+            info["uuid"] = str(p.uuid)
+    return info
+
+
+def check_launch(args, rank, world):
+    """--check-launch: the N-rank flow without a GPU -- process group, rank census, the ONE-gather result path on CPU
+    tensors.  Lets the launcher and the collective plumbing be tested on a box with no (or one) GPU."""
+    import torch
+    import torch.distributed as dist
+    from rover_slam_amd import sharding
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    shard = sharding.shard_frames(4, world, rank) if args.scaling == "weak" else sharding.shard_frames_strong(8 * world, world, rank)
+    pack = sharding.ResultPack(shard.frames, 8, torch.device("cpu"))
+    pack.n.copy_(torch.arange(shard.start, shard.start + shard.frames, dtype=torch.int32))
+    g = sharding.RootGather(pack, world, rank)
+    g()
+    ident = [None] * world
+    me = rank_identity(torch, torch.device("cpu"), -1)
+    if world > 1:
+        dist.all_gather_object(ident, me)
+        ones = torch.ones(1)
+        dist.all_reduce(ones)
+    else:
+        ident, ones = [me], torch.ones(1)
+    if rank == 0:
+        n_all = sharding.assemble(g, shard.owned)[0]
+        print(json.dumps({"check_launch": True, "n_gpus": world, "ranks": world, "scaling": args.scaling,
+                          "launcher": os.environ.get("RFE_BENCH_LAUNCHER", "external (torchrun / environment)"),
+                          "rccl": {"backend": "gloo", "world_size": world, "allreduce_sum_of_ones": int(ones.item()), "devices": ident},
+                          "gathered_frame_ids": n_all.tolist(), "payload_bytes_per_rank": g.nbytes}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
 
 def main():
@@ -250,9 +376,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): 32 frames per GPU per step; strong: 256 frames per step in all, 256/N per GPU")
+    ap.add_argument("--sustained-steps", type=int, default=200,
+                    help="further steps after the timed region for the `sustained` object (per-step spread, clocks); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the short PCIe-inclusive measurement (N=1)")
-    ap.add_argument("--gather-desc", action="store_true", help="also gather the 256-d descriptors to rank 0")
+    ap.add_argument("--gather-desc", action="store_true", help="also gather scores and the 256-d descriptors to rank 0")
+    ap.add_argument("--lg-fold", type=int, default=None, choices=[0, 1], help="override RFE_OPT_LG_FOLD_WO (default: the library's)")
+    ap.add_argument("--check-launch", action="store_true", help="N-rank flow only (gloo, CPU tensors, no GPU): launcher / collective self-test")
     ap.add_argument("--workload", default="c4", choices=["c2", "c3", "c4", "c5"],
                     help="BASELINE.json configs: c4 (default, the metric's workload) = 33 frames + 32 pairs per GPU; "
                          "c2 = SuperPoint only, batch 1 (latency); c3 = one 640x480 pair, SuperPoint x2 + LightGlue (latency); "
@@ -263,29 +395,53 @@ def main():
                     help="frames (= pairs) each GPU owns per step; 32 = BASELINE configs[3] (256 frames over 8 GPUs), other values are exploratory")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} disagrees with WORLD_SIZE={world}; refusing to report a mislabelled number", file=sys.stderr)
+        sys.exit(2)
+    if args.check_launch:
+        sys.exit(check_launch(args, rank, world))
 
     import torch
     import torch.distributed as dist
     ndev = torch.cuda.device_count()
     backend = os.environ.get("RFE_BENCH_BACKEND", "nccl")   # "gloo": functional check of the N>1 flow on a 1-GPU box
+    if backend == "nccl" and world > ndev:
+        print(f"bench.py: {world} ranks but {ndev} visible GPU(s)", file=sys.stderr)
+        sys.exit(2)
     dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    rccl = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        # what the process group really is: backend, size, one identity record per rank, and a collective on device
+        # memory that only comes out right if all `world` ranks took part
+        ident = [None] * world
+        dist.all_gather_object(ident, rank_identity(torch, dev, dev_index))
+        ones = torch.ones(1, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        rccl = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "allreduce_sum_of_ones": int(ones.item()),
+                "devices": ident, "distinct_devices": len({(d.get("pci_bus_id"), d.get("uuid"), d["device_index"]) for d in ident})}
+        if rccl["allreduce_sum_of_ones"] != world:
+            print(f"bench.py: all-reduce over the process group saw {rccl['allreduce_sum_of_ones']} ranks, expected {world}", file=sys.stderr)
+            sys.exit(3)
 
     from rover_slam_amd import capi, weights as Wt, synth, sharding
     ctx = capi.Context(dev_index)
     wsp, wlg = Wt.make_superpoint(seed=7), Wt.make_lightglue(seed=11)
     ctx.set_weights(capi.KIND_SUPERPOINT, wsp)
     ctx.set_weights(capi.KIND_LIGHTGLUE, wlg)
+    if args.lg_fold is not None:
+        ctx.set_option(capi.OPT_LG_FOLD_WO, args.lg_fold)
     stream = torch.cuda.Stream(dev)          # library kernels and the RCCL gather share this stream
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
@@ -298,19 +454,18 @@ def main():
         return
     if args.workload != "c4":
         FRAMES_PER_GPU = 1                      # latency configurations: batch 1
-    shard = sharding.shard_frames(FRAMES_PER_GPU, world, rank)
+    if args.scaling == "strong" and args.workload == "c4":
+        shard = sharding.shard_frames_strong(STRONG_TOTAL_FRAMES, world, rank)
+        FRAMES_PER_GPU = shard.owned
+    else:
+        shard = sharding.shard_frames(FRAMES_PER_GPU, world, rank)
     B = shard.frames if args.workload != "c2" else 1
     # each rank owns frames [32r, 32r+32]: one frame of overlap, no inter-GPU dependency
     frames_np, _ = synth.make_frames(B, H, W, seed=20240314 + 1000 * rank)
     frames = torch.from_numpy(frames_np).to(dev)
-    n = torch.zeros(B, dtype=torch.int32, device=dev)
-    kxy = torch.zeros(B, KMAX, 2, dtype=torch.int32, device=dev)
-    score = torch.zeros(B, KMAX, dtype=torch.float32, device=dev)
-    desc = torch.zeros(B, KMAX, 256, dtype=torch.float32, device=dev)
-    S = torch.zeros(max(B - 1, 1), dtype=torch.int32, device=dev)
-    pairs = torch.zeros(max(B - 1, 1), KMAX, 2, dtype=torch.int32, device=dev)
-    ms = torch.zeros(max(B - 1, 1), KMAX, dtype=torch.float32, device=dev)
-    send = [n, kxy, S, pairs] + ([desc] if args.gather_desc else [])
+    pack = sharding.ResultPack(B, KMAX, dev)    # every output of the step in one contiguous buffer; the gather moves its prefix
+    n, kxy, score, desc, S, pairs, ms = pack.n, pack.kxy, pack.score, pack.desc, pack.S, pack.pairs, pack.ms
+    gather = sharding.RootGather(pack, world, rank, with_desc=args.gather_desc) if world > 1 else None
 
     def step():
         if args.workload == "c2":
@@ -320,8 +475,8 @@ def main():
         ctx._chk(capi.lib.rfe_extract_match_stream_dev(
             ctx.h, frames.data_ptr(), H, W, W, B, KMAX, 0.0005, 0.1, n.data_ptr(), kxy.data_ptr(), score.data_ptr(),
             desc.data_ptr(), S.data_ptr(), pairs.data_ptr(), ms.data_ptr()))
-        if world > 1:   # the trivial gather over RCCL/xGMI (compact results only unless --gather-desc)
-            sharding.gather_to_root(send, world, rank)
+        if gather is not None:   # the trivial gather over RCCL/xGMI: ONE collective, preallocated receive buffer on rank 0
+            gather()
 
     def fence():
         if world > 1:
@@ -362,12 +517,14 @@ def main():
         ctx.profile(False)
         ctx.profile_filter(None)
     prof = prof_full
+    per_rank_ms = [dt / max(args.steps, 1) * 1e3]
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        tall = torch.zeros(world, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        tall[rank] = dt
+        dist.all_reduce(tall)                      # every rank's own clock around the same barrier-bracketed region
+        per_rank_ms = [float(v) / args.steps * 1e3 for v in tall.tolist()]
+        dt = float(tall.max().item())              # MAX over ranks
 
-    pcie = None
     if args.workload != "c4":      # latency configurations: a short line, no roofline object (not the metric's workload)
         # the per-stage HIP events cost a few microseconds each, which shows at these step times: the headline of a
         # latency run is a second timed loop without them, the stage table comes from the profiled loop above
@@ -387,6 +544,38 @@ def main():
                               "stages_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}))
         ctx.close()
         return
+
+    # ---- sustained: SURVEY 8(d) asks for >= 200 timed iterations.  The headline keeps the driver's --steps; this loop
+    # runs the same step (gather included) `--sustained-steps` more times with one event per step on the stream (no host
+    # synchronisation inside the loop) and reports the spread and the clocks the chip settled at.
+    sustained = None
+    if args.sustained_steps > 0:
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.sustained_steps + 1)]
+        fence()
+        clk0 = gpu_clocks(dev_index)
+        t0 = time.perf_counter()
+        evs[0].record(stream)
+        for i in range(args.sustained_steps):
+            step()
+            evs[i + 1].record(stream)
+        clk_mid = gpu_clocks(dev_index)             # read while the queue is still draining
+        fence()
+        wall = time.perf_counter() - t0
+        per = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(args.sustained_steps)], np.float64)
+        wmax = wall
+        if world > 1:
+            tw = torch.tensor([wall], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+            wmax = float(tw.item())
+        sustained = {"steps": args.sustained_steps, "seconds": round(wmax, 3),
+                     "value": round(FRAMES_PER_GPU * world * args.sustained_steps / wmax, 2), "unit": "frames/s",
+                     "ms_per_step": {"mean": round(float(per.mean()), 4), "std": round(float(per.std()), 4), "min": round(float(per.min()), 4),
+                                     "max": round(float(per.max()), 4), "p50": round(float(np.median(per)), 4),
+                                     "first_10_mean": round(float(per[:10].mean()), 4), "last_10_mean": round(float(per[-10:].mean()), 4)},
+                     "clocks_before": clk0, "clocks_under_load": clk_mid,
+                     "note": "rank 0's per-step HIP-event intervals on the library's stream; value = all ranks' frames / max-over-ranks wall time"}
+
+    pcie = None
     if world == 1 and not args.no_pcie:
         # PCIe-inclusive variant (never the headline `value`): frames start in pinned host memory, results end there.
         # Double buffered: a copy stream uploads batch k+1 and downloads the results of batch k-1 while batch k computes.
@@ -430,6 +619,11 @@ def main():
                     raise RuntimeError(f"PCIe pipeline: {nm} of buffer set {si} differs from the resident path "
                                        f"({int((h_ != t_.cpu()).sum())} elements)")
 
+    gathered_ok = None
+    if world > 1 and rank == 0:   # the gathered payload of the last step really holds every rank's results
+        gn = sharding.assemble(gather, shard.owned)[0]
+        gathered_ok = bool(gn.numel() == world * shard.owned + 1 and torch.equal(gather.rank_view(0, "n").cpu(), n.cpu()) and int((gn > 0).sum()) == gn.numel())
+
     if rank == 0:
         lens = n.cpu().numpy()
         total_frames = FRAMES_PER_GPU * world * args.steps
@@ -445,16 +639,21 @@ def main():
             f = stage_flops(k, B, lens, calls // full_steps)
             stages[k] = {"ms_per_step": round(msv / full_steps, 4), "launches_per_step": calls // full_steps,
                          "tflops": round(f / (msv / calls * 1e-3) / 1e12, 2) if f else None}
+        fold = ctx.get_option(capi.OPT_LG_FOLD_WO)
         out = {
             "metric": "frames/s SuperPoint+LightGlue 640x480", "value": round(value, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"configs[3] per GPU: {FRAMES_PER_GPU + 1} synthetic 640x480 u8 frames resident in HBM, SuperPoint extract "
                                    f"(Kmax={KMAX}, thr=0.0005) + LightGlue match of {FRAMES_PER_GPU} consecutive pairs (9 layers, filter 0.1); "
-                                   f"{FRAMES_PER_GPU} frames counted per GPU per step; seeded synthetic weights",
-                       "frames_per_gpu": FRAMES_PER_GPU, "kmax": KMAX, "mean_keypoints": float(lens.mean()),
+                                   f"{FRAMES_PER_GPU} frames counted per GPU per step; seeded synthetic weights; the same resident frames every step "
+                                   "(compute-bound path, no data-dependent control flow besides the keypoint counts)",
+                       "frames_per_gpu": FRAMES_PER_GPU, "kmax": KMAX, "mean_keypoints": float(lens.mean()), "lg_fold_wo": fold,
                        "sharding": f"frames sharded over {world} GPU(s), 1 overlap frame per rank"
-                                   + ("; gather of counts/keypoints/matches to rank 0 over RCCL" if world > 1 else "")},
+                                   + ("; ONE gather per step of counts/keypoints/matches to rank 0 over RCCL" if world > 1 else "")},
+            "ranks": world,
+            "launcher": os.environ.get("RFE_BENCH_LAUNCHER", "external (torchrun / environment)" if world > 1 else "single process"),
+            "per_rank_ms_per_step": {"min": round(min(per_rank_ms), 3), "max": round(max(per_rank_ms), 3), "all": [round(v, 3) for v in per_rank_ms]},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2) if achieved else None,
                          "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_TFLOPS, 4) if achieved else None,
                          "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 PMC, separate pass)",
@@ -464,12 +663,20 @@ def main():
             "stages_note": f"separate untimed pass of {full_steps} steps with events around every stage (costs ~2 %); the timed "
                            "region instruments the dominant kernel only",
         }
+        if rccl is not None:
+            out["rccl"] = rccl
+            out["gather"] = {"collectives_per_step": 1, "payload_bytes_per_rank": gather.nbytes, "with_descriptors": bool(args.gather_desc),
+                             "receive_buffer": "preallocated once on rank 0", "last_step_payload_verified": gathered_ok}
+        if sustained is not None:
+            out["sustained"] = sustained
         if pcie is not None:
             out["pcie_inclusive"] = {"value": round(pcie, 2), "unit": "frames/s",
                                      "note": "same step with H2D of the 33 u8 frames and D2H of all results (descriptors included) per step, pinned host memory, double buffered on a copy stream; not the headline value"}
         if world == 1 and not args.no_cpu_baseline:
-            gpu = {k: v.cpu().numpy() for k, v in (("n", n), ("kxy", kxy), ("score", score), ("desc", desc), ("S", S), ("pairs", pairs))}
+            gpu = {k: v.cpu().numpy() for k, v in (("n", n), ("kxy", kxy), ("score", score), ("desc", desc), ("S", S), ("pairs", pairs), ("ms", ms))}
+            gpu["fold"] = fold
             out["cpu_baseline"] = cpu_baseline(frames_np, wsp, wlg, gpu)
+            out["cpu_baseline_torch"] = torch_cpu_baseline(frames_np, wsp, wlg)
             ref = ort_reference_baseline(frames_np)          # only where onnxruntime + the real blobs exist (not in this image)
             if ref is not None:
                 out["cpu_baseline_port"] = out["cpu_baseline"]
@@ -477,6 +684,7 @@ def main():
         print(json.dumps(out))
     ctx.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -7,13 +7,15 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librover_fe.so")
+# RFE_LIBRARY selects another build of the same ABI (tools/ use the -DRFE_TUNING build for A/B measurements)
+LIB_PATH = os.environ.get("RFE_LIBRARY") or os.path.join(_HERE, "librover_fe.so")
 
 KIND_SUPERPOINT, KIND_LIGHTGLUE = 1, 2
+OPT_LG_FOLD_WO = 1
 
 EXPORTS = [
     "rfe_init", "rfe_destroy", "rfe_last_error", "rfe_version", "rfe_load_weights", "rfe_set_weights",
-    "rfe_weight_count", "rfe_weights_id", "rfe_set_stream", "rfe_synchronize", "rfe_malloc", "rfe_free", "rfe_memcpy_h2d",
+    "rfe_weight_count", "rfe_weights_id", "rfe_set_option", "rfe_get_option", "rfe_set_stream", "rfe_synchronize", "rfe_malloc", "rfe_free", "rfe_memcpy_h2d",
     "rfe_memcpy_d2h", "rfe_extract_u8", "rfe_extract_u8_dev", "rfe_match", "rfe_match_dev", "rfe_match_fused",
     "rfe_extract_match_stream_dev", "rfe_stereo_match", "rfe_stereo_match_dev", "rfe_l2_distance_matrix", "rfe_binarize_descriptors",
     "rfe_search_candidates", "rfe_distinctive_descriptors",
@@ -40,6 +42,8 @@ lib.rfe_weight_count.argtypes = [C.c_int]
 lib.rfe_weight_count.restype = C.c_int64
 lib.rfe_weights_id.restype = C.c_uint64
 lib.rfe_weights_id.argtypes = [C.c_void_p, C.c_int]
+lib.rfe_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
+lib.rfe_get_option.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
 lib.rfe_set_stream.argtypes = [C.c_void_p, C.c_void_p]
 lib.rfe_synchronize.argtypes = [C.c_void_p]
 lib.rfe_malloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
@@ -151,6 +155,14 @@ class Context:
 
     def load_weights(self, sp_path=None, lg_path=None):
         self._chk(lib.rfe_load_weights(self.h, sp_path.encode() if sp_path else None, lg_path.encode() if lg_path else None))
+
+    def set_option(self, option, value):
+        self._chk(lib.rfe_set_option(self.h, option, int(value)))
+
+    def get_option(self, option):
+        v = C.c_int()
+        self._chk(lib.rfe_get_option(self.h, option, C.byref(v)))
+        return v.value
 
     def set_stream(self, stream_ptr):
         self._chk(lib.rfe_set_stream(self.h, stream_ptr))

@@ -232,12 +232,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 }
 
 void launch_gemm_nt(hipStream_t s, const GemmArgs& g_in) {
-    static const int rend_on = getenv("RFE_GEMM_REND") ? atoi(getenv("RFE_GEMM_REND")) : 1;   // A/B switch, see profiles/r01_pmc.md
+    static const int rend_on = tune_int("RFE_GEMM_REND", 1);   // A/B switch, see profiles/r01_pmc.md
     GemmArgs g = g_in;
     g.rend = rend_on;
     const int batch = g.batch > 0 ? g.batch : 1;
     auto tiles = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * batch; };
-    static const bool force_tepi = getenv("RFE_GEMM_TEPI") != nullptr;   // tuning switch
+    static const bool force_tepi = tune_env("RFE_GEMM_TEPI") != nullptr;   // tuning switch
     const bool tepi = force_tepi || g.R != nullptr || g.rope_cs != nullptr;
 #define RFE_GEMM_GO(MB_, NB_, GRID)                                                                  \
     do {                                                                                             \

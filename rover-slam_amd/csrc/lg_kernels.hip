@@ -393,7 +393,7 @@ void launch_lg_attention(hipStream_t s, const float* q, const float* k, const fl
     // (2P sequences always are; the per-frame self block of the stream mode runs on B sequences, e.g. 33)
     const int units8 = (4 * nseq + 7) / 8 * 8;
     // latency regime: fewer (sequence, head, query block) units than CUs -> split the keys until the chip is covered
-    static const int split_env = getenv("RFE_ATT_SPLIT") ? atoi(getenv("RFE_ATT_SPLIT")) : -1;   // 0/1 = off, n = force n ranges
+    static const int split_env = tune_int("RFE_ATT_SPLIT", -1);   // 0/1 = off, n = force n ranges
     if (part && (size_t)nseq * Lq <= AT_SPLIT_MAX_ROWS && split_env != 0 && split_env != 1) {
         const int units = nqb * 4 * nseq;
         int ns = 1;
@@ -407,18 +407,18 @@ void launch_lg_attention(hipStream_t s, const float* q, const float* k, const fl
             return;
         }
     }
-    static const bool single = getenv("RFE_ATT_DBUF") == nullptr;   // tuning switch: RFE_ATT_DBUF=1 selects the double-buffered variant
-    static const bool q64 = getenv("RFE_ATT_Q64") != nullptr;        // tuning switch: 64 queries per wave
+    static const bool single = tune_env("RFE_ATT_DBUF") == nullptr;   // tuning switch: RFE_ATT_DBUF=1 selects the double-buffered variant
+    static const bool q64 = tune_env("RFE_ATT_Q64") != nullptr;        // tuning switch: 64 queries per wave
     if (q64 && Lq >= 512) {
         const int nqb2 = (Lq + 255) / 256;
         hipLaunchKernelGGL(lg_attention_q64_kernel, dim3(nqb2 * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb2, qlen, klen, kv_map, nseq);
         return;
     }
-    static const int abl = getenv("RFE_DBG_ATT_ABL") ? atoi(getenv("RFE_DBG_ATT_ABL")) : 0;   // timing ablations (wrong results)
+    static const int abl = tune_int("RFE_DBG_ATT_ABL", 0);   // timing ablations (wrong results)
     if (abl == 1) { hipLaunchKernelGGL((lg_attention_kernel<false, 1>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0, nullptr, nseq); return; }
     if (abl == 2) { hipLaunchKernelGGL((lg_attention_kernel<false, 2>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0, nullptr, nseq); return; }
     if (abl == 3) { hipLaunchKernelGGL((lg_attention_kernel<false, 3>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0, nullptr, nseq); return; }
-    static const int prio = getenv("RFE_ATT_PRIO") ? atoi(getenv("RFE_ATT_PRIO")) : 1;   // s_setprio(1) around the MFMA clusters (+0.8 %); RFE_ATT_PRIO=0 disables
+    static const int prio = tune_int("RFE_ATT_PRIO", 1);   // s_setprio(1) around the MFMA clusters (+0.8 %); RFE_ATT_PRIO=0 disables
     if (single)
         hipLaunchKernelGGL(lg_attention_kernel<false>, dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nullptr, nseq);
     else

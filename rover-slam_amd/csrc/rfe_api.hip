@@ -126,6 +126,21 @@ extern "C" void rfe_destroy(rfe_ctx* c) {
     delete c;
 }
 
+extern "C" int rfe_set_option(rfe_ctx* c, int option, int value) {
+    if (!c) return RFE_ERR_INVALID;
+    switch (option) {
+        case RFE_OPT_LG_FOLD_WO: c->opt_lg_fold = value != 0; return RFE_OK;
+        default: return fail(c, RFE_ERR_INVALID, "rfe_set_option: unknown option");
+    }
+}
+extern "C" int rfe_get_option(rfe_ctx* c, int option, int* value) {
+    if (!c || !value) return RFE_ERR_INVALID;
+    switch (option) {
+        case RFE_OPT_LG_FOLD_WO: *value = c->opt_lg_fold ? 1 : 0; return RFE_OK;
+        default: return fail(c, RFE_ERR_INVALID, "rfe_get_option: unknown option");
+    }
+}
+
 extern "C" int rfe_set_stream(rfe_ctx* c, void* s) {
     if (!c) return RFE_ERR_INVALID;
     c->stream = s ? (hipStream_t)s : c->own_stream;
@@ -395,10 +410,13 @@ struct SpBuffers {
     float* cand_score; int32_t* cand_idx;
 };
 
+// conv1a as its own launch (78.6 MB/frame activation in HBM) instead of recomputed inside conv1b: A/B and test switch
+bool sp_unfused_conv1() { static const bool u = tune_env("RFE_UNFUSED_CONV1") != nullptr; return u; }
+
 size_t sp_ws_bytes(int B, int H, int W) {
     const size_t hw = (size_t)B * H * W, cells = hw / 64;
     size_t t = 0;
-    t += al(hw * 64 * 4);          // a1
+    if (sp_unfused_conv1()) t += al(hw * 64 * 4);   // a1: never materialised on the default (fused) path
     t += al(hw / 4 * 64 * 4) * 2;  // p1, a2
     t += al(hw / 16 * 64 * 4);     // p2
     t += al(hw / 16 * 128 * 4);    // a3
@@ -414,7 +432,7 @@ size_t sp_ws_bytes(int B, int H, int W) {
 void sp_carve(void* ws, int B, int H, int W, SpBuffers& b) {
     const size_t hw = (size_t)B * H * W, cells = hw / 64;
     Bump a(ws);
-    b.a1 = a.take<float>(hw * 64); b.p1 = a.take<float>(hw / 4 * 64); b.a2 = a.take<float>(hw / 4 * 64);
+    b.a1 = sp_unfused_conv1() ? a.take<float>(hw * 64) : nullptr; b.p1 = a.take<float>(hw / 4 * 64); b.a2 = a.take<float>(hw / 4 * 64);
     b.p2 = a.take<float>(hw / 16 * 64); b.a3 = a.take<float>(hw / 16 * 128);
     b.p3 = a.take<float>(cells * 128); b.a4 = a.take<float>(cells * 128); b.f4 = a.take<float>(cells * 128);
     b.pa = a.take<float>(cells * 256); b.da = a.take<float>(cells * 256); b.dmap = a.take<float>(cells * 256);
@@ -451,8 +469,7 @@ int sp_forward_maps(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, in
     hipStream_t s = c->stream;
     const SpWeightsDev& w = c->sp;
     const int Hc = H / 8, Wc = W / 8, cells = B * Hc * Wc;
-    static const bool unfused = getenv("RFE_UNFUSED_CONV1") != nullptr;   // tuning / test switch
-    if (unfused) {
+    if (sp_unfused_conv1()) {
         { ProfScope p(c, "conv1a"); launch_conv1a_u8(s, img, stride, B, H, W, w.conv1a_w, w.bias[L_1A], b.a1); }
         { ProfScope p(c, "conv1b"); launch_conv3x3(s, b.a1, B, H, W, 64, w.packed[L_1B], w.bias[L_1B], 64, true, true, b.p1, L_1B); }
     } else {   // conv1a recomputed inside conv1b's LDS staging: the [B,H,W,64] activation never touches HBM
@@ -469,7 +486,7 @@ int sp_forward_maps(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, in
     // side stream while the detector head continues on the main one with its tail of small bandwidth / latency-bound
     // kernels (convPb, softmax, 5 NMS passes, selection), which would otherwise leave most of the chip idle.
     // With events around every stage (full profiling pass) the heads stay serial so that the stage times are clean.
-    static const bool fork_env = getenv("RFE_SP_NO_FORK") == nullptr;
+    static const bool fork_env = tune_env("RFE_SP_NO_FORK") == nullptr;
     const bool fork = fork_env && !(c->prof && c->prof_filter.empty());
     hipStream_t sd = fork ? c->side_stream : s;
     if (fork) { RFE_HIP(c, hipEventRecord(c->ev_fork, s)); RFE_HIP(c, hipStreamWaitEvent(sd, c->ev_fork, 0)); }
@@ -519,14 +536,17 @@ extern "C" int rfe_extract_u8(rfe_ctx* c, const uint8_t* img, int H, int W, int 
     if (rc) return rc;
     if (!img || !n || !kxy || !score || !desc || stride < W) return fail(c, RFE_ERR_INVALID, "extract: null pointer or stride < W");
     RFE_HIP(c, hipSetDevice(c->device));
-    const size_t ib = al((size_t)B * H * stride), nb = al((size_t)B * 4), kb = al((size_t)B * Kmax * 8),
+    // the device copy is tight (pitch W): a cv::Mat ROI has stride > W and its last row ends W bytes into the row, so
+    // only W bytes of every row are read (B*H*stride bytes from the first pixel would run past a ROI at the bottom of
+    // its parent buffer)
+    const size_t ib = al((size_t)B * H * W), nb = al((size_t)B * 4), kb = al((size_t)B * Kmax * 8),
                  sb = al((size_t)B * Kmax * 4), db = al((size_t)B * Kmax * 1024);
     if ((rc = ensure_ws(c, &c->ws_io, &c->ws_io_bytes, ib + nb + kb + sb + db))) return rc;
     char* p = (char*)c->ws_io;
     uint8_t* d_img = (uint8_t*)p; int32_t* d_n = (int32_t*)(p + ib); int32_t* d_k = (int32_t*)(p + ib + nb);
     float* d_s = (float*)(p + ib + nb + kb); float* d_d = (float*)(p + ib + nb + kb + sb);
-    RFE_HIP(c, hipMemcpyAsync(d_img, img, (size_t)B * H * stride, hipMemcpyHostToDevice, c->stream));
-    if ((rc = sp_forward(c, d_img, H, W, stride, B, Kmax, thr, d_n, d_k, d_s, d_d))) return rc;
+    RFE_HIP(c, hipMemcpy2DAsync(d_img, (size_t)W, img, (size_t)stride, (size_t)W, (size_t)B * H, hipMemcpyHostToDevice, c->stream));
+    if ((rc = sp_forward(c, d_img, H, W, W, B, Kmax, thr, d_n, d_k, d_s, d_d))) return rc;
     RFE_HIP(c, hipMemcpyAsync(n, d_n, (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
     RFE_HIP(c, hipMemcpyAsync(kxy, d_k, (size_t)B * Kmax * 8, hipMemcpyDeviceToHost, c->stream));
     RFE_HIP(c, hipMemcpyAsync(score, d_s, (size_t)B * Kmax * 4, hipMemcpyDeviceToHost, c->stream));
@@ -577,7 +597,6 @@ void lg_carve(void* ws, int P, int L, LgBuffers& b, size_t extra_bytes = 0) {
 // block) may use it whenever its own requirement fits
 float* lg_part(const LgBuffers& b, int nseq, int L) { return (b.apart && lg_attention_part_bytes(nseq, L) > 0) ? b.apart : nullptr; }
 
-bool lg_fold() { static const bool f = getenv("RFE_LG_NO_FOLD") == nullptr; return f; }
 
 // x + ffn([x | msg]) in place on x
 void lg_ffn(rfe_ctx* c, LgBuffers& b, float* x, const float* second, int rows, const float* w1, const float* b1, const float* g,
@@ -604,7 +623,7 @@ void lg_self_block(rfe_ctx* c, LgBuffers& b, const LgLayerDev& Lw, float* x, con
       a.rope_cs = cs; a.rope_sn = sn; a.rope_ncols = 512;
       launch_gemm_nt(s, a); }
     { ProfScope p(c, "lg_attention"); launch_lg_attention(s, b.qkv, b.qkv + 256, b.qkv + 512, 768, b.ctx, nseq, L, L, lens, lens, nullptr, lg_part(b, nseq, L)); }
-    if (lg_fold()) {
+    if (c->opt_lg_fold) {
         lg_ffn(c, b, x, b.ctx, rows, Lw.w1f, Lw.b1f, Lw.lng, Lw.lnb, Lw.w2, Lw.b2);
     } else {
         { ProfScope p(c, "lg_proj"); launch_gemm_nt(s, gemm_plain(b.ctx, 256, Lw.wo, 256, Lw.bo, b.msg, 256, rows, 256, 256)); }
@@ -627,7 +646,7 @@ int lg_forward(rfe_ctx* c, LgBuffers& b, int P, int L, float thr, int cap, int32
         // ---- cross block
         { ProfScope p(c, "lg_cross_qkv"); launch_gemm_nt(s, gemm_plain(b.x, 256, Lw.cwqkv, 256, Lw.cbqkv, b.qkv, 512, rows, 512, 256)); }
         { ProfScope p(c, "lg_attention"); launch_lg_attention(s, b.qkv, b.qkv, b.qkv + 256, 512, b.ctx, nseq, L, L, b.lens, b.lens, b.kvmap, lg_part(b, nseq, L)); }
-        if (lg_fold()) {
+        if (c->opt_lg_fold) {
             lg_ffn(c, b, b.x, b.ctx, rows, Lw.cw1f, Lw.cb1f, Lw.clng, Lw.clnb, Lw.cw2, Lw.cb2);
         } else {
             { ProfScope p(c, "lg_proj"); launch_gemm_nt(s, gemm_plain(b.ctx, 256, Lw.cwo, 256, Lw.cbo, b.msg, 256, rows, 256, 256)); }
@@ -778,7 +797,7 @@ extern "C" int rfe_extract_match_stream_dev(rfe_ctx* c, const uint8_t* img, int 
     lg_carve(c->ws_lg, P, L, b, extra_bytes);
     float* kn_all = (float*)b.extra;
     hipStream_t s = c->stream;
-    static const bool dedup = getenv("RFE_NO_SELF_DEDUP") == nullptr;   // tuning / test switch
+    static const bool dedup = tune_env("RFE_NO_SELF_DEDUP") == nullptr;   // tuning / test switch
     if (!dedup || L != Kmax) {
         { ProfScope p(c, "lg_misc");
           launch_normalize_kpts(s, kxy, (int64_t)B * Kmax, H, W, kn_all);
@@ -834,7 +853,7 @@ extern "C" int rfe_stereo_match(rfe_ctx* c, const uint8_t* imgL, const uint8_t* 
     if (N < 0 || Nr < 0 || N > 4096 || H <= 0 || W <= 0 || stride < W) return fail(c, RFE_ERR_INVALID, "stereo_match: bad argument");
     if (N == 0) return RFE_OK;
     RFE_HIP(c, hipSetDevice(c->device));
-    const size_t bi = al((size_t)H * stride), bkl = al((size_t)N * 8), bkr = al((size_t)std::max(Nr, 1) * 8),
+    const size_t bi = al((size_t)H * W), bkl = al((size_t)N * 8), bkr = al((size_t)std::max(Nr, 1) * 8),
                  bdl = al((size_t)N * 1024), bdr = al((size_t)std::max(Nr, 1) * 1024), bo = al((size_t)N * 4);
     int rc = ensure_ws(c, &c->ws_io, &c->ws_io_bytes, 2 * bi + bkl + bkr + bdl + bdr + 2 * bo);
     if (rc) return rc;
@@ -843,15 +862,15 @@ extern "C" int rfe_stereo_match(rfe_ctx* c, const uint8_t* imgL, const uint8_t* 
     float* dkl = (float*)p; p += bkl; float* dkr = (float*)p; p += bkr; float* ddl = (float*)p; p += bdl; float* ddr = (float*)p; p += bdr;
     float* du = (float*)p; p += bo; float* dz = (float*)p;
     hipStream_t s = c->stream;
-    RFE_HIP(c, hipMemcpyAsync(dIL, imgL, (size_t)H * stride, hipMemcpyHostToDevice, s));
-    RFE_HIP(c, hipMemcpyAsync(dIR, imgR, (size_t)H * stride, hipMemcpyHostToDevice, s));
+    RFE_HIP(c, hipMemcpy2DAsync(dIL, (size_t)W, imgL, (size_t)stride, (size_t)W, (size_t)H, hipMemcpyHostToDevice, s));   // tight device copy (ROI-safe)
+    RFE_HIP(c, hipMemcpy2DAsync(dIR, (size_t)W, imgR, (size_t)stride, (size_t)W, (size_t)H, hipMemcpyHostToDevice, s));
     RFE_HIP(c, hipMemcpyAsync(dkl, kL, (size_t)N * 8, hipMemcpyHostToDevice, s));
     RFE_HIP(c, hipMemcpyAsync(ddl, dL, (size_t)N * 1024, hipMemcpyHostToDevice, s));
     if (Nr > 0) {
         RFE_HIP(c, hipMemcpyAsync(dkr, kR, (size_t)Nr * 8, hipMemcpyHostToDevice, s));
         RFE_HIP(c, hipMemcpyAsync(ddr, dR, (size_t)Nr * 1024, hipMemcpyHostToDevice, s));
     }
-    if ((rc = rfe_stereo_match_dev(c, dIL, dIR, H, W, stride, dkl, N, dkr, Nr, ddl, ddr, mb, mbf, du, dz))) return rc;
+    if ((rc = rfe_stereo_match_dev(c, dIL, dIR, H, W, W, dkl, N, dkr, Nr, ddl, ddr, mb, mbf, du, dz))) return rc;
     RFE_HIP(c, hipMemcpyAsync(uRight, du, (size_t)N * 4, hipMemcpyDeviceToHost, s));
     RFE_HIP(c, hipMemcpyAsync(depth, dz, (size_t)N * 4, hipMemcpyDeviceToHost, s));
     RFE_HIP(c, hipStreamSynchronize(s));

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <memory>
 #include <string>
 #include <vector>
@@ -11,6 +12,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace rfe {
+
+// Tuning / ablation switches read from the environment exist only in a -DRFE_TUNING build (make TUNING=1 ->
+// librover_fe_tuning.so, used by tools/ for A/B measurements).  The shipped library never consults the environment:
+// its numerics and kernel choices depend on its arguments and on rfe_set_option alone.
+#ifdef RFE_TUNING
+inline const char* tune_env(const char* name) { return getenv(name); }
+#else
+inline const char* tune_env(const char*) { return nullptr; }
+#endif
+inline int tune_int(const char* name, int dflt) { const char* e = tune_env(name); return e ? atoi(e) : dflt; }
 
 // ---------------------------------------------------------------- SuperPoint layer table
 // names follow the reference's dead libtorch header include/SuperPoint.h:24-41
@@ -82,6 +93,7 @@ struct rfe_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     bool has_sp = false, has_lg = false;
+    bool opt_lg_fold = false;            // RFE_OPT_LG_FOLD_WO
     rfe::SpWeightsDev sp;                // views into *sp_hold / *lg_hold
     rfe::LgWeightsDev lg;
     std::shared_ptr<void> sp_hold, lg_hold;   // device copies, shared by every ctx of the process that loaded the same blob on the same device

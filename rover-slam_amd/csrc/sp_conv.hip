@@ -27,7 +27,7 @@ constexpr int NT = CONV_NT;
 
 // input channels per LDS chunk: 16 (58.6 KB LDS, 2 workgroups/CU) or 8 (29.3 KB, 3-4 workgroups/CU)
 int conv_ck() {
-    static const int ck = [] { const char* e = getenv("RFE_CONV_CK"); const int v = e ? atoi(e) : CONV_CK; return (v == 8 || v == 16) ? v : CONV_CK; }();
+    static const int ck = [] { const char* e = tune_env("RFE_CONV_CK"); const int v = e ? atoi(e) : CONV_CK; return (v == 8 || v == 16) ? v : CONV_CK; }();
     return ck;
 }
 
@@ -456,7 +456,7 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
     dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B * (cout / NT));
     const bool ck8 = conv_ck() == 8;
     // latency regime: too few 8 x 32 x 64 tiles to occupy the chip -> 4 x 32 x 32 tiles (4x the workgroups)
-    static const int small_thr = getenv("RFE_CONV_SMALL") ? atoi(getenv("RFE_CONV_SMALL")) : 512;   // 0 disables
+    static const int small_thr = tune_int("RFE_CONV_SMALL", 512);   // 0 disables
     if (ck8 && !pool && (long long)grid.x * grid.y * grid.z < small_thr && (cin == 64 || cin == 128)) {
         dim3 gs((W + TW - 1) / TW, (H + STH - 1) / STH, B * (cout / SNT));
         if (cin == 128 && relu) hipLaunchKernelGGL((conv3x3_small_kernel<128, true, 8>), gs, dim3(256), 0, s, in, wp, bias, out, H, W, cout);
@@ -465,11 +465,11 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
         else hipLaunchKernelGGL((conv3x3_small_kernel<64, false, 8>), gs, dim3(256), 0, s, in, wp, bias, out, H, W, cout);
         return;
     }
-    static const bool no_wide = getenv("RFE_CONV_NO_WIDE") != nullptr;   // tuning / test switch
+    static const bool no_wide = tune_env("RFE_CONV_NO_WIDE") != nullptr;   // tuning / test switch
     // 60 x 80 grid, measured (TFLOP/s, batch 33): 8x32 tile 94 (conv4) / 103 (heads); wide 4x80 tile 97 / 94 (the 256-channel
     // heads re-stage the larger input tile four times); 12x16 tile of 3-wave workgroups 83 / 108.
     // -> conv4a/4b take the wide tile, convPa/Da the 12x16 tile.  RFE_CONV_TALL: 0 = 8x32 everywhere, 1 = 12x16 everywhere, 2 = wide for conv4 only
-    static const int tall = getenv("RFE_CONV_TALL") ? atoi(getenv("RFE_CONV_TALL")) : -1;
+    static const int tall = tune_int("RFE_CONV_TALL", -1);
     if (!no_wide && ck8 && !pool && relu && cin == 128 && (tag == L_4A || tag == L_4B || tag == L_PA || tag == L_DA)) {
         const bool heads = tag == L_PA || tag == L_DA;
         if ((tall == 1 || (tall == -1 && heads)) && W % 16 == 0 && H % 12 == 0) {
