@@ -151,6 +151,21 @@ int rfe_stereo_match_dev(rfe_ctx* ctx, const uint8_t* imgL, const uint8_t* imgR,
                          const float* kL, int N, const float* kR, int Nr, const float* dL, const float* dR,
                          float mb, float mbf, float* uRight, float* depth);
 
+/* ---- stereo stream (BASELINE configs[4]): ONE device-resident call per stereo frame ----
+ * What the reference does per stereo frame, fused: the stereo Frame constructor extracts the left and right views on two
+ * threads (src/Frame.cc:106-171, :142-147) and calls ComputeStereoMatches (:165, :1159-1446); Tracking then matches the
+ * frame against the previous one with LightGlue (SPmatcher::MatchingPoints_onnx, Frame overload, src/Matchers/SPmatcher.cc:457-542,
+ * called from :1050-1080).  Here: both views through SuperPoint as one batch of 2, the sparse stereo match on the device-
+ * resident features (keypoint counts never visit the host), and one LightGlue match of the PREVIOUS left view (set 0,
+ * kept inside the ctx) against this left view (set 1) with the true image size.  Asynchronous on the ctx stream.
+ * imgL/imgR: device u8 [H,W], row pitch `stride`.  reset != 0 (or a change of H, W, Kmax) starts a new sequence: S = 0.
+ * Outputs (device): n [2] (left, right), kxy [2,Kmax,2], score [2,Kmax], desc [2,Kmax,256] as rfe_extract_u8_dev;
+ * uRight / depth [Kmax] as rfe_stereo_match (entries >= n[0] are -1); S [1], pairs [Kmax,2], ms [Kmax] as rfe_match_dev. */
+int rfe_stereo_frame_dev(rfe_ctx* ctx, const uint8_t* imgL_dev, const uint8_t* imgR_dev, int H, int W, int stride, int Kmax,
+                         float thr, float filter_thr, float mb, float mbf, int reset, int32_t* n_dev, int32_t* kxy_dev,
+                         float* score_dev, float* desc_dev, float* uRight_dev, float* depth_dev, int32_t* S_dev,
+                         int32_t* pairs_dev, float* ms_dev);
+
 /* ---- descriptor helpers for the callers' classic searches, host pointers ----
  * rfe_l2_distance_matrix: out[i*N + j] = SPmatcher::DescriptorDistance_sp(a_i, b_j)
  *   (src/Matchers/SPmatcher.cc:2184-2189) for all pairs of a [M,256] x b [N,256]; the candidate lists of

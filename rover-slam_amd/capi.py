@@ -17,7 +17,7 @@ EXPORTS = [
     "rfe_init", "rfe_destroy", "rfe_last_error", "rfe_version", "rfe_load_weights", "rfe_set_weights",
     "rfe_weight_count", "rfe_weights_id", "rfe_set_option", "rfe_get_option", "rfe_set_stream", "rfe_synchronize", "rfe_malloc", "rfe_free", "rfe_memcpy_h2d",
     "rfe_memcpy_d2h", "rfe_extract_u8", "rfe_extract_u8_dev", "rfe_match", "rfe_match_dev", "rfe_match_fused",
-    "rfe_extract_match_stream_dev", "rfe_stereo_match", "rfe_stereo_match_dev", "rfe_l2_distance_matrix", "rfe_binarize_descriptors",
+    "rfe_extract_match_stream_dev", "rfe_stereo_match", "rfe_stereo_match_dev", "rfe_stereo_frame_dev", "rfe_l2_distance_matrix", "rfe_binarize_descriptors",
     "rfe_search_candidates", "rfe_distinctive_descriptors",
     "rfe_profile_enable", "rfe_profile_filter", "rfe_profile_reset", "rfe_profile_read",
     "rfe_k_conv3x3", "rfe_k_linear", "rfe_k_scoremap", "rfe_k_lightglue_taps",
@@ -63,6 +63,8 @@ lib.rfe_extract_match_stream_dev.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int,
 _st = [C.c_void_p, _u8p, _u8p, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_float, C.c_float, _fp, _fp]
 lib.rfe_stereo_match.argtypes = _st
 lib.rfe_stereo_match_dev.argtypes = _st
+lib.rfe_stereo_frame_dev.argtypes = [C.c_void_p, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                     C.c_int, _ip, _ip, _fp, _fp, _fp, _fp, _ip, _ip, _fp]
 lib.rfe_l2_distance_matrix.argtypes = [C.c_void_p, _fp, C.c_int, _fp, C.c_int, _fp]
 lib.rfe_binarize_descriptors.argtypes = [C.c_void_p, _fp, C.c_int, _u8p]
 lib.rfe_search_candidates.argtypes = [C.c_void_p, _fp, C.c_int, _fp, C.c_int, _ip, _ip, _u8p, _ip, _fp, _fp]
@@ -120,6 +122,40 @@ class DevBuf:
         if self.ptr:
             lib.rfe_free(self.ctx.h, self.ptr)
             self.ptr = None
+
+
+class StereoStream:
+    """Device-resident stereo stream (rfe_stereo_frame_dev): owns the output buffers, push() enqueues one stereo frame
+    (device image pointers) without any host synchronisation, results() downloads the last frame's outputs."""
+
+    def __init__(self, ctx, H, W, kmax=1024, mb=0.11, mbf=0.11 * 435.0, thr=0.0005, filter_thr=0.1):
+        self.ctx, self.H, self.W, self.K = ctx, H, W, kmax
+        self.mb, self.mbf, self.thr, self.filter_thr = mb, mbf, thr, filter_thr
+        K = kmax
+        self._spec = [("n", np.int32, (2,)), ("kxy", np.int32, (2, K, 2)), ("score", np.float32, (2, K)), ("desc", np.float32, (2, K, 256)),
+                      ("u_right", np.float32, (K,)), ("depth", np.float32, (K,)), ("S", np.int32, (1,)), ("pairs", np.int32, (K, 2)),
+                      ("ms", np.float32, (K,))]
+        self.bufs = {name: ctx.alloc(int(np.prod(shape)) * np.dtype(dt).itemsize) for name, dt, shape in self._spec}
+        self.first = True
+
+    def push(self, img_l_dev, img_r_dev, stride=None, reset=False):
+        b = self.bufs
+        self.ctx._chk(lib.rfe_stereo_frame_dev(self.ctx.h, _addr(img_l_dev), _addr(img_r_dev), self.H, self.W, stride or self.W, self.K,
+                                               self.thr, self.filter_thr, self.mb, self.mbf, int(reset or self.first), b["n"].ptr,
+                                               b["kxy"].ptr, b["score"].ptr, b["desc"].ptr, b["u_right"].ptr, b["depth"].ptr,
+                                               b["S"].ptr, b["pairs"].ptr, b["ms"].ptr))
+        self.first = False
+
+    def results(self):
+        self.ctx.synchronize()
+        out = {name: self.bufs[name].download(shape, dt) for name, dt, shape in self._spec}
+        out["S"] = int(out["S"][0])
+        return out
+
+    def close(self):
+        for b in self.bufs.values():
+            b.free()
+        self.bufs = {}
 
 
 class Context:

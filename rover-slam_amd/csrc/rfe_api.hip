@@ -118,7 +118,7 @@ extern "C" void rfe_destroy(rfe_ctx* c) {
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
     c->sp_hold.reset(); c->lg_hold.reset();   // the last ctx holding a device copy frees it
-    fr(c->ws_sp); fr(c->ws_lg); fr(c->ws_io); fr(c->ws_tmp);
+    fr(c->ws_sp); fr(c->ws_lg); fr(c->ws_io); fr(c->ws_tmp); fr(c->ws_st);
     if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -875,6 +875,63 @@ extern "C" int rfe_stereo_match(rfe_ctx* c, const uint8_t* imgL, const uint8_t* 
     RFE_HIP(c, hipMemcpyAsync(depth, dz, (size_t)N * 4, hipMemcpyDeviceToHost, s));
     RFE_HIP(c, hipStreamSynchronize(s));
     prof_collect(c);
+    return RFE_OK;
+}
+
+// =====================================================================================
+// stereo stream (BASELINE configs[4]): one device-resident entry point per stereo frame
+// =====================================================================================
+__global__ void st_zero_count_kernel(int32_t* S) { S[0] = 0; }
+
+extern "C" int rfe_stereo_frame_dev(rfe_ctx* c, const uint8_t* imgL, const uint8_t* imgR, int H, int W, int stride, int Kmax,
+                                    float thr, float filter_thr, float mb, float mbf, int reset, int32_t* n, int32_t* kxy,
+                                    float* score, float* desc, float* uRight, float* depth, int32_t* S, int32_t* pairs,
+                                    float* ms) {
+    int rc = sp_check(c, H, W, 2, Kmax);
+    if (rc) return rc;
+    if ((rc = lg_check(c, 1, Kmax, Kmax))) return rc;
+    if (!imgL || !imgR || !n || !kxy || !score || !desc || !uRight || !depth || !S || !pairs || !ms || stride < W || !(mb > 0.f))
+        return fail(c, RFE_ERR_INVALID, "stereo_frame: null pointer, stride < W or mb <= 0");
+    RFE_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    // state: [2,H,W] staged views | sadv [Kmax] | kn_prev, kn_cur [Kmax,2] | desc_prev [Kmax,256] | n_prev [1]
+    const size_t b_img = al((size_t)2 * H * W), b_sad = al((size_t)Kmax * 4), b_kn = al((size_t)Kmax * 8), b_desc = al((size_t)Kmax * 1024);
+    const bool fresh = c->st_H != H || c->st_W != W || c->st_K != Kmax;
+    if ((rc = ensure_ws(c, &c->ws_st, &c->ws_st_bytes, b_img + b_sad + 2 * b_kn + b_desc + 256))) return rc;
+    if (fresh || reset) { c->st_have_prev = false; c->st_H = H; c->st_W = W; c->st_K = Kmax; }
+    char* p = (char*)c->ws_st;
+    uint8_t* d_img = (uint8_t*)p; p += b_img;
+    int32_t* sadv = (int32_t*)p; p += b_sad;
+    float* kn_prev = (float*)p; p += b_kn; float* kn_cur = (float*)p; p += b_kn;
+    float* desc_prev = (float*)p; p += b_desc; int32_t* n_prev = (int32_t*)p;
+    // both views as ONE batch of 2 (the reference runs them on two threads, src/Frame.cc:142-147)
+    RFE_HIP(c, hipMemcpy2DAsync(d_img, (size_t)W, imgL, (size_t)stride, (size_t)W, (size_t)H, hipMemcpyDeviceToDevice, s));
+    RFE_HIP(c, hipMemcpy2DAsync(d_img + (size_t)H * W, (size_t)W, imgR, (size_t)stride, (size_t)W, (size_t)H, hipMemcpyDeviceToDevice, s));
+    if ((rc = sp_forward(c, d_img, H, W, W, 2, Kmax, thr, n, kxy, score, desc))) return rc;
+    // Frame::ComputeStereoMatches (src/Frame.cc:1159-1446) on the device-resident features; counts stay on the device
+    { ProfScope ps(c, "stereo_match");
+      launch_stereo_match_counts(s, d_img, d_img + (size_t)H * W, H, W, W, kxy, kxy + (size_t)Kmax * 2, Kmax, n, desc,
+                                 desc + (size_t)Kmax * 256, mb, mbf, uRight, depth, sadv); }
+    // temporal match: previous left view (set 0) against this left view (set 1), true image size like the Frame overload
+    // of MatchingPoints_onnx (src/Matchers/SPmatcher.cc:457-542, :463-464)
+    { ProfScope ps(c, "lg_misc"); launch_normalize_kpts(s, kxy, Kmax, H, W, kn_cur); }
+    if (c->st_have_prev) {
+        const int L = ((Kmax + 3) / 4) * 4;
+        if ((rc = ensure_ws(c, &c->ws_lg, &c->ws_lg_bytes, lg_ws_bytes(1, L)))) return rc;
+        LgBuffers b;
+        lg_carve(c->ws_lg, 1, L, b);
+        { ProfScope ps(c, "lg_misc");
+          if ((rc = lg_stage(c, b, kn_prev, kn_cur, desc_prev, desc, n_prev, n, 1, Kmax, Kmax, L))) return rc; }
+        if ((rc = lg_forward(c, b, 1, L, filter_thr, Kmax, S, pairs, ms, nullptr))) return rc;
+    } else {
+        hipLaunchKernelGGL(st_zero_count_kernel, dim3(1), dim3(1), 0, s, S);
+    }
+    { ProfScope ps(c, "lg_misc");   // this left view becomes the previous one
+      RFE_HIP(c, hipMemcpyAsync(kn_prev, kn_cur, (size_t)Kmax * 8, hipMemcpyDeviceToDevice, s));
+      RFE_HIP(c, hipMemcpyAsync(desc_prev, desc, (size_t)Kmax * 1024, hipMemcpyDeviceToDevice, s));
+      RFE_HIP(c, hipMemcpyAsync(n_prev, n, 4, hipMemcpyDeviceToDevice, s)); }
+    c->st_have_prev = true;
+    RFE_HIP(c, hipGetLastError());
     return RFE_OK;
 }
 

@@ -102,6 +102,8 @@ struct rfe_ctx {
     void* ws_lg = nullptr; size_t ws_lg_bytes = 0;
     void* ws_io = nullptr; size_t ws_io_bytes = 0;   // staging for host-pointer entry points
     void* ws_tmp = nullptr; size_t ws_tmp_bytes = 0; // test hooks
+    void* ws_st = nullptr; size_t ws_st_bytes = 0;   // stereo stream state: staged views, previous left view's features
+    int st_H = 0, st_W = 0, st_K = 0; bool st_have_prev = false;
     // profiling
     bool prof = false;
     std::string prof_filter;          // non-empty: only this stage records events
@@ -175,6 +177,10 @@ void launch_normalize_kpts(hipStream_t s, const int32_t* kxy, int64_t n, int row
 void launch_stereo_match(hipStream_t s, const uint8_t* imgL, const uint8_t* imgR, int H, int W, int stride,
                          const float* kL, int N, const float* kR, int Nr, const float* dL, const float* dR, float mb,
                          float mbf, float* uRight, float* depth, int32_t* sadv);
+
+void launch_stereo_match_counts(hipStream_t s, const uint8_t* imgL, const uint8_t* imgR, int H, int W, int stride,
+                                const int32_t* kL, const int32_t* kR, int Kmax, const int32_t* counts, const float* dL,
+                                const float* dR, float mb, float mbf, float* uRight, float* depth, int32_t* sadv);
 
 void launch_l2_matrix(hipStream_t s, const float* a, int M, const float* b, int N, float* out);
 void launch_binarize(hipStream_t s, const float* d, int64_t rows, uint8_t* out);

@@ -14,19 +14,24 @@
 
 namespace rfe {
 
+// KT: keypoint coordinate type -- float (the caller's cv::KeyPoint::pt) or int32 (the extractor's own output, device
+// resident); counts: optional device-side {N, Nr} (stream mode: no host round trip for the keypoint counts), the grid
+// then covers the capacity and surplus waves leave at once.
+template <typename KT>
 __global__ __launch_bounds__(256) void stereo_match_kernel(
     const uint8_t* __restrict__ imgL, const uint8_t* __restrict__ imgR, int H, int W, int stride,
-    const float* __restrict__ kL, int N, const float* __restrict__ kR, int Nr, const float* __restrict__ dL,
-    const float* __restrict__ dR, float maxD, float mbf, float* __restrict__ uRight, float* __restrict__ depth,
-    int32_t* __restrict__ sadv) {
+    const KT* __restrict__ kL, int N, const KT* __restrict__ kR, int Nr, const int32_t* __restrict__ counts,
+    const float* __restrict__ dL, const float* __restrict__ dR, float maxD, float mbf, float* __restrict__ uRight,
+    float* __restrict__ depth, int32_t* __restrict__ sadv) {
     const int lane = threadIdx.x & 63;
     const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (counts) { N = counts[0] < N ? counts[0] : N; Nr = counts[1] < Nr ? counts[1] : Nr; }
     if (iL >= N) return;
     const float TH_HIGH = 1.4f, TH_LOW = 1.2f;
     const float thOrbDist = (TH_HIGH + TH_LOW) / 2;
     const float minD = 0.f;
     float outU = -1.0f, outZ = -1.0f; int outS = -1;
-    const float uL = kL[2 * iL], vL = kL[2 * iL + 1];
+    const float uL = (float)kL[2 * iL], vL = (float)kL[2 * iL + 1];
     const float minU = uL - maxD, maxU = uL - minD;
     float bestDist = TH_HIGH; int bestIdx = -1;
     if (!(maxU < 0)) {
@@ -36,7 +41,7 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(
             const int iR = base + lane;
             bool cand = false;
             if (iR < Nr) {
-                const float uR = kR[2 * iR], yR = kR[2 * iR + 1];
+                const float uR = (float)kR[2 * iR], yR = (float)kR[2 * iR + 1];
                 cand = !(row < (int)floorf(yR - 2.0f) || row > (int)ceilf(yR + 2.0f)) && uR >= minU && uR <= maxU;
             }
             unsigned long long mask = __ballot(cand);
@@ -56,7 +61,7 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(
         }
     }
     if (bestDist < thOrbDist && bestIdx >= 0) {
-        const float uR0 = kR[2 * bestIdx];
+        const float uR0 = (float)kR[2 * bestIdx];
         const int su = (int)roundf(uL), sv = (int)roundf(vL), sr = (int)roundf(uR0);
         const int w = 5, Lh = 5;
         const bool ok = !(sr - Lh - w < 0 || sr + Lh + w + 1 >= W) && !(sv - w < 0 || sv + w >= H || su - w < 0 || su + w >= W);
@@ -97,12 +102,14 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(
 }
 
 // median outlier cut (Frame.cc:1431-1445): one workgroup, N <= 4096
-__global__ __launch_bounds__(1024) void stereo_filter_kernel(int N, int P2, const int32_t* __restrict__ sadv,
-                                                             float* __restrict__ uRight, float* __restrict__ depth) {
+__global__ __launch_bounds__(1024) void stereo_filter_kernel(int N, int P2, const int32_t* __restrict__ counts,
+                                                             const int32_t* __restrict__ sadv, float* __restrict__ uRight,
+                                                             float* __restrict__ depth) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
     __shared__ int cnt;
     const int tid = threadIdx.x;
+    if (counts) N = counts[0] < N ? counts[0] : N;
     if (tid == 0) cnt = 0;
     for (int k = tid; k < P2; k += 1024) keys[k] = ~0ull;   // padding sorts last
     __syncthreads();
@@ -138,11 +145,30 @@ void launch_stereo_match(hipStream_t s, const uint8_t* imgL, const uint8_t* imgR
                          float mbf, float* uRight, float* depth, int32_t* sadv) {
     if (N <= 0) return;
     const float maxD = mbf / mb;
-    hipLaunchKernelGGL(stereo_match_kernel, dim3((N + 3) / 4), dim3(256), 0, s, imgL, imgR, H, W, stride, kL, N, kR, Nr,
-                       dL, dR, maxD, mbf, uRight, depth, sadv);
+    hipLaunchKernelGGL(stereo_match_kernel<float>, dim3((N + 3) / 4), dim3(256), 0, s, imgL, imgR, H, W, stride, kL, N, kR, Nr,
+                       (const int32_t*)nullptr, dL, dR, maxD, mbf, uRight, depth, sadv);
     int P2 = 1;
     while (P2 < N) P2 <<= 1;
-    hipLaunchKernelGGL(stereo_filter_kernel, dim3(1), dim3(1024), (size_t)P2 * 8, s, N, P2, sadv, uRight, depth);
+    hipLaunchKernelGGL(stereo_filter_kernel, dim3(1), dim3(1024), (size_t)P2 * 8, s, N, P2, (const int32_t*)nullptr, sadv, uRight, depth);
+}
+
+// device-resident form: integer keypoints straight from the extractor, counts = device {n_left, n_right}, capacity Kmax.
+// Entries >= n_left of uRight / depth are set to -1 (no match) so the outputs are fully defined.
+__global__ void stereo_fill_kernel(float* __restrict__ uRight, float* __restrict__ depth, int32_t* __restrict__ sadv, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { uRight[i] = -1.0f; depth[i] = -1.0f; sadv[i] = -1; }
+}
+void launch_stereo_match_counts(hipStream_t s, const uint8_t* imgL, const uint8_t* imgR, int H, int W, int stride,
+                                const int32_t* kL, const int32_t* kR, int Kmax, const int32_t* counts, const float* dL,
+                                const float* dR, float mb, float mbf, float* uRight, float* depth, int32_t* sadv) {
+    if (Kmax <= 0) return;
+    const float maxD = mbf / mb;
+    hipLaunchKernelGGL(stereo_fill_kernel, dim3((Kmax + 255) / 256), dim3(256), 0, s, uRight, depth, sadv, Kmax);
+    hipLaunchKernelGGL(stereo_match_kernel<int32_t>, dim3((Kmax + 3) / 4), dim3(256), 0, s, imgL, imgR, H, W, stride, kL, Kmax, kR, Kmax,
+                       counts, dL, dR, maxD, mbf, uRight, depth, sadv);
+    int P2 = 1;
+    while (P2 < Kmax) P2 <<= 1;
+    hipLaunchKernelGGL(stereo_filter_kernel, dim3(1), dim3(1024), (size_t)P2 * 8, s, Kmax, P2, counts, sadv, uRight, depth);
 }
 
 // ------------------------------------------------------------------------------------------

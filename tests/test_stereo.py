@@ -166,3 +166,61 @@ def test_distinctive_descriptors_matches_oracle(oracle):
     rbest, rmed = oracle.distinctive_descriptors(desc, off)
     assert np.array_equal(best, rbest) and np.array_equal(med, rmed)
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,kmax", [(480, 752, 1024), (120, 160, 300)])
+def test_stereo_frame_stream_vs_oracle(oracle, H, W, kmax):
+    """BASELINE configs[4]: rfe_stereo_frame_dev (batch-of-2 extraction -> ComputeStereoMatches -> temporal LightGlue against
+    the previous left view, all device resident, keypoint counts never on the host) against the oracle run stage by stage
+    on the same stereo frames; 752x480 is the EuRoC size."""
+    from rover_slam_amd import capi
+    ctx = capi.Context(0)
+    wsp, wlg = Wt.make_superpoint(seed=7), Wt.make_lightglue(seed=11)
+    ctx.set_weights(capi.KIND_SUPERPOINT, wsp)
+    ctx.set_weights(capi.KIND_LIGHTGLUE, wlg)
+    mb, mbf = 0.11, 0.11 * 435.0
+    rng = np.random.default_rng(H)
+    disp, T = 13, 3
+    scene = synth.make_scene(rng, H, W + disp + 8 * T, margin=0)
+    st = capi.StereoStream(ctx, H, W, kmax, mb=mb, mbf=mbf)
+    pad = 24                                                    # device images with a row pitch > W, like a cv::Mat ROI
+    prev = None
+    for t in range(T):
+        x0 = 6 * t
+        left = np.clip(scene[:, x0:x0 + W] + rng.integers(0, 8, (H, W)), 0, 255).astype(np.uint8)
+        right = np.clip(scene[:, x0 + disp:x0 + disp + W] + rng.integers(0, 8, (H, W)), 0, 255).astype(np.uint8)
+        wide = np.full((2, H, W + pad), 255, np.uint8)
+        wide[0, :, :W], wide[1, :, :W] = left, right
+        dimg = ctx.alloc(wide.nbytes).upload(wide)
+        st.push(dimg.ptr, dimg.ptr + H * (W + pad), stride=W + pad)
+        got = st.results()
+        dimg.free()
+        rl, rr = oracle.superpoint(wsp, left, kmax=kmax), oracle.superpoint(wsp, right, kmax=kmax)
+        assert got["n"].tolist() == [rl["n"], rr["n"]]
+        for v, r in ((0, rl), (1, rr)):
+            assert np.array_equal(got["kxy"][v], r["kxy"]) and np.array_equal(got["score"][v], r["score"])
+            assert np.array_equal(got["desc"][v], r["desc"])
+        nl, nr = rl["n"], rr["n"]
+        u_ref, z_ref = oracle.stereo_match(left, right, rl["kxy"][:nl].astype(np.float32), rr["kxy"][:nr].astype(np.float32),
+                                           rl["desc"][:nl], rr["desc"][:nr], mb, mbf)
+        assert np.array_equal(got["u_right"][:nl], u_ref) and np.array_equal(got["depth"][:nl], z_ref)
+        assert (got["u_right"][nl:] == -1).all() and (got["depth"][nl:] == -1).all()
+        assert (u_ref >= 0).sum() > 10
+        if prev is None:
+            assert got["S"] == 0
+        else:
+            lg = oracle.lightglue(wlg, oracle.normalize_keypoints(prev["kxy"][:prev["n"]].astype(np.float32), H, W),
+                                  oracle.normalize_keypoints(rl["kxy"][:nl].astype(np.float32), H, W), prev["desc"][:prev["n"]], rl["desc"][:nl])
+            assert got["S"] == lg["S"] and np.array_equal(got["pairs"][:lg["S"]], lg["pairs"])
+            assert np.abs(got["ms"][:lg["S"]] - lg["ms"]).max() <= 1e-4      # the stated fp32 tolerance of the match scores
+            assert lg["S"] > 10
+        prev = rl
+    # reset starts a new sequence
+    wide = np.ascontiguousarray(np.stack([left, right]))
+    dimg = ctx.alloc(wide.nbytes).upload(wide)
+    st.push(dimg.ptr, dimg.ptr + H * W, reset=True)
+    assert st.results()["S"] == 0
+    dimg.free()
+    st.close()
+    ctx.close()
