@@ -93,7 +93,7 @@ struct rfe_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     bool has_sp = false, has_lg = false;
-    bool opt_lg_fold = false;            // RFE_OPT_LG_FOLD_WO
+    bool opt_lg_fold = true;             // RFE_OPT_LG_FOLD_WO
     rfe::SpWeightsDev sp;                // views into *sp_hold / *lg_hold
     rfe::LgWeightsDev lg;
     std::shared_ptr<void> sp_hold, lg_hold;   // device copies, shared by every ctx of the process that loaded the same blob on the same device

@@ -14,7 +14,8 @@ against a second, unrelated code base.  Differences handled here:
     right/bottom edges).
   * HF LightGlue early-stop / pruning are disabled by driving the layers directly.
 
-usage: python tools/gen_golden.py   (writes tests/golden/sp_*.npz, lg_*.npz)
+usage: python tools/gen_golden.py            (writes tests/golden/sp_{a,b,c}.npz, lg_{a,b}.npz: small cases)
+       python tools/gen_golden.py fullsize   (writes sp_{d,e}.npz, lg_{c,d}.npz: the sizes bench.py runs, top-k path, ragged pair)
 """
 import os
 import sys
@@ -69,6 +70,29 @@ def run_hf_superpoint(m, img_u8):
     return dict(n=int(keep.sum()), kxy=kxy, score=score, desc=desc, scoremap=sc[0].numpy())
 
 
+def run_hf_superpoint_topk(m, img_u8, kmax):
+    """Top-k path (count > Kmax, which every bench frame takes): HF's own functions in HF's own order -- pixel scores +
+    simple_nms, threshold, border removal, torch.topk, descriptor sampling -- driven one by one so that
+    remove_keypoints_from_borders gets the true image size (inside the model it is called with (8H, 8W) and never removes
+    the right / bottom border, which would change WHICH keypoints make the top k)."""
+    from transformers.models.superpoint import modeling_superpoint as MS
+    H, W = img_u8.shape
+    x = torch.from_numpy(img_u8.astype(np.float32) * np.float32(1.0 / 255.0))[None, None]
+    with torch.no_grad():
+        feat = m.encoder(x)[0]
+        dec = m.keypoint_decoder
+        scores = dec._get_pixel_scores(feat)
+        kp = torch.nonzero(scores[0] > dec.keypoint_threshold)
+        sc = scores[0][tuple(kp.t())]
+        kp, sc = MS.remove_keypoints_from_borders(kp, sc, dec.border_removal_distance, H, W)
+        ncand = int(kp.shape[0])
+        kp, sc = MS.top_k_keypoints(kp, sc, kmax)
+        kxy = torch.flip(kp, [1]).to(sc.dtype)
+        desc = m.descriptor_decoder(feat, kxy[None])
+        assert desc.shape == (kxy.shape[0], 256)
+    return dict(n=int(kxy.shape[0]), candidates=ncand, kxy=kxy.round().to(torch.int32).numpy(), score=sc.numpy(), desc=desc.numpy())
+
+
 def hf_lightglue_modules(blob):
     from transformers import LightGlueConfig
     from transformers.models.lightglue import modeling_lightglue as ML
@@ -103,19 +127,30 @@ def hf_lightglue_modules(blob):
 
 
 def run_hf_lightglue(mods, k0n, k1n, d0, d1, thr=0.1):
+    """M != N: both sides are padded to max(M, N) and HF's own masking (additive attention mask in the layers, 0/1 mask
+    in the assignment) hides the padding."""
     ML, pos, layers, assign = mods
-    kp = torch.from_numpy(np.stack([k0n, k1n]))       # [2, N, 2]
-    x = torch.from_numpy(np.stack([d0, d1]))          # [2, N, 256]
+    M, N = len(k0n), len(k1n)
+    L = max(M, N)
+    padk = lambda k: np.concatenate([k, np.zeros((L - len(k), 2), np.float32)])
+    padd = lambda d: np.concatenate([d, np.zeros((L - len(d), 256), np.float32)])
+    kp = torch.from_numpy(np.stack([padk(k0n), padk(k1n)]))       # [2, L, 2]
+    x = torch.from_numpy(np.stack([padd(d0), padd(d1)]))          # [2, L, 256]
+    amask = mask01 = None
+    if M != N:
+        mask01 = torch.zeros(2, L)
+        mask01[0, :M] = 1; mask01[1, :N] = 1
+        amask = ((1.0 - mask01) * torch.finfo(torch.float32).min)[:, None, None, :]
     with torch.no_grad():
         enc = pos(kp)[0]
-        for L in layers:
-            x = L(x, enc, attention_mask=None)[0]
-        scores = assign(x, None)                       # [1, N+1, N+1]
+        for Lyr in layers:
+            x = Lyr(x, enc, attention_mask=amask)[0]
+        scores = assign(x, mask01)                     # [1, L+1, L+1]
         matches, mscores = ML.get_matches_from_scores(scores, thr)
-    m0 = matches[0].numpy()
-    idx = np.nonzero(m0 >= 0)[0]
+    m0 = matches[0].numpy()[:M]
+    idx = np.nonzero((m0 >= 0) & (m0 < N))[0]
     pairs = np.stack([idx, m0[idx]], 1).astype(np.int32)
-    return dict(x0=x[0].numpy(), x1=x[1].numpy(), scores=scores[0, :-1, :-1].numpy(), pairs=pairs,
+    return dict(x0=x[0, :M].numpy(), x1=x[1, :N].numpy(), scores=scores[0, :M, :N].numpy(), pairs=pairs,
                 ms=mscores[0].numpy()[idx])
 
 
@@ -152,5 +187,44 @@ def main():
         print(f"lg_{tag}: n={n} matches={len(hf['pairs'])}")
 
 
+def main_fullsize():
+    """Fixtures at the sizes the benchmark runs: 480x640 and 480x752 SuperPoint through the top-k
+    path (Kmax = 1024) on frame 0 of bench.py's own synthetic stream, LightGlue at M = N = 1024 and a ragged 700 x 1024 pair."""
+    os.makedirs(GOLD, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    wsp = Wt.make_superpoint(seed=7)
+    m = hf_superpoint(wsp, 1024)
+    frames, _ = R.synth.make_frames(2, 480, 640, seed=20240314)        # bench.py rank 0, frames 0 and 1
+    wide, _ = R.synth.make_frames(1, 480, 752, seed=5)
+    for tag, img in (("d", frames[0]), ("e", wide[0])):
+        hf = run_hf_superpoint_topk(m, img, 1024)
+        np.savez_compressed(os.path.join(GOLD, f"sp_{tag}.npz"), image=img, seed=7, dustbin_bias=0.0, kmax=1024, n=hf["n"],
+                            candidates=hf["candidates"], kxy=hf["kxy"], score=hf["score"], desc=hf["desc"])
+        print(f"sp_{tag}: {img.shape} n={hf['n']} of {hf['candidates']} candidates")
+    wlg = Wt.make_lightglue(seed=11)
+    mods = hf_lightglue_modules(wlg)
+    # the recipe of lg_a / lg_b at full size: set 1 = permuted noisy copy of a random unit-vector set 0 (with random
+    # weights two REAL frames yield only a handful of matches; this construction gives several hundred whose lists and
+    # scores can be compared)
+    rng = np.random.default_rng(2024)
+    for tag, M, N in (("c", 1024, 1024), ("d", 700, 1024)):
+        d0 = rng.standard_normal((1024, 256)).astype(np.float32)
+        d0 /= np.linalg.norm(d0, axis=1, keepdims=True)
+        perm = rng.permutation(1024)
+        d1 = d0[perm] + 0.01 * rng.standard_normal((1024, 256)).astype(np.float32)
+        d1 = (d1 / np.linalg.norm(d1, axis=1, keepdims=True)).astype(np.float32)[:N]
+        k0 = rng.uniform(-0.9, 0.9, (1024, 2)).astype(np.float32)
+        k1 = (k0[perm] + 0.02 * rng.standard_normal((1024, 2))).astype(np.float32)[:N]
+        k0, d0 = k0[:M], d0[:M]
+        hf = run_hf_lightglue(mods, k0, k1, d0, d1)
+        np.savez_compressed(os.path.join(GOLD, f"lg_{tag}.npz"), seed=11, k0n=k0, k1n=k1, d0=d0, d1=d1, perm=perm,
+                            x0_rows4=hf["x0"][::4], x1_rows4=hf["x1"][::4], pairs=hf["pairs"], ms=hf["ms"])
+        print(f"lg_{tag}: {M} x {N} matches={len(hf['pairs'])}")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "fullsize":
+        main_fullsize()
+    else:
+        main()
