@@ -1,12 +1,16 @@
 // SuperPoint.h -- compatibility veneer for the name BASELINE.json cites.  The reference's
 // include/SuperPoint.h:18-60 (struct SuperPoint : torch::nn::Module, class SPDetector) is dead code:
 // it needs libtorch, is not in CMakeLists.txt:75-148 and nothing includes it.  This header offers the
-// same entry points on top of librover_fe.so: detect() then getKeyPoints() / computeDescriptors().
+// same entry points on top of librover_fe.so: SPdetect(), and SPDetector::detect() then getKeyPoints() / computeDescriptors()
+// (include/SuperPoint.h:45-57).  `SuperPoint` names the runner class, so `std::shared_ptr<SuperPoint> model` keeps compiling;
+// the torch::Tensor overload of detect() takes the 8-bit grayscale cv::Mat instead.
 #pragma once
 #include <memory>
 #include "Extractors/SPextractor.h"
 
 namespace ORB_SLAM3 {
+
+typedef SuperPointOnnxRunner SuperPoint;   // reference: struct SuperPoint : torch::nn::Module (include/SuperPoint.h:18-43)
 
 class SPDetector {
 public:
@@ -37,5 +41,16 @@ private:
     std::vector<int> sel_;
     cv::Mat desc_;
 };
+
+// include/SuperPoint.h:45: one call -- keypoints with response >= threshold, returns their descriptors [K,256] CV_32F
+inline cv::Mat SPdetect(std::shared_ptr<SuperPoint> model, cv::Mat img, std::vector<cv::KeyPoint>& keypoints, double threshold,
+                        bool nms = true, bool cuda = true) {
+    SPDetector det(model);
+    det.detect(img, cuda);
+    det.getKeyPoints((float)threshold, 0, img.cols, 0, img.rows, keypoints, nms);
+    cv::Mat desc;
+    det.computeDescriptors(keypoints, desc);
+    return desc;
+}
 
 }  // namespace ORB_SLAM3

@@ -17,6 +17,8 @@
 #define CV_32F 5
 #define CV_8UC1 0
 #define CV_32FC1 5
+#define CV_8UC3 16      // depth + ((channels - 1) << 3), as in OpenCV
+#define CV_32FC3 21
 namespace cv {
 struct Point2f {
     float x = 0, y = 0;
@@ -29,7 +31,7 @@ struct Size { int width = 0, height = 0; Size() = default; Size(int w, int h) : 
 struct KeyPoint {
     Point2f pt; float size = 0, angle = -1, response = 0; int octave = 0, class_id = -1;
 };
-// row-major, reference-counted, 1 channel, CV_8U or CV_32F
+// row-major, reference-counted, 1 or 3 interleaved channels, CV_8U or CV_32F
 class Mat {
 public:
     int rows = 0, cols = 0;
@@ -46,8 +48,9 @@ public:
         data = buf_.get();
     }
     int type() const { return type_; }
-    int channels() const { return 1; }
-    size_t elemSize() const { return type_ == CV_32F ? 4 : 1; }
+    int channels() const { return (type_ >> 3) + 1; }
+    int depth() const { return type_ & 7; }
+    size_t elemSize() const { return (size_t)(depth() == CV_32F ? 4 : 1) * channels(); }
     bool empty() const { return data == nullptr || rows * cols == 0; }
     bool isContinuous() const { return step == (size_t)cols * elemSize(); }
     Size size() const { return Size(cols, rows); }

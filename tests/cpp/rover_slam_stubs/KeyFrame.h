@@ -1,0 +1,2 @@
+#pragma once
+namespace ORB_SLAM3 { class KeyFrame {}; }

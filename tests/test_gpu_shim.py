@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("H,W", [(120, 160), (480, 752)])   # small case, and the EuRoC stereo size of BASELINE config 5
 def test_cpp_shims_match_oracle(tmp_path, oracle, H, W):
     exe = str(tmp_path / "shim_driver")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"),
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),   # the reference builds -std=c++14 (CMakeLists.txt:12)
                            os.path.join(ROOT, "tests", "cpp", "shim_driver.cpp"), "-o", exe,
                            "-L" + os.path.join(ROOT, "rover-slam_amd"), "-lrover_fe", "-L/opt/rocm/lib", "-lamdhip64",
                            "-Wl,-rpath," + os.path.join(ROOT, "rover-slam_amd"), "-Wl,-rpath,/opt/rocm/lib"])
@@ -41,9 +41,10 @@ def test_cpp_shims_match_oracle(tmp_path, oracle, H, W):
         kp = np.frombuffer(buf, np.float32, n * 5, off).reshape(n, 5); off += n * 20
         desc = np.frombuffer(buf, np.float32, n * 256, off).reshape(n, 256); off += n * 1024
         ext.append((n, kp, desc))
-    s_frame, s_quirk, m = struct.unpack_from("<iii", buf, off); off += 12
+    s_frame, s_quirk, s_p2f_mat, s_p2f_ptr, m = struct.unpack_from("<iiiii", buf, off); off += 20
     vn_frame = np.frombuffer(buf, np.int32, m, off); off += 4 * m
     vn_quirk = np.frombuffer(buf, np.int32, m, off); off += 4 * m
+    vn_p2f_mat = np.frombuffer(buf, np.int32, m, off); off += 4 * m
     u_right = np.frombuffer(buf, np.float32, m, off); off += 4 * m
     z_depth = np.frombuffer(buf, np.float32, m, off)
     ref = [oracle.superpoint(wsp, frames[i], kmax=200) for i in range(2)]
@@ -55,10 +56,12 @@ def test_cpp_shims_match_oracle(tmp_path, oracle, H, W):
         assert np.array_equal(desc, r_["desc"][:n])
     kp0, kp1 = [r_["kxy"][:r_["n"]].astype(np.float32) for r_ in ref]
     d0, d1 = [r_["desc"][:r_["n"]] for r_ in ref]
-    for (rows, cols), s_got, vn_got in (((H, W), s_frame, vn_frame), ((300, 400), s_quirk, vn_quirk)):
+    # all four MatchingPoints_onnx overloads: Frame (true image size), KeyPoint + Mat, Point2f + Mat, Point2f + float* (300x400 quirk)
+    for (rows, cols), s_got, vn_got in (((H, W), s_frame, vn_frame), ((300, 400), s_quirk, vn_quirk), ((300, 400), s_p2f_mat, vn_p2f_mat),
+                                        ((300, 400), s_p2f_ptr, None)):
         lg = oracle.lightglue(wlg, oracle.normalize_keypoints(kp0, rows, cols), oracle.normalize_keypoints(kp1, rows, cols), d0, d1)
         s_ref, vn_ref = oracle.postprocess_fused(lg["pairs"], lg["ms"], 0.0, len(kp0))
-        assert s_got == s_ref and np.array_equal(vn_got, vn_ref)
+        assert s_got == s_ref and (vn_got is None or np.array_equal(vn_got, vn_ref))
     # Frame::ComputeStereoMatches through include/rfe/stereo_match.h (frames 0 / 1 as left / right view)
     u_ref, z_ref = oracle.stereo_match(frames[0], frames[1], kp0, kp1, d0, d1, 0.11, 0.11 * 435.0)
     assert np.array_equal(u_right, u_ref) and np.array_equal(z_depth, z_ref)
