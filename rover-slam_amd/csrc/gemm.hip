@@ -25,7 +25,7 @@ constexpr int BK = 32, LDT = BK + 1;
 // a single 1024-keypoint pair has only M = 2048 rows, 16 tiles of 128 x 256 would use 16 of the 256 CUs).
 // TEPI: LDS-transposed whole-row epilogue (rotary variant); false = per-lane 4-byte stores.  The residual variant reads
 // R in the D layout (four rows of 128-B segments in flight per step) and adds it after bias / alpha like the oracle.
-template <int MB, int NB, bool TEPI>
+template <int MB, int NB, bool TEPI, bool PFT = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     constexpr int BM = MB * 64, BN = NB * 64;
     __shared__ float lds_ab[(BM + BN) * LDT];   // A tile | B tile; reused for the rotary tables in the epilogue
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     // would otherwise expose a full global-memory round trip: there the next tile's loads are issued before the MFMA
     // loop of the current one (16 VGPRs).  The throughput tiles rely on the other resident workgroups instead
     // (register prefetch measured slower there).
-    constexpr bool PF = (MB == 1);
+    constexpr bool PF = (MB == 1) || PFT;
     float4 ra[A_IT], rb[B_IT];
     auto load_tile = [&](int k0) {
         if (A2t && k0 >= g.K1) {
@@ -239,9 +239,12 @@ void launch_gemm_nt(hipStream_t s, const GemmArgs& g_in) {
     auto tiles = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * batch; };
     static const bool force_tepi = tune_env("RFE_GEMM_TEPI") != nullptr;   // tuning switch
     const bool tepi = force_tepi || g.R != nullptr || g.rope_cs != nullptr;
+    static const bool pft = tune_int("RFE_GEMM_PF", 0) != 0;   // tuning switch: register prefetch also on the 128-row tiles
 #define RFE_GEMM_GO(MB_, NB_, GRID)                                                                  \
     do {                                                                                             \
-        if (tepi) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, true>), GRID, dim3(256), 0, s, g);    \
+        if (pft && MB_ == 2 && tepi) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, true, MB_ == 2>), GRID, dim3(256), 0, s, g);    \
+        else if (pft && MB_ == 2) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, false, MB_ == 2>), GRID, dim3(256), 0, s, g);       \
+        else if (tepi) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, true>), GRID, dim3(256), 0, s, g);    \
         else hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, false>), GRID, dim3(256), 0, s, g);        \
     } while (0)
     // largest tile that still gives every CU a workgroup; small problems (single-pair latency) fall to 64 x 64

@@ -40,7 +40,9 @@ constexpr size_t AT_SPLIT_MAX_ROWS = 8192;    // only problems this small are la
 // SPLIT: split-key variant for latency-bound problems (one pair = 64 (sequence, head, query block) units for 256 CUs and
 // a 2048-MFMA serial chain per wave): blockIdx.y selects one of gridDim.y key ranges, the workgroup writes its
 // unnormalised accumulators and (reference max, sum) to `part`, and lg_attention_combine_kernel merges the ranges.
-template <bool DBUF, int ABL = 0, bool SPLIT = false>
+// PF: single LDS buffer, but the NEXT tile's K/V rows are fetched global->registers right after the barrier that publishes the
+// current tile, so the fetch latency runs under this workgroup's own MFMAs instead of relying on co-resident workgroups.
+template <bool DBUF, int ABL = 0, bool SPLIT = false, bool PF = false>
 __global__ __launch_bounds__(256, 2) void lg_attention_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld, float* __restrict__ out,
     int Lq, int Lk, int nqb, const int* __restrict__ qlen, const int* __restrict__ klen, const int* __restrict__ kv_map,
@@ -116,10 +118,16 @@ __global__ __launch_bounds__(256, 2) void lg_attention_kernel(
         kbeg = (int)blockIdx.y * per;
         kend = kbeg + per < nk ? kbeg + per : nk;
     }
+    if (PF && kbeg < kend) fetch(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += AT_K) {
         const bool more = DBUF && (k0 + AT_K < kend);
         if (DBUF) {
             if (more) fetch(k0 + AT_K);
+        } else if (PF) {
+            __syncthreads();
+            stash(0);
+            __syncthreads();
+            if (k0 + AT_K < kend) fetch(k0 + AT_K);
         } else if (!(ABL & 2) || k0 == 0) {
             __syncthreads();
             fetch(k0);
@@ -419,7 +427,10 @@ void launch_lg_attention(hipStream_t s, const float* q, const float* k, const fl
     if (abl == 2) { hipLaunchKernelGGL((lg_attention_kernel<false, 2>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0, nullptr, nseq); return; }
     if (abl == 3) { hipLaunchKernelGGL((lg_attention_kernel<false, 3>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0, nullptr, nseq); return; }
     static const int prio = tune_int("RFE_ATT_PRIO", 1);   // s_setprio(1) around the MFMA clusters (+0.8 %); RFE_ATT_PRIO=0 disables
-    if (single)
+    static const bool pf = tune_int("RFE_ATT_PF", 0) != 0;   // tuning switch: register prefetch of the next K/V tile
+    if (pf)
+        hipLaunchKernelGGL((lg_attention_kernel<false, 0, false, true>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nullptr, nseq);
+    else if (single)
         hipLaunchKernelGGL(lg_attention_kernel<false>, dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nullptr, nseq);
     else
         hipLaunchKernelGGL(lg_attention_kernel<true>, dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nullptr, nseq);

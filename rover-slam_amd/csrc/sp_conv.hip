@@ -201,12 +201,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
 // Generalised: M-blocks of 2 rows x 16 columns, NW waves of two vertically stacked blocks each, laid out column-major
 // over a TROWS x TCOLS tile.  <5, 4, 80> is the wide tile above (10 waves on 4 SIMDs at 2 workgroups/CU: 3,3,2,2 ->
 // measured only +6 %); <3, 12, 16> tiles 60 x 80 exactly with 3-wave workgroups (4 per CU = 3 waves on every SIMD).
-template <int CIN, bool RELU, int TAG, int CK, int NW, int TROWS, int TCOLS>
+// WSTRIDE: LDS row stride of the staged planes in words, 0 = TCOLS + 2.  An A-fragment read touches 16 consecutive words of
+// row R (lanes 0-15) and of row R + 1 (lanes 16-31): the two runs fall on disjoint banks only when the stride is 16 mod 32
+// (48 for the 16-wide tile, 112 for the 80-wide one); stride 18 / 82 makes lanes 30-31 collide with lanes 0-1 on every read.
+template <int CIN, bool RELU, int TAG, int CK, int NW, int TROWS, int TCOLS, int WSTRIDE = 0>
 __global__ __launch_bounds__(NW * 64, NW == 3 ? 4 : 2) void conv3x3_blk16_kernel(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ out, int H, int W, int COUT) {
     constexpr int KCH = CK * 9, NTHR = NW * 64;
-    constexpr int WIH_ = TROWS + 2, WIW_ = TCOLS + 2, WTWS_ = WIW_, WPLANE_ = WIH_ * WTWS_, WCOLS = TCOLS / 16;
+    constexpr int WIH_ = TROWS + 2, WIW_ = TCOLS + 2, WTWS_ = WSTRIDE ? WSTRIDE : WIW_, WPLANE_ = WIH_ * WTWS_, WCOLS = TCOLS / 16;
+    static_assert(WTWS_ >= WIW_, "row stride must hold the haloed row");
     static_assert(NW * 4 * 16 == TROWS * TCOLS, "NW waves x (4 rows x 16 columns) must cover the tile");
     __shared__ __attribute__((aligned(16))) float lds[CK * WPLANE_ + KCH * NT];
     float* lds_in = lds;
@@ -474,6 +478,15 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
         const bool heads = tag == L_PA || tag == L_DA;
         if ((tall == 1 || (tall == -1 && heads)) && W % 16 == 0 && H % 12 == 0) {
             dim3 gt(W / 16, H / 12, B * (cout / NT));
+            static const int pad = tune_int("RFE_CONV_PAD", 0);   // tuning switch: conflict-free LDS row stride
+            if (pad) {
+                switch (tag) {
+                    case L_4A: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4A, 8, 3, 12, 16, 48>), gt, dim3(192), 0, s, in, wp, bias, out, H, W, cout); return;
+                    case L_4B: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4B, 8, 3, 12, 16, 48>), gt, dim3(192), 0, s, in, wp, bias, out, H, W, cout); return;
+                    case L_PA: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_PA, 8, 3, 12, 16, 48>), gt, dim3(192), 0, s, in, wp, bias, out, H, W, cout); return;
+                    default: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_DA, 8, 3, 12, 16, 48>), gt, dim3(192), 0, s, in, wp, bias, out, H, W, cout); return;
+                }
+            }
             switch (tag) {
                 case L_4A: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4A, 8, 3, 12, 16>), gt, dim3(192), 0, s, in, wp, bias, out, H, W, cout); return;
                 case L_4B: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4B, 8, 3, 12, 16>), gt, dim3(192), 0, s, in, wp, bias, out, H, W, cout); return;
@@ -483,7 +496,10 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
         }
         if ((tall == 2 || tall == -1) && W % 80 == 0 && !heads) {
             dim3 gw(W / 80, (H + 3) / 4, B * (cout / NT));
-            if (tag == L_4A) hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4A, 8, 5, 4, 80>), gw, dim3(320), 0, s, in, wp, bias, out, H, W, cout);
+            static const int padw = tune_int("RFE_CONV_PAD", 0);
+            if (padw && tag == L_4A) hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4A, 8, 5, 4, 80, 112>), gw, dim3(320), 0, s, in, wp, bias, out, H, W, cout);
+            else if (padw) hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4B, 8, 5, 4, 80, 112>), gw, dim3(320), 0, s, in, wp, bias, out, H, W, cout);
+            else if (tag == L_4A) hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4A, 8, 5, 4, 80>), gw, dim3(320), 0, s, in, wp, bias, out, H, W, cout);
             else hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4B, 8, 5, 4, 80>), gw, dim3(320), 0, s, in, wp, bias, out, H, W, cout);
             return;
         }

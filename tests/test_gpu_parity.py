@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from rover_slam_amd import weights as Wt, synth
-from tolerances import LG_SCORE_TOL, LG_SCORE_TOL_SMALL, LG_STATE_TOL, LG_LOGSCORE_TOL, lists_agree
+from tolerances import LG_SCORE_TOL, LG_SCORE_TOL_SMALL, LG_STATE_TOL, LG_LOGSCORE_RTOL, lists_agree
 
 pytestmark = pytest.mark.gpu
 
@@ -165,7 +165,7 @@ def test_lightglue_vs_oracle_and_golden(ctx, oracle, golden_dir, tag):
     r = oracle.lightglue(Wt.make_lightglue(seed=11), k0, k1, d0, d1, debug=True)
     # fp32 tolerance: flash-style online softmax and permuted PV reduction order vs the oracle's plain softmax
     assert np.abs(x0 - r["x0"]).max() < LG_STATE_TOL and np.abs(x1 - r["x1"]).max() < LG_STATE_TOL
-    assert np.abs(sc - r["scores"]).max() < LG_LOGSCORE_TOL   # log-domain assignment scores, |values| up to ~1e2
+    assert np.abs(sc - r["scores"]).max() < LG_LOGSCORE_RTOL * np.abs(r["scores"]).max()   # log-domain assignment scores
     S, pairs, ms = ctx.match(k0[None], k1[None], d0[None], d1[None], [M], [N])
     assert S[0] == r["S"] == len(g["pairs"])
     assert np.array_equal(pairs[0, :S[0]], r["pairs"]) and np.array_equal(pairs[0, :S[0]], g["pairs"])

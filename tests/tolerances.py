@@ -4,17 +4,21 @@ SuperPoint has none: keypoints, scores and descriptors are bit-exact against the
 
 LightGlue match scores are probabilities exp(log-assignment); the log-assignment is a difference of O(30-100)
 similarity logits and their log-sum-exps, so a few fp32 ulps there (6e-6 each at 50) are 1e-4-level in the score.
-Measured at K = 1024 over 40 (weight seed, input) cases, max |score difference| over common matches:
-  oracle (fp32) vs float64 evaluation of the same graph   1.6e-4
-  HIP path vs oracle                                       2.1e-4 (Wo folded into ffn.0, the default) / 1.7e-4 (unfolded)
-  HF transformers (fp32, torch CPU) vs float64             1.2e-4
-i.e. any two fp32 evaluation orders of this graph differ by 1-2e-4; 1e-4 is below the noise floor of fp32 itself at
-this size, and the fold does not change the picture.  Final token states agree to 1e-5 (bar 1e-4).
+Measured at K = 1024 over 40 (weight seed, input) cases (tools/lg_tolerance_study.py -> profiles/r02_lg_tolerance.md),
+max |score difference| over common matches, match lists identical in every case and variant:
+  oracle (fp32) vs float64 evaluation of the same graph   2.6e-4
+  HIP path vs oracle                                       3.2e-4 (Wo folded into ffn.0, the default) / 2.0e-4 (unfolded)
+  HIP path vs float64                                      2.4e-4 (folded) / 1.8e-4 (unfolded)
+  HF transformers (fp32, torch CPU) vs float64             1.2e-4 (the two full-size fixtures)
+i.e. any two fp32 evaluation orders of this graph differ by 1-3e-4 (the case with the largest HIP-vs-oracle figure is the
+one where the ORACLE sits 2.6e-4 from float64 and the HIP path 7e-5): 1e-4 is below the noise floor of fp32 itself at this
+size, and the fold does not change the picture.  Final token states agree to 1e-5 (bar 1e-4).
 """
 LG_SCORE_TOL = 5e-4         # |match score difference|, any keypoint count up to 1024
 LG_SCORE_TOL_SMALL = 1e-4   # <= 256 keypoints per side
 LG_STATE_TOL = 1e-4         # final token states x0 / x1
-LG_LOGSCORE_TOL = 2e-3      # log-domain assignment matrix, |values| up to ~1e2
+LG_LOGSCORE_RTOL = 1e-5     # log-domain assignment matrix relative to its largest magnitude (|values| up to ~450, one fp32
+                            # ulp there is 3e-5; measured 2.4e-3 absolute = 5.4e-6 relative)
 
 
 def lists_agree(pairs_a, ms_a, pairs_b, ms_b, filter_thr=0.1, slack=5e-4):
