@@ -110,6 +110,15 @@ int rfe_extract_u8_dev(rfe_ctx* ctx, const uint8_t* img_dev, int H, int W, int s
                        int Kmax, float thr, int32_t* n_dev, int32_t* kxy_dev, float* score_dev,
                        float* desc_dev);
 
+/* The same with a second descriptor output for the loop-closure side: desc_bin u8 [B,Kmax,256] = desc > 0,
+ * i.e. Frame::binarize_descriptors (src/Frame.cc:1034-1043) written by the sampling kernel itself, ready for
+ * Converter::toDescriptorVector + the DBoW3 vocabulary of Frame::ComputeBoW3 (:1044-1054), which stay on the CPU.
+ * desc_bin may be NULL (= the plain call). */
+int rfe_extract_u8_bin(rfe_ctx* ctx, const uint8_t* img, int H, int W, int stride, int B, int Kmax, float thr, int32_t* n,
+                       int32_t* kxy, float* score, float* desc, uint8_t* desc_bin);
+int rfe_extract_u8_bin_dev(rfe_ctx* ctx, const uint8_t* img_dev, int H, int W, int stride, int B, int Kmax, float thr,
+                           int32_t* n_dev, int32_t* kxy_dev, float* score_dev, float* desc_dev, uint8_t* desc_bin_dev);
+
 /* ---- LightGlue ----
  * P pairs.  k0n/k1n: normalised keypoints [P,Mmax,2] / [P,Nmax,2]; d0/d1: [P,Mmax,256] /
  * [P,Nmax,256]; m/n: [P] valid counts.  filter_thr: in-graph match filter (0.1).

@@ -16,7 +16,7 @@ OPT_LG_FOLD_WO = 1
 EXPORTS = [
     "rfe_init", "rfe_destroy", "rfe_last_error", "rfe_version", "rfe_load_weights", "rfe_set_weights",
     "rfe_weight_count", "rfe_weights_id", "rfe_set_option", "rfe_get_option", "rfe_set_stream", "rfe_synchronize", "rfe_malloc", "rfe_free", "rfe_memcpy_h2d",
-    "rfe_memcpy_d2h", "rfe_extract_u8", "rfe_extract_u8_dev", "rfe_match", "rfe_match_dev", "rfe_match_fused",
+    "rfe_memcpy_d2h", "rfe_extract_u8", "rfe_extract_u8_dev", "rfe_extract_u8_bin", "rfe_extract_u8_bin_dev", "rfe_match", "rfe_match_dev", "rfe_match_fused",
     "rfe_extract_match_stream_dev", "rfe_stereo_match", "rfe_stereo_match_dev", "rfe_stereo_frame_dev", "rfe_l2_distance_matrix", "rfe_binarize_descriptors",
     "rfe_search_candidates", "rfe_distinctive_descriptors",
     "rfe_profile_enable", "rfe_profile_filter", "rfe_profile_reset", "rfe_profile_read",
@@ -53,6 +53,8 @@ lib.rfe_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
 _ext = [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _ip, _ip, _fp, _fp]
 lib.rfe_extract_u8.argtypes = _ext
 lib.rfe_extract_u8_dev.argtypes = _ext
+lib.rfe_extract_u8_bin.argtypes = _ext + [_u8p]
+lib.rfe_extract_u8_bin_dev.argtypes = _ext + [_u8p]
 _mt = [C.c_void_p, _fp, _fp, _fp, _fp, _ip, _ip, C.c_int, C.c_int, C.c_int, C.c_float, _ip, _ip, _fp]
 lib.rfe_match.argtypes = _mt
 lib.rfe_match_dev.argtypes = _mt
@@ -210,8 +212,9 @@ class Context:
         return DevBuf(self, nbytes)
 
     # ---- host-buffer entry points
-    def extract(self, img_u8, kmax=1024, thr=0.0005, pad_cols=0):
-        """img_u8: [B,H,W] or [H,W] uint8 (host).  Returns n[B], kxy[B,Kmax,2], score[B,Kmax], desc[B,Kmax,256].
+    def extract(self, img_u8, kmax=1024, thr=0.0005, pad_cols=0, binarized=False):
+        """img_u8: [B,H,W] or [H,W] uint8 (host).  Returns n[B], kxy[B,Kmax,2], score[B,Kmax], desc[B,Kmax,256]
+        (+ desc_bin u8 [B,Kmax,256] when binarized=True: Frame::binarize_descriptors written by the sampling kernel).
         pad_cols > 0 passes the frames with a row stride of W + pad_cols bytes (like a cv::Mat ROI)."""
         img = np.ascontiguousarray(img_u8, np.uint8)
         if img.ndim == 2:
@@ -226,6 +229,11 @@ class Context:
         kxy = np.zeros((B, kmax, 2), np.int32)
         score = np.zeros((B, kmax), np.float32)
         desc = np.zeros((B, kmax, 256), np.float32)
+        if binarized:
+            dbin = np.zeros((B, kmax, 256), np.uint8)
+            self._chk(lib.rfe_extract_u8_bin(self.h, img.ctypes.data, H, W, stride, B, kmax, thr, n.ctypes.data, kxy.ctypes.data,
+                                             score.ctypes.data, desc.ctypes.data, dbin.ctypes.data))
+            return n, kxy, score, desc, dbin
         self._chk(lib.rfe_extract_u8(self.h, img.ctypes.data, H, W, stride, B, kmax, thr, n.ctypes.data, kxy.ctypes.data,
                                      score.ctypes.data, desc.ctypes.data))
         return n, kxy, score, desc

@@ -506,7 +506,7 @@ int sp_forward_maps(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, in
 }
 
 int sp_forward(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, int B, int Kmax, float thr,
-               int32_t* n, int32_t* kxy, float* score, float* desc) {
+               int32_t* n, int32_t* kxy, float* score, float* desc, uint8_t* desc_bin = nullptr) {
     SpBuffers b;
     bool forked;
     int rc = sp_forward_maps(c, img, H, W, stride, B, b, false, forked);
@@ -514,24 +514,34 @@ int sp_forward(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, int B, 
     { ProfScope p(c, "sp_select");
       launch_select(c->stream, b.nmap, B, H, W, Kmax, thr, b.cand_score, b.cand_idx, n, kxy, score, (int32_t*)b.ss /*NMS scratch, free by now*/);
       if (forked) RFE_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));   // descriptor map ready
-      launch_desc_sample(c->stream, b.dmap, B, H / 8, W / 8, H, W, n, kxy, Kmax, desc); }
+      launch_desc_sample(c->stream, b.dmap, B, H / 8, W / 8, H, W, n, kxy, Kmax, desc, desc_bin); }
     RFE_HIP(c, hipGetLastError());
     return RFE_OK;
 }
 
 }  // namespace
 
-extern "C" int rfe_extract_u8_dev(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, int B, int Kmax,
-                                  float thr, int32_t* n, int32_t* kxy, float* score, float* desc) {
+extern "C" int rfe_extract_u8_bin_dev(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, int B, int Kmax,
+                                      float thr, int32_t* n, int32_t* kxy, float* score, float* desc, uint8_t* desc_bin) {
     int rc = sp_check(c, H, W, B, Kmax);
     if (rc) return rc;
     if (!img || !n || !kxy || !score || !desc || stride < W) return fail(c, RFE_ERR_INVALID, "extract: null pointer or stride < W");
     RFE_HIP(c, hipSetDevice(c->device));
-    return sp_forward(c, img, H, W, stride, B, Kmax, thr, n, kxy, score, desc);
+    return sp_forward(c, img, H, W, stride, B, Kmax, thr, n, kxy, score, desc, desc_bin);
+}
+
+extern "C" int rfe_extract_u8_dev(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, int B, int Kmax,
+                                  float thr, int32_t* n, int32_t* kxy, float* score, float* desc) {
+    return rfe_extract_u8_bin_dev(c, img, H, W, stride, B, Kmax, thr, n, kxy, score, desc, nullptr);
 }
 
 extern "C" int rfe_extract_u8(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, int B, int Kmax, float thr,
                               int32_t* n, int32_t* kxy, float* score, float* desc) {
+    return rfe_extract_u8_bin(c, img, H, W, stride, B, Kmax, thr, n, kxy, score, desc, nullptr);
+}
+
+extern "C" int rfe_extract_u8_bin(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, int B, int Kmax, float thr,
+                                  int32_t* n, int32_t* kxy, float* score, float* desc, uint8_t* desc_bin) {
     int rc = sp_check(c, H, W, B, Kmax);
     if (rc) return rc;
     if (!img || !n || !kxy || !score || !desc || stride < W) return fail(c, RFE_ERR_INVALID, "extract: null pointer or stride < W");
@@ -540,13 +550,15 @@ extern "C" int rfe_extract_u8(rfe_ctx* c, const uint8_t* img, int H, int W, int 
     // only W bytes of every row are read (B*H*stride bytes from the first pixel would run past a ROI at the bottom of
     // its parent buffer)
     const size_t ib = al((size_t)B * H * W), nb = al((size_t)B * 4), kb = al((size_t)B * Kmax * 8),
-                 sb = al((size_t)B * Kmax * 4), db = al((size_t)B * Kmax * 1024);
-    if ((rc = ensure_ws(c, &c->ws_io, &c->ws_io_bytes, ib + nb + kb + sb + db))) return rc;
+                 sb = al((size_t)B * Kmax * 4), db = al((size_t)B * Kmax * 1024), bb = desc_bin ? al((size_t)B * Kmax * 256) : 0;
+    if ((rc = ensure_ws(c, &c->ws_io, &c->ws_io_bytes, ib + nb + kb + sb + db + bb))) return rc;
     char* p = (char*)c->ws_io;
     uint8_t* d_img = (uint8_t*)p; int32_t* d_n = (int32_t*)(p + ib); int32_t* d_k = (int32_t*)(p + ib + nb);
     float* d_s = (float*)(p + ib + nb + kb); float* d_d = (float*)(p + ib + nb + kb + sb);
     RFE_HIP(c, hipMemcpy2DAsync(d_img, (size_t)W, img, (size_t)stride, (size_t)W, (size_t)B * H, hipMemcpyHostToDevice, c->stream));
-    if ((rc = sp_forward(c, d_img, H, W, W, B, Kmax, thr, d_n, d_k, d_s, d_d))) return rc;
+    uint8_t* d_b = desc_bin ? (uint8_t*)(p + ib + nb + kb + sb + db) : nullptr;
+    if ((rc = sp_forward(c, d_img, H, W, W, B, Kmax, thr, d_n, d_k, d_s, d_d, d_b))) return rc;
+    if (desc_bin) RFE_HIP(c, hipMemcpyAsync(desc_bin, d_b, (size_t)B * Kmax * 256, hipMemcpyDeviceToHost, c->stream));
     RFE_HIP(c, hipMemcpyAsync(n, d_n, (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
     RFE_HIP(c, hipMemcpyAsync(kxy, d_k, (size_t)B * Kmax * 8, hipMemcpyDeviceToHost, c->stream));
     RFE_HIP(c, hipMemcpyAsync(score, d_s, (size_t)B * Kmax * 4, hipMemcpyDeviceToHost, c->stream));

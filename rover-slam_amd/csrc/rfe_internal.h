@@ -156,7 +156,7 @@ void launch_select(hipStream_t s, const float* nms, int B, int H, int W, int Kma
                    int32_t* chunk_cnt /*B * ceil(H*W/4096) ints of scratch*/);
 void launch_descmap_norm(hipStream_t s, float* dmap, int64_t cells);
 void launch_desc_sample(hipStream_t s, const float* dmap, int B, int Hc, int Wc, int H, int W,
-                        const int32_t* n, const int32_t* kxy, int Kmax, float* desc);
+                        const int32_t* n, const int32_t* kxy, int Kmax, float* desc, uint8_t* desc_bin /*optional u8 [B,Kmax,256] = desc > 0*/);
 // lg_kernels.hip
 void launch_lg_posenc(hipStream_t s, const float* kn, const float* wr, int rows, float* cs, float* sn);
 void launch_lg_attention(hipStream_t s, const float* q, const float* k, const float* v, int ld /*row stride of q,k,v*/,

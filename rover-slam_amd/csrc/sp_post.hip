@@ -382,13 +382,16 @@ void launch_descmap_norm(hipStream_t s, float* dmap, int64_t cells) {
 // descriptor map at ((x-3.5)/(W-4.5), (y-3.5)/(H-4.5)), then L2 normalise.
 __global__ __launch_bounds__(256) void desc_sample_kernel(const float* __restrict__ dmap, int Hc, int Wc, int H, int W,
                                                           const int32_t* __restrict__ n, const int32_t* __restrict__ kxy,
-                                                          int Kmax, float* __restrict__ desc) {
+                                                          int Kmax, float* __restrict__ desc, uint8_t* __restrict__ desc_bin) {
     const int b = blockIdx.y;
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (k >= Kmax) return;
     const int lane = threadIdx.x & 63;
     float4* o = reinterpret_cast<float4*>(desc + ((size_t)b * Kmax + k) * 256) + lane;
-    if (k >= n[b]) { *o = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+    // optional second output: Frame::binarize_descriptors (src/Frame.cc:1034-1043, cv::threshold(row, 0, 1, THRESH_BINARY)):
+    // u8 [K,256] = desc > 0, what ComputeBoW3 hands to the DBoW3 vocabulary -- written here so that no second pass reads desc
+    uchar4* ob = desc_bin ? reinterpret_cast<uchar4*>(desc_bin + ((size_t)b * Kmax + k) * 256) + lane : nullptr;
+    if (k >= n[b]) { *o = make_float4(0.f, 0.f, 0.f, 0.f); if (ob) *ob = make_uchar4(0, 0, 0, 0); return; }
     const int x = kxy[((size_t)b * Kmax + k) * 2], y = kxy[((size_t)b * Kmax + k) * 2 + 1];
     const float gx = (((float)x - 3.5f) / ((float)W - 4.5f)) * 2.0f - 1.0f;
     const float gy = (((float)y - 3.5f) / ((float)H - 4.5f)) * 2.0f - 1.0f;
@@ -413,10 +416,11 @@ __global__ __launch_bounds__(256) void desc_sample_kernel(const float* __restric
     const float d = fmaxf(sqrtf(wave_sumsq256(v)), 1e-12f);
     v.x = v.x / d; v.y = v.y / d; v.z = v.z / d; v.w = v.w / d;
     *o = v;
+    if (ob) *ob = make_uchar4(v.x > 0.f, v.y > 0.f, v.z > 0.f, v.w > 0.f);
 }
 void launch_desc_sample(hipStream_t s, const float* dmap, int B, int Hc, int Wc, int H, int W, const int32_t* n,
-                        const int32_t* kxy, int Kmax, float* desc) {
-    hipLaunchKernelGGL(desc_sample_kernel, dim3((Kmax + 3) / 4, B), dim3(256), 0, s, dmap, Hc, Wc, H, W, n, kxy, Kmax, desc);
+                        const int32_t* kxy, int Kmax, float* desc, uint8_t* desc_bin) {
+    hipLaunchKernelGGL(desc_sample_kernel, dim3((Kmax + 3) / 4, B), dim3(256), 0, s, dmap, Hc, Wc, H, W, n, kxy, Kmax, desc, desc_bin);
 }
 
 }  // namespace rfe

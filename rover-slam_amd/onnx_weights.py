@@ -7,8 +7,12 @@ UNVALIDATED AGAINST THE REAL BLOBS: both files are missing from the reference ch
 (.MISSING_LARGE_BLOBS:4-5).  The tensor naming assumed here is that of the public SuperPoint / LightGlue
 PyTorch modules the LightGlue-ONNX style exports are traced from (`conv1a.weight` ..., `transformers.{i}.
 self_attn.Wqkv` ...); Linear weights that the exporter turned into anonymous MatMul constants are recovered
-through the graph (MatMul -> Add(bias with the parameter's name), or Gemm).  `tests/test_onnx_weights.py`
-exercises reader and mapping on ONNX files written by the test itself with exactly that naming; when a real
+through the graph (MatMul -> Add(bias with the parameter's name), or Gemm).  Files that went through onnx-simplifier
+keep no parameter names at all (initializers renamed to numeric ids, MatMul + Add fused into Gemm, weights stored
+[in,out] or [out,in] according to transB): for those the Linear layers are taken in order of FIRST USE in the
+(topologically sorted) node list and checked, one by one, against the shape sequence of the published LightGlue graph;
+the first disagreement is reported with its position, the expected and the found shape -- nothing is guessed past it.
+`tests/test_onnx_weights.py` exercises reader and both mappings on ONNX files written by the test itself; when a real
 file deviates, `convert_*` raises and lists what it could not place.
 
 Only a protobuf *wire-format* reader is implemented (ModelProto.graph.{initializer,node}); external-data
@@ -111,7 +115,7 @@ def read_model(path):
                 if arr is not None:
                     inits[name] = arr
             elif gfn == 1 and gwt == 2:  # GraphProto.node
-                node = dict(op="", inputs=[], outputs=[], name="")
+                node = dict(op="", inputs=[], outputs=[], name="", attrs={})
                 for nfn, nwt, nv in _fields(gv):
                     if nfn == 1:
                         node["inputs"].append(bytes(nv).decode())
@@ -121,6 +125,15 @@ def read_model(path):
                         node["name"] = bytes(nv).decode()
                     elif nfn == 4:
                         node["op"] = bytes(nv).decode()
+                    elif nfn == 5 and nwt == 2:   # AttributeProto: integer attributes only (transB, axis ...)
+                        aname, aval = "", None
+                        for afn, awt, av in _fields(nv):
+                            if afn == 1:
+                                aname = bytes(av).decode()
+                            elif afn == 3 and awt == 0:
+                                aval = av
+                        if aval is not None:
+                            node["attrs"][aname] = aval
                 nodes.append(node)
     return inits, nodes
 
@@ -144,6 +157,64 @@ def _linears_from_graph(inits, nodes):
             if w is not None and w.ndim == 2:
                 # Gemm keeps PyTorch's [out,in] with transB=1; if the exporter stored [in,out] the shapes tell
                 out[n["inputs"][2][:-5]] = (w if w.shape[0] == b.shape[0] else np.ascontiguousarray(w.T), b)
+    return out
+
+
+def _linears_in_order_of_use(inits, nodes):
+    """Name-free view of the graph: every Linear parameter set, once, in order of first use in the node list, as
+    (W [out,in], bias or None, where).  Gemm: B is [out,in] when transB = 1, [in,out] otherwise (ONNX semantics);
+    MatMul: the constant operand is W^T; its bias is the 1-D constant of the Add that consumes the product."""
+    consumers = {}
+    for n in nodes:
+        for i in n["inputs"]:
+            consumers.setdefault(i, []).append(n)
+    seen, out = set(), []
+    for idx, n in enumerate(nodes):
+        if n["op"] == "Gemm" and len(n["inputs"]) >= 2 and n["inputs"][1] in inits and inits[n["inputs"][1]].ndim == 2:
+            wn = n["inputs"][1]
+            if wn in seen:
+                continue
+            seen.add(wn)
+            w = inits[wn] if n["attrs"].get("transB", 0) == 1 else inits[wn].T
+            b = inits.get(n["inputs"][2]) if len(n["inputs"]) >= 3 else None
+            out.append((np.ascontiguousarray(w), b, f"node {idx} Gemm({wn})"))
+        elif n["op"] == "MatMul":
+            wn = [i for i in n["inputs"] if i in inits and inits[i].ndim == 2]
+            if len(wn) != 1 or wn[0] in seen:
+                continue
+            seen.add(wn[0])
+            b = None
+            for c in consumers.get(n["outputs"][0] if n["outputs"] else "", []):
+                if c["op"] == "Add":
+                    cb = [i for i in c["inputs"] if i in inits and inits[i].ndim == 1]
+                    if len(cb) == 1:
+                        b = inits[cb[0]]
+            out.append((np.ascontiguousarray(inits[wn[0]].T), b, f"node {idx} MatMul({wn[0]})"))
+    return out
+
+
+def _layernorms_in_order_of_use(inits, nodes, width=512):
+    """(gamma, beta) of every LayerNorm(width), once, in order of first use: LayerNormalization nodes, or the decomposed
+    form's Mul(x_hat, gamma) -> Add(beta) with two 1-D constants of that width."""
+    consumers = {}
+    for n in nodes:
+        for i in n["inputs"]:
+            consumers.setdefault(i, []).append(n)
+    seen, out = set(), []
+    for n in nodes:
+        if n["op"] == "LayerNormalization" and len(n["inputs"]) >= 3 and n["inputs"][1] in inits and inits[n["inputs"][1]].shape == (width,):
+            if n["inputs"][1] not in seen:
+                seen.add(n["inputs"][1])
+                out.append((inits[n["inputs"][1]], inits[n["inputs"][2]]))
+        elif n["op"] == "Mul":
+            g = [i for i in n["inputs"] if i in inits and inits[i].shape == (width,)]
+            if len(g) == 1 and g[0] not in seen:
+                for c in consumers.get(n["outputs"][0] if n["outputs"] else "", []):
+                    bb = [i for i in c["inputs"] if c["op"] == "Add" and i in inits and inits[i].shape == (width,)]
+                    if len(bb) == 1:
+                        seen.add(g[0])
+                        out.append((inits[g[0]], inits[bb[0]]))
+                        break
     return out
 
 
@@ -203,6 +274,9 @@ def convert_lightglue(path, n_layers=Wt.LG_LAYERS):
     def put(name, arr):
         t[name] = np.asarray(arr, np.float32)
 
+    named = any(k.startswith("transformers.") for k in inits)
+    if not named:
+        return _convert_lightglue_by_structure(path, inits, nodes, n_layers)
     try:
         wr = inits.get("posenc.Wr.weight")
         if wr is None:   # bias-free Linear: anonymous MatMul constant [2,32]
@@ -243,6 +317,60 @@ def convert_lightglue(path, n_layers=Wt.LG_LAYERS):
         blob[off:off + arr.size] = arr.ravel()
     if missing:
         raise ValueError(f"{path}: cannot place LightGlue tensors {missing[:12]}...; linears recovered: {sorted(lin)[:20]}")
+    return blob
+
+
+def _convert_lightglue_by_structure(path, inits, nodes, n_layers):
+    """No parameter names survive (onnx-simplifier output): Linear layers in order of first use against the shape sequence
+    of the published graph -- posenc (32x2, no bias); per layer self {Wqkv 768x256, out_proj 256x256, ffn.0 512x512,
+    ffn.3 256x512} then cross {to_qk, to_v, to_out 256x256, ffn.0 512x512, ffn.3 256x512}; final_proj 256x256,
+    matchability 1x256 -- and LayerNorm(512) pairs in order of first use (self, cross per layer)."""
+    lins = _linears_in_order_of_use(inits, nodes)
+    lns = _layernorms_in_order_of_use(inits, nodes)
+    expect = [("posenc.Wr", None, (32, 2), False)]
+    for l in range(n_layers):
+        p = f"layers.{l}."
+        expect += [(p + "self.Wqkv", p + "self.bqkv", (768, 256), True), (p + "self.Wo", p + "self.bo", (256, 256), True),
+                   (p + "self.W1", p + "self.b1", (512, 512), True), (p + "self.W2", p + "self.b2", (256, 512), True),
+                   (p + "cross.Wqk", p + "cross.bqk", (256, 256), True), (p + "cross.Wv", p + "cross.bv", (256, 256), True),
+                   (p + "cross.Wo", p + "cross.bo", (256, 256), True), (p + "cross.W1", p + "cross.b1", (512, 512), True),
+                   (p + "cross.W2", p + "cross.b2", (256, 512), True)]
+    expect += [("final_proj.W", "final_proj.b", (256, 256), True), ("matchability.w", "matchability.b", (1, 256), True)]
+    problems = []
+    if len(lins) != len(expect):
+        problems.append(f"{len(lins)} Linear layers in the graph, the published {n_layers}-layer LightGlue has {len(expect)}")
+    t = {}
+    for pos, (wname, bname, shape, has_bias) in enumerate(expect):
+        if pos >= len(lins):
+            problems.append(f"Linear #{pos} ({wname} {shape}): graph has no more Linear layers")
+            break
+        w, b, where = lins[pos]
+        if tuple(w.shape) != shape or (has_bias and (b is None or b.shape != (shape[0],))):
+            problems.append(f"Linear #{pos}: expected {wname} {shape}{' + bias' if has_bias else ''}, found {tuple(w.shape)}"
+                            f"{'' if b is None else ' + bias ' + str(tuple(b.shape))} at {where}")
+            break          # everything after a disagreement would be guesswork
+        if wname.endswith("self.Wqkv"):
+            w, b = _deinterleave_qkv(w, b)
+        t[wname] = w.reshape(256) if wname == "matchability.w" else w
+        if bname:
+            t[bname] = b.reshape(-1)
+    if len(lns) != 2 * n_layers:
+        problems.append(f"{len(lns)} LayerNorm(512) parameter pairs found, expected {2 * n_layers}")
+    else:
+        for l in range(n_layers):
+            for j, tag in enumerate(("self", "cross")):
+                t[f"layers.{l}.{tag}.ln_g"], t[f"layers.{l}.{tag}.ln_b"] = lns[2 * l + j]
+    man, n = Wt.lg_manifest()
+    blob = np.empty(n, np.float32)
+    if not problems:
+        for name, off, shape in man:
+            arr = t.get(name)
+            if arr is None or tuple(arr.shape) != tuple(shape):
+                problems.append(f"{name}: not placed")
+                continue
+            blob[off:off + arr.size] = np.asarray(arr, np.float32).ravel()
+    if problems:
+        raise ValueError(f"{path}: cannot place LightGlue tensors by structure (no parameter names in the file): " + "; ".join(problems[:6]))
     return blob
 
 

@@ -33,9 +33,12 @@ def _tensor(name, arr):
     return body
 
 
-def _node(op, inputs, outputs, name=""):
+def _node(op, inputs, outputs, name="", attrs=None):
     body = b"".join(_ld(1, i.encode()) for i in inputs) + b"".join(_ld(2, o.encode()) for o in outputs)
-    return body + _ld(3, name.encode()) + _ld(4, op.encode())
+    body += _ld(3, name.encode()) + _ld(4, op.encode())
+    for k, v in (attrs or {}).items():        # AttributeProto{name = 1, i = 3, type = 20 (INT = 2)}
+        body += _ld(5, _ld(1, k.encode()) + _vi((3 << 3) | 0) + _vi(v) + _vi((20 << 3) | 0) + _vi(2))
+    return body
 
 
 def _model(initializers, nodes):
@@ -107,6 +110,74 @@ def test_lightglue_roundtrip(tmp_path):
     path.write_bytes(_model(inits, nodes))
     got = OW.convert_lightglue(str(path))
     assert np.array_equal(got, blob)
+
+
+def _simplified_lightglue(t, drop=None, extra_first=False):
+    """A file shaped like onnx-simplifier output: every initializer renamed to a numeric id, no node names, Linear layers
+    as Gemm (alternating transB = 1 with [out,in] and transB = 0 with [in,out] constants), LayerNormalization nodes, the
+    self block's weights used twice (image 0, image 1), nodes in execution order."""
+    inits, nodes, cnt, flip = [], [], [0], [0]
+
+    def const(arr):
+        cnt[0] += 1
+        inits.append((str(cnt[0]), np.ascontiguousarray(arr, np.float32)))
+        return str(cnt[0])
+
+    def gemm(w, b, uses=1):
+        flip[0] ^= 1
+        tb = flip[0]
+        wn, bn = const(w if tb else w.T), const(b)
+        for u in range(uses):
+            nodes.append(_node("Gemm", [f"x{cnt[0]}_{u}", wn, bn], [f"y{cnt[0]}_{u}"], "", {"transB": tb} if tb else {"alpha_i": 1}))
+
+    def ln(g, b, uses=1):
+        gn, bn = const(g), const(b)
+        for u in range(uses):
+            nodes.append(_node("LayerNormalization", [f"h{cnt[0]}_{u}", gn, bn], [f"n{cnt[0]}_{u}"], "", {"axis": 1}))
+
+    if extra_first:
+        gemm(np.zeros((256, 256), np.float32), np.zeros(256, np.float32))
+    wr = const(t["posenc.Wr"].T)
+    nodes.append(_node("MatMul", ["kpts", wr], ["theta"]))
+    for l in range(Wt.LG_LAYERS):
+        p = f"layers.{l}."
+        steps = [("self.Wqkv", "self.bqkv", 2), ("self.Wo", "self.bo", 2), ("self.W1", "self.b1", 2), "ln_self", ("self.W2", "self.b2", 2),
+                 ("cross.Wqk", "cross.bqk", 2), ("cross.Wv", "cross.bv", 2), ("cross.Wo", "cross.bo", 2), ("cross.W1", "cross.b1", 2), "ln_cross",
+                 ("cross.W2", "cross.b2", 2)]
+        for st in steps:
+            if st == "ln_self":
+                ln(t[p + "self.ln_g"], t[p + "self.ln_b"], 2)
+            elif st == "ln_cross":
+                ln(t[p + "cross.ln_g"], t[p + "cross.ln_b"], 2)
+            elif (l, st[0]) != drop:
+                w, b = t[p + st[0]], t[p + st[1]]
+                if st[0] == "self.Wqkv":
+                    w, b = _interleave_qkv(w, b)
+                gemm(w, b, st[2])
+    gemm(t["final_proj.W"], t["final_proj.b"], 2)
+    gemm(t["matchability.w"].reshape(1, 256), t["matchability.b"], 2)
+    return _model(inits, nodes)
+
+
+def test_lightglue_simplifier_style_file(tmp_path):
+    """initializers renamed to numeric ids, Gemm instead of MatMul + Add, transposed weights."""
+    blob = Wt.make_lightglue(seed=6)
+    t = _named(blob, Wt.lg_manifest()[0])
+    path = tmp_path / "lightglue_sim.onnx"
+    path.write_bytes(_simplified_lightglue(t))
+    inits, nodes = OW.read_model(str(path))
+    assert all(k.isdigit() for k in inits) and {n["op"] for n in nodes} == {"Gemm", "LayerNormalization", "MatMul"}
+    assert any(n["attrs"].get("transB") == 1 for n in nodes) and any("transB" not in n["attrs"] for n in nodes if n["op"] == "Gemm")
+    assert np.array_equal(OW.convert_lightglue(str(path)), blob)
+    # a file that deviates is not guessed at: the first Linear that does not fit is named with position and shapes
+    path.write_bytes(_simplified_lightglue(t, drop=(3, "cross.Wv")))
+    with pytest.raises(ValueError) as e:
+        OW.convert_lightglue(str(path))
+    msg = str(e.value)
+    assert "83 Linear layers in the graph" in msg and "has 84" in msg and "expected layers.3.cross.Wo (256, 256) + bias, found (512, 512)" in msg
+    path.write_bytes(_simplified_lightglue(t, extra_first=True))     # e.g. an input projection the published graph does not have
+    with pytest.raises(ValueError, match=r"Linear #0: expected posenc.Wr \(32, 2\), found \(256, 256\)"):
+        OW.convert_lightglue(str(path))
 
 
 def test_lightglue_incomplete_file_is_reported(tmp_path):

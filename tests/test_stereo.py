@@ -83,6 +83,13 @@ def test_distance_matrix_and_binarize():
     bits = np.empty((37, 256), np.uint8)
     ctx._chk(capi.lib.rfe_binarize_descriptors(ctx.h, a.ctypes.data, 37, bits.ctypes.data))
     assert np.array_equal(bits, (a > 0).astype(np.uint8))
+    # the same bits as a second output of the extractor itself (no second pass over the descriptors): Frame::binarize_descriptors
+    ctx.set_weights(capi.KIND_SUPERPOINT, Wt.make_superpoint(seed=7, dustbin_bias=5.0))    # K < Kmax: padding rows too
+    frames, _ = synth.make_frames(2, 120, 160, seed=3)
+    n, kxy, score, desc, dbin = ctx.extract(frames, kmax=300, binarized=True)
+    n2, kxy2, score2, desc2 = ctx.extract(frames, kmax=300)
+    assert np.array_equal(desc, desc2) and np.array_equal(kxy, kxy2) and n.min() > 10 and n.max() < 300
+    assert np.array_equal(dbin, (desc > 0).astype(np.uint8)) and 0.2 < dbin[0, :n[0]].mean() < 0.8
     ctx.close()
 
 

@@ -33,7 +33,7 @@ def main():
             try:
                 d = json.loads(r.stdout.strip().splitlines()[-1])
             except Exception:
-                print(f"{name}: FAILED rc={r.returncode} {r.stderr[-400:]}", flush=True)
+                print(f"{name}: FAILED rc={r.returncode} {r.stderr.strip().splitlines()[-1][:300] if r.stderr.strip() else ''}", flush=True)
                 continue
             st = d["stages"]
             rows.append((name, d["value"], d["ms_per_step"], {k: st[k]["ms_per_step"] for k in STAGES if k in st}))
