@@ -47,14 +47,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     float* C = g.C + (size_t)z * g.sC;
 
     f32x16 acc[MB][NB];
+    // rinit: the residual joins the bias in the accumulator initialisation (x + b) + sum instead of x + (b + sum): the
+    // epilogue has nothing left to read (only valid with alpha = 1 and no ReLU; changes the last-bit rounding of the sum)
+    const bool rinit = TEPI && g.rinit && g.R && !g.rope_cs;
+    const float* Rz0 = rinit ? g.R + (size_t)z * g.sR : nullptr;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int n = n0 + (wn * NB + nb) * 32 + i;
         const float bv = (g.bias && n < g.N) ? g.bias[n] : 0.f;
+        const int nc = n < g.N ? n : g.N - 1;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = bv;
+            for (int r = 0; r < 16; ++r) {
+                float v0 = bv;
+                if (TEPI && rinit) {
+                    int m = m0 + (wm * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    m = m < M ? m : M - 1;
+                    v0 = Rz0[(size_t)m * g.ldr + nc] + bv;
+                }
+                acc[mb][nb][r] = v0;
+            }
     }
 
     // staging: thread -> (row = tid/8 + 32*it, 4 consecutive k).  Rows past the M / N edge are CLAMPED
@@ -130,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     }
 
     if (!TEPI || (g.rend && g.R && !g.rope_cs)) {   // plain bias (+alpha, +ReLU, +residual) epilogue: 128-B coalesced accesses straight from the D layout
-        const float* Rz = (TEPI && g.R) ? g.R + (size_t)z * g.sR : nullptr;
+        const float* Rz = (TEPI && g.R && !rinit) ? g.R + (size_t)z * g.sR : nullptr;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -235,6 +248,8 @@ void launch_gemm_nt(hipStream_t s, const GemmArgs& g_in) {
     static const int rend_on = tune_int("RFE_GEMM_REND", 1);   // A/B switch, see profiles/r01_pmc.md
     GemmArgs g = g_in;
     g.rend = rend_on;
+    static const int rinit_on = tune_int("RFE_GEMM_RINIT", 0);   // A/B switch
+    g.rinit = rinit_on && g.alpha == 1.0f && !g.relu;
     const int batch = g.batch > 0 ? g.batch : 1;
     auto tiles = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * batch; };
     static const bool force_tepi = tune_env("RFE_GEMM_TEPI") != nullptr;   // tuning switch

@@ -40,16 +40,21 @@ constexpr size_t AT_SPLIT_MAX_ROWS = 8192;    // only problems this small are la
 // SPLIT: split-key variant for latency-bound problems (one pair = 64 (sequence, head, query block) units for 256 CUs and
 // a 2048-MFMA serial chain per wave): blockIdx.y selects one of gridDim.y key ranges, the workgroup writes its
 // unnormalised accumulators and (reference max, sum) to `part`, and lg_attention_combine_kernel merges the ranges.
-// PF: single LDS buffer, but the NEXT tile's K/V rows are fetched global->registers right after the barrier that publishes the
-// current tile, so the fetch latency runs under this workgroup's own MFMAs instead of relying on co-resident workgroups.
-template <bool DBUF, int ABL = 0, bool SPLIT = false, bool PF = false>
-__global__ __launch_bounds__(256, 2) void lg_attention_kernel(
+// ROPE: the LightGlue rotary encoding of the self blocks is applied HERE, to the Q fragment as it is loaded and to every K tile
+// as it is staged -- (t0, t1) -> (t0 c - t1 s, t1 c + t0 s) on adjacent pairs (2f, 2f+1), c / s = rope_cs / rope_sn[row][f],
+// the same three fp32 operations the qkv projection's epilogue used to apply (bit-identical results) -- so that the
+// projection GEMM keeps its plain coalesced epilogue.  K rows are rotated once per staging workgroup (8 query blocks per
+// (sequence, head) = 8x redundant VALU work, ~1 % of the MFMA time; the tables are 128 B per row and L2 resident).
+// Variants that did not pay (double-buffered LDS, register prefetch of the next tile, 64 queries per wave, 256-query
+// workgroups) are recorded in profiles/r01_pmc.md and profiles/r02_pmc.md.
+template <int ABL = 0, bool SPLIT = false, bool ROPE = false>
+__global__ __launch_bounds__(256, 4) void lg_attention_kernel(   // 4 workgroups per CU: at most 128 VGPRs
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld, float* __restrict__ out,
     int Lq, int Lk, int nqb, const int* __restrict__ qlen, const int* __restrict__ klen, const int* __restrict__ kv_map,
-    int prio, float* __restrict__ part, int nseq_total) {
-    // K/V tiles double buffered in LDS; the next tile is prefetched global->registers under the MFMAs
-    __shared__ float Ks[DBUF ? 2 : 1][AT_K * AT_LDK];
-    __shared__ float Vs[DBUF ? 2 : 1][AT_K * 64];
+    int prio, float* __restrict__ part, int nseq_total, const float* __restrict__ rope_cs, const float* __restrict__ rope_sn) {
+    constexpr bool DBUF = false;   // (the double-buffered variant measured 4 % slower; kept out of the build)
+    __shared__ float Ks[1][AT_K * AT_LDK];
+    __shared__ float Vs[1][AT_K * 64];
     // XCD-aware decode (blocks are dealt round-robin to the 8 XCDs): all query blocks of one
     // (sequence, head) run on the same XCD so its K/V (512 KB) is fetched into one L2 only.
     const int Lb = blockIdx.x, xcd = Lb & 7, t_ = Lb >> 3;
@@ -71,11 +76,29 @@ __global__ __launch_bounds__(256, 2) void lg_attention_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int qrow = qb * AT_Q + wave * 32 + j;  // this lane's query (may be >= nq: computed, stored as 0)
-    const float* qp = q + ((size_t)seq * Lq + (qrow < Lq ? qrow : Lq - 1)) * ld + head * 64 + h;
+    const size_t qrow_c = (size_t)seq * Lq + (qrow < Lq ? qrow : Lq - 1);
+    const float* qp = q + qrow_c * ld + head * 64 + h;
     constexpr float kScale = 0.125f * 1.44269504088896341f;  // 1/sqrt(64) * log2(e): softmax in base 2, folded into Q
     float qreg[32];
+    if (ROPE) {   // lane (j, h) keeps component h of every pair: both components are loaded, the rotated one is kept
+        const float2* qp2 = reinterpret_cast<const float2*>(q + qrow_c * ld + head * 64);
+        const float4* cp = reinterpret_cast<const float4*>(rope_cs + qrow_c * 32);
+        const float4* sp = reinterpret_cast<const float4*>(rope_sn + qrow_c * 32);
 #pragma unroll
-    for (int s = 0; s < 32; ++s) qreg[s] = qp[2 * s] * kScale;
+        for (int s4 = 0; s4 < 8; ++s4) {
+            const float4 c4 = cp[s4], n4 = sp[s4];
+            const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, ss[4] = {n4.x, n4.y, n4.z, n4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float2 t = qp2[s4 * 4 + e];
+                const float r0 = t.x * cc[e] - t.y * ss[e], r1 = t.y * cc[e] + t.x * ss[e];
+                qreg[s4 * 4 + e] = (h ? r1 : r0) * kScale;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 32; ++s) qreg[s] = qp[2 * s] * kScale;
+    }
 
     f32x16 o0, o1;
 #pragma unroll
@@ -94,6 +117,13 @@ __global__ __launch_bounds__(256, 2) void lg_attention_kernel(
             if (key < nk) {
                 rk[it] = *reinterpret_cast<const float4*>(kbase + (size_t)key * ld + sdq * 4);
                 rv[it] = *reinterpret_cast<const float4*>(vbase + (size_t)key * ld + sdq * 4);
+                if (ROPE) {   // dims 4 sdq .. 4 sdq + 3 = pairs f = 2 sdq, 2 sdq + 1
+                    const size_t trow = ((size_t)kvseq * Lk + key) * 32 + 2 * sdq;
+                    const float2 c2 = *reinterpret_cast<const float2*>(rope_cs + trow);
+                    const float2 s2 = *reinterpret_cast<const float2*>(rope_sn + trow);
+                    const float4 t = rk[it];
+                    rk[it] = make_float4(t.x * c2.x - t.y * s2.x, t.y * c2.x + t.x * s2.x, t.z * c2.y - t.w * s2.y, t.w * c2.y + t.z * s2.y);
+                }
             }
         }
     };
@@ -118,16 +148,10 @@ __global__ __launch_bounds__(256, 2) void lg_attention_kernel(
         kbeg = (int)blockIdx.y * per;
         kend = kbeg + per < nk ? kbeg + per : nk;
     }
-    if (PF && kbeg < kend) fetch(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += AT_K) {
         const bool more = DBUF && (k0 + AT_K < kend);
         if (DBUF) {
             if (more) fetch(k0 + AT_K);
-        } else if (PF) {
-            __syncthreads();
-            stash(0);
-            __syncthreads();
-            if (k0 + AT_K < kend) fetch(k0 + AT_K);
         } else if (!(ABL & 2) || k0 == 0) {
             __syncthreads();
             fetch(k0);
@@ -223,142 +247,6 @@ __global__ __launch_bounds__(256, 2) void lg_attention_kernel(
     }
 }
 
-// Variant with NQ = 2 query blocks (64 queries) per wave, 256 queries per workgroup: every K / V^T fragment
-// read from LDS feeds two MFMAs, a wave issues 256 MFMAs between barriers instead of 128, and the two
-// independent QK^T chains fill each other's issue gaps.  Same arithmetic per query as the kernel above.
-__global__ __launch_bounds__(256, 2) void lg_attention_q64_kernel(
-    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld, float* __restrict__ out,
-    int Lq, int Lk, int nqb, const int* __restrict__ qlen, const int* __restrict__ klen, const int* __restrict__ kv_map, int nseq_total) {
-    constexpr int NQ = 2, QB = 128 * NQ;
-    __shared__ float Ks[AT_K * AT_LDK];
-    __shared__ float Vs[AT_K * 64];
-    const int Lb = blockIdx.x, xcd = Lb & 7, t_ = Lb >> 3;
-    const int qb = t_ % nqb, unit = (t_ / nqb) * 8 + xcd;
-    if (unit >= 4 * nseq_total) return;
-    const int seq = unit >> 2, head = unit & 3;
-    const int kvseq = kv_map ? kv_map[seq] : seq;
-    const int nq = qlen ? qlen[seq] : Lq;
-    const int nk = klen ? klen[kvseq] : Lk;
-    const int tid = threadIdx.x, lane = tid & 63;
-    if (qb * QB >= nq) {
-        for (int e = tid; e < QB * 64; e += 256) {
-            const int row = qb * QB + (e >> 6);
-            if (row < Lq) out[((size_t)seq * Lq + row) * 256 + head * 64 + (e & 63)] = 0.f;
-        }
-        return;
-    }
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 31, h = lane >> 5;
-    int qrow[NQ];
-    float qreg[NQ][32];
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-        qrow[u] = qb * QB + (wave * NQ + u) * 32 + j;
-        const float* qp = q + ((size_t)seq * Lq + (qrow[u] < Lq ? qrow[u] : Lq - 1)) * ld + head * 64 + h;
-#pragma unroll
-        for (int s = 0; s < 32; ++s) qreg[u][s] = qp[2 * s];
-    }
-    f32x16 o0[NQ], o1[NQ];
-    float m_run[NQ], l_run[NQ];
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-        m_run[u] = -INFINITY; l_run[u] = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[u][r] = 0.f; o1[u][r] = 0.f; }
-    }
-    const float* kbase = k + (size_t)kvseq * Lk * ld + head * 64;
-    const float* vbase = v + (size_t)kvseq * Lk * ld + head * 64;
-    const int skey = tid >> 4, sdq = tid & 15;
-    constexpr float kScale = 0.125f * 1.44269504088896341f;
-    // the next K/V tile is fetched global->registers BEFORE the current tile is multiplied (single LDS buffer):
-    // co-resident workgroups run in phase, so un-prefetched fetch latency would idle the matrix pipe for all of them
-    float4 rk[4], rv[4];
-    auto fetch = [&](int k0) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            int key = k0 + skey + 16 * it;
-            key = key < nk ? key : nk - 1;          // clamped: keys >= nk are masked in the softmax
-            rk[it] = *reinterpret_cast<const float4*>(kbase + (size_t)key * ld + sdq * 4);
-            rv[it] = *reinterpret_cast<const float4*>(vbase + (size_t)key * ld + sdq * 4);
-        }
-    };
-    fetch(0);
-    for (int k0 = 0; k0 < nk; k0 += AT_K) {
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int key = skey + 16 * it;
-            float* dk = Ks + key * AT_LDK + sdq * 4;
-            dk[0] = rk[it].x; dk[1] = rk[it].y; dk[2] = rk[it].z; dk[3] = rk[it].w;
-            *reinterpret_cast<float4*>(Vs + key * 64 + sdq * 4) = rv[it];
-        }
-        __syncthreads();
-        if (k0 + AT_K < nk) fetch(k0 + AT_K);
-#pragma unroll
-        for (int sub = 0; sub < AT_K / 32; ++sub) {
-            if (k0 + sub * 32 >= nk) break;
-            f32x16 st[NQ];
-#pragma unroll
-            for (int u = 0; u < NQ; ++u)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) st[u][r] = 0.f;
-            const float* ka = Ks + (sub * 32 + j) * AT_LDK + h;
-#pragma unroll
-            for (int s = 0; s < 32; ++s) {
-                const float a = ka[2 * s];
-#pragma unroll
-                for (int u = 0; u < NQ; ++u) st[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qreg[u][s], st[u], 0, 0, 0);
-            }
-            const bool partial = k0 + sub * 32 + 32 > nk;   // only the last key tile needs masking
-#pragma unroll
-            for (int u = 0; u < NQ; ++u) {
-                float mx = -INFINITY;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = k0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    st[u][r] = (!partial || key < nk) ? st[u][r] * kScale : -INFINITY;
-                    mx = fmaxf(mx, st[u][r]);
-                }
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
-                const float m_new = fmaxf(m_run[u], mx);
-                const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_new);
-                float ps = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { st[u][r] = __builtin_amdgcn_exp2f(st[u][r] - m_new); ps += st[u][r]; }
-                ps += __shfl_xor(ps, 32);
-                l_run[u] = l_run[u] * alpha + ps;
-                m_run[u] = m_new;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { o0[u][r] *= alpha; o1[u][r] *= alpha; }
-            }
-            const float* va = Vs + (sub * 32 + 4 * h) * 64 + j;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kr = (r & 3) + 8 * (r >> 2);
-                const float a0 = va[kr * 64], a1 = va[kr * 64 + 32];
-#pragma unroll
-                for (int u = 0; u < NQ; ++u) {
-                    o0[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, st[u][r], o0[u], 0, 0, 0);
-                    o1[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, st[u][r], o1[u], 0, 0, 0);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-        if (qrow[u] < Lq) {
-            const float inv = (qrow[u] < nq && l_run[u] > 0.f) ? 1.0f / l_run[u] : 0.f;
-            float* op = out + ((size_t)seq * Lq + qrow[u]) * 256 + head * 64;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int d = (r & 3) + 8 * (r >> 2) + 4 * h;
-                op[d] = o0[u][r] * inv;
-                op[d + 32] = o1[u][r] * inv;
-            }
-        }
-    }
-}
-
 // merges the key ranges of the split variant: out = sum_s o_s 2^(m_s - m) / sum_s l_s 2^(m_s - m), m = max_s m_s
 __global__ __launch_bounds__(256) void lg_attention_combine_kernel(const float* __restrict__ part, int ns, int nseq, int Lq,
                                                                    const int* __restrict__ qlen, float* __restrict__ out) {
@@ -394,12 +282,14 @@ size_t lg_attention_part_bytes(int nseq, int Lq) {   // scratch of the split-key
 }
 
 void launch_lg_attention(hipStream_t s, const float* q, const float* k, const float* v, int ld, float* out, int nseq, int Lq,
-                         int Lk, const int* qlen, const int* klen, const int* kv_map, float* part) {
+                         int Lk, const int* qlen, const int* klen, const int* kv_map, float* part, const float* rope_cs,
+                         const float* rope_sn) {
     const int nqb = (Lq + AT_Q - 1) / AT_Q;
     // (sequence, head) units, padded to a multiple of 8: the kernels deal their blocks round-robin over the 8 XCDs and map
     // block -> (unit, query block) by unit = (t / nqb) * 8 + xcd, which is a bijection only for a multiple of 8 units
     // (2P sequences always are; the per-frame self block of the stream mode runs on B sequences, e.g. 33)
     const int units8 = (4 * nseq + 7) / 8 * 8;
+    const bool rope = rope_cs != nullptr;
     // latency regime: fewer (sequence, head, query block) units than CUs -> split the keys until the chip is covered
     static const int split_env = tune_int("RFE_ATT_SPLIT", -1);   // 0/1 = off, n = force n ranges
     if (part && (size_t)nseq * Lq <= AT_SPLIT_MAX_ROWS && split_env != 0 && split_env != 1) {
@@ -408,32 +298,28 @@ void launch_lg_attention(hipStream_t s, const float* q, const float* k, const fl
         while (ns < AT_SPLIT_MAX && units * ns * 2 <= 256 && Lk / (ns * 2) >= 2 * AT_K) ns *= 2;
         if (split_env > 1) ns = split_env < AT_SPLIT_MAX ? split_env : AT_SPLIT_MAX;
         if (ns > 1) {
-            hipLaunchKernelGGL((lg_attention_kernel<false, 0, true>), dim3(nqb * units8, ns), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk,
-                               nqb, qlen, klen, kv_map, 1, part, nseq);
+            if (rope)
+                hipLaunchKernelGGL((lg_attention_kernel<0, true, true>), dim3(nqb * units8, ns), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk,
+                                   nqb, qlen, klen, kv_map, 1, part, nseq, rope_cs, rope_sn);
+            else
+                hipLaunchKernelGGL((lg_attention_kernel<0, true, false>), dim3(nqb * units8, ns), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk,
+                                   nqb, qlen, klen, kv_map, 1, part, nseq, rope_cs, rope_sn);
             hipLaunchKernelGGL(lg_attention_combine_kernel, dim3((unsigned)(((size_t)nseq * Lq * 64 + 255) / 256)), dim3(256), 0, s, part,
                                ns, nseq, Lq, qlen, out);
             return;
         }
     }
-    static const bool single = tune_env("RFE_ATT_DBUF") == nullptr;   // tuning switch: RFE_ATT_DBUF=1 selects the double-buffered variant
-    static const bool q64 = tune_env("RFE_ATT_Q64") != nullptr;        // tuning switch: 64 queries per wave
-    if (q64 && Lq >= 512) {
-        const int nqb2 = (Lq + 255) / 256;
-        hipLaunchKernelGGL(lg_attention_q64_kernel, dim3(nqb2 * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb2, qlen, klen, kv_map, nseq);
-        return;
-    }
-    static const int abl = tune_int("RFE_DBG_ATT_ABL", 0);   // timing ablations (wrong results)
-    if (abl == 1) { hipLaunchKernelGGL((lg_attention_kernel<false, 1>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0, nullptr, nseq); return; }
-    if (abl == 2) { hipLaunchKernelGGL((lg_attention_kernel<false, 2>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0, nullptr, nseq); return; }
-    if (abl == 3) { hipLaunchKernelGGL((lg_attention_kernel<false, 3>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0, nullptr, nseq); return; }
+#ifdef RFE_TUNING
+    const int abl = tune_int("RFE_DBG_ATT_ABL", 0);   // timing ablations (wrong results), tuning build only
+    if (abl == 1) { hipLaunchKernelGGL((lg_attention_kernel<1>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0, nullptr, nseq, rope_cs, rope_sn); return; }
+    if (abl == 2) { hipLaunchKernelGGL((lg_attention_kernel<2>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0, nullptr, nseq, rope_cs, rope_sn); return; }
+    if (abl == 3) { hipLaunchKernelGGL((lg_attention_kernel<3>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0, nullptr, nseq, rope_cs, rope_sn); return; }
+#endif
     static const int prio = tune_int("RFE_ATT_PRIO", 1);   // s_setprio(1) around the MFMA clusters (+0.8 %); RFE_ATT_PRIO=0 disables
-    static const bool pf = tune_int("RFE_ATT_PF", 0) != 0;   // tuning switch: register prefetch of the next K/V tile
-    if (pf)
-        hipLaunchKernelGGL((lg_attention_kernel<false, 0, false, true>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nullptr, nseq);
-    else if (single)
-        hipLaunchKernelGGL(lg_attention_kernel<false>, dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nullptr, nseq);
+    if (rope)
+        hipLaunchKernelGGL((lg_attention_kernel<0, false, true>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nullptr, nseq, rope_cs, rope_sn);
     else
-        hipLaunchKernelGGL(lg_attention_kernel<true>, dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nullptr, nseq);
+        hipLaunchKernelGGL((lg_attention_kernel<0, false, false>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nullptr, nseq, rope_cs, rope_sn);
 }
 
 // ---------------------------------------------------------------- LayerNorm(512) + GELU(erf), in place

@@ -630,11 +630,16 @@ void lg_self_block(rfe_ctx* c, LgBuffers& b, const LgLayerDev& Lw, float* x, con
                    const int32_t* lens, int nseq, int L) {
     hipStream_t s = c->stream;
     const int rows = nseq * L;
-    { ProfScope p(c, "lg_qkv");   // q,k,v = Wqkv x + b with the rotary applied to q,k in the GEMM epilogue
+    // q,k,v = Wqkv x + b; the rotary of q and k is applied by the attention kernel on load (RFE_ROPE_IN_GEMM, tuning build:
+    // in the GEMM epilogue as in round 1 -- bit-identical, 14 % slower projection)
+    static const bool rope_in_gemm = tune_env("RFE_ROPE_IN_GEMM") != nullptr;
+    { ProfScope p(c, "lg_qkv");
       GemmArgs a = gemm_plain(x, 256, Lw.wqkv, 256, Lw.bqkv, b.qkv, 768, rows, 768, 256);
-      a.rope_cs = cs; a.rope_sn = sn; a.rope_ncols = 512;
+      if (rope_in_gemm) { a.rope_cs = cs; a.rope_sn = sn; a.rope_ncols = 512; }
       launch_gemm_nt(s, a); }
-    { ProfScope p(c, "lg_attention"); launch_lg_attention(s, b.qkv, b.qkv + 256, b.qkv + 512, 768, b.ctx, nseq, L, L, lens, lens, nullptr, lg_part(b, nseq, L)); }
+    { ProfScope p(c, "lg_attention");
+      launch_lg_attention(s, b.qkv, b.qkv + 256, b.qkv + 512, 768, b.ctx, nseq, L, L, lens, lens, nullptr, lg_part(b, nseq, L),
+                          rope_in_gemm ? nullptr : cs, rope_in_gemm ? nullptr : sn); }
     if (c->opt_lg_fold) {
         lg_ffn(c, b, x, b.ctx, rows, Lw.w1f, Lw.b1f, Lw.lng, Lw.lnb, Lw.w2, Lw.b2);
     } else {

@@ -81,6 +81,7 @@ struct GemmArgs {
     const float* rope_sn;             //   columns n < rope_ncols in adjacent pairs (2f, 2f+1), f = (n%64)/2
     int rope_ncols;
     int rend;                         // residual added in the direct (D-layout) epilogue
+    int rinit;                        // residual added to the bias in the accumulator initialisation
 };
 
 }  // namespace rfe
@@ -162,7 +163,8 @@ void launch_lg_posenc(hipStream_t s, const float* kn, const float* wr, int rows,
 void launch_lg_attention(hipStream_t s, const float* q, const float* k, const float* v, int ld /*row stride of q,k,v*/,
                          float* out, int nseq, int Lq, int Lk, const int* qlen, const int* klen,
                          const int* kv_map /*seq -> kv seq index, or null = identity*/,
-                         float* part /*lg_attention_part_bytes(nseq, Lq) of scratch for the split-key variant, or null*/);
+                         float* part /*lg_attention_part_bytes(nseq, Lq) of scratch for the split-key variant, or null*/,
+                         const float* rope_cs = nullptr, const float* rope_sn = nullptr /*rotary tables [nseq*Lq, 32]: applied to q and k (self blocks)*/);
 size_t lg_attention_part_bytes(int nseq, int Lq);
 void launch_lg_ln_gelu(hipStream_t s, float* h, const float* g, const float* b, int64_t rows);
 void launch_lg_assign(hipStream_t s, const float* sim, const float* z0, const float* z1, int P, int L,
