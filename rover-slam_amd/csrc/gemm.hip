@@ -47,27 +47,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     float* C = g.C + (size_t)z * g.sC;
 
     f32x16 acc[MB][NB];
-    // rinit: the residual joins the bias in the accumulator initialisation (x + b) + sum instead of x + (b + sum): the
-    // epilogue has nothing left to read (only valid with alpha = 1 and no ReLU; changes the last-bit rounding of the sum)
-    const bool rinit = TEPI && g.rinit && g.R && !g.rope_cs;
-    const float* Rz0 = rinit ? g.R + (size_t)z * g.sR : nullptr;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int n = n0 + (wn * NB + nb) * 32 + i;
         const float bv = (g.bias && n < g.N) ? g.bias[n] : 0.f;
-        const int nc = n < g.N ? n : g.N - 1;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v0 = bv;
-                if (TEPI && rinit) {
-                    int m = m0 + (wm * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    m = m < M ? m : M - 1;
-                    v0 = Rz0[(size_t)m * g.ldr + nc] + bv;
-                }
-                acc[mb][nb][r] = v0;
-            }
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = bv;
     }
 
     // staging: thread -> (row = tid/8 + 32*it, 4 consecutive k).  Rows past the M / N edge are CLAMPED
@@ -142,8 +129,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
         }
     }
 
-    if (!TEPI || (g.rend && g.R && !g.rope_cs)) {   // plain bias (+alpha, +ReLU, +residual) epilogue: 128-B coalesced accesses straight from the D layout
-        const float* Rz = (TEPI && g.R && !rinit) ? g.R + (size_t)z * g.sR : nullptr;
+    // workgroups whose column tile holds no rotary columns (the q and v thirds of the qkv projection) take the direct epilogue
+    const bool wg_rope = g.rope_cs != nullptr && n0 < g.rope_ncols && n0 + BN > g.rope_n0;
+    if (!TEPI || (g.rend && g.R && !g.rope_cs) || (g.rope_cs && !wg_rope && !g.R)) {   // plain bias (+alpha, +ReLU, +residual) epilogue: 128-B coalesced accesses straight from the D layout
+        const float* Rz = (TEPI && g.R) ? g.R + (size_t)z * g.sR : nullptr;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -222,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
             const int m = mbase + row, n = n0 + q * 4;
             if (m >= M || n >= g.N) continue;
             float4 v = *reinterpret_cast<const float4*>(ch + row * CS + q * 4);
-            if (rope && n < g.rope_ncols) {   // LightGlue rotary: (t0,t1) -> (t0 c - t1 s, t1 c + t0 s), pairs (2f,2f+1), f = (n%64)/2
+            if (rope && n < g.rope_ncols && n >= g.rope_n0) {   // LightGlue rotary: (t0,t1) -> (t0 c - t1 s, t1 c + t0 s), pairs (2f,2f+1), f = (n%64)/2
                 const int f = (n & 63) >> 1;
                 const float2 c2 = *reinterpret_cast<const float2*>(tab + row * 64 + f);
                 const float2 s2 = *reinterpret_cast<const float2*>(tab + row * 64 + 32 + f);
@@ -248,13 +237,11 @@ void launch_gemm_nt(hipStream_t s, const GemmArgs& g_in) {
     static const int rend_on = tune_int("RFE_GEMM_REND", 1);   // A/B switch, see profiles/r01_pmc.md
     GemmArgs g = g_in;
     g.rend = rend_on;
-    static const int rinit_on = tune_int("RFE_GEMM_RINIT", 0);   // A/B switch
-    g.rinit = rinit_on && g.alpha == 1.0f && !g.relu;
     const int batch = g.batch > 0 ? g.batch : 1;
     auto tiles = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * batch; };
     static const bool force_tepi = tune_env("RFE_GEMM_TEPI") != nullptr;   // tuning switch
     const bool tepi = force_tepi || g.R != nullptr || g.rope_cs != nullptr;
-    static const bool pft = tune_int("RFE_GEMM_PF", 0) != 0;   // tuning switch: register prefetch also on the 128-row tiles
+    static const bool pft = tune_int("RFE_GEMM_PF", 1) != 0;   // register prefetch of the next K tile also on the 128-row tiles (+1 % on ffn1 / ffn2, profiles/r02_pmc.md); RFE_GEMM_PF=0 (tuning build) disables
 #define RFE_GEMM_GO(MB_, NB_, GRID)                                                                  \
     do {                                                                                             \
         if (pft && MB_ == 2 && tepi) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, true, MB_ == 2>), GRID, dim3(256), 0, s, g);    \

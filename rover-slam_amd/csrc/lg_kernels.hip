@@ -40,14 +40,15 @@ constexpr size_t AT_SPLIT_MAX_ROWS = 8192;    // only problems this small are la
 // SPLIT: split-key variant for latency-bound problems (one pair = 64 (sequence, head, query block) units for 256 CUs and
 // a 2048-MFMA serial chain per wave): blockIdx.y selects one of gridDim.y key ranges, the workgroup writes its
 // unnormalised accumulators and (reference max, sum) to `part`, and lg_attention_combine_kernel merges the ranges.
-// ROPE: the LightGlue rotary encoding of the self blocks is applied HERE, to the Q fragment as it is loaded and to every K tile
-// as it is staged -- (t0, t1) -> (t0 c - t1 s, t1 c + t0 s) on adjacent pairs (2f, 2f+1), c / s = rope_cs / rope_sn[row][f],
-// the same three fp32 operations the qkv projection's epilogue used to apply (bit-identical results) -- so that the
-// projection GEMM keeps its plain coalesced epilogue.  K rows are rotated once per staging workgroup (8 query blocks per
-// (sequence, head) = 8x redundant VALU work, ~1 % of the MFMA time; the tables are 128 B per row and L2 resident).
+// ROPE: the LightGlue rotary encoding of the self blocks -- (t0, t1) -> (t0 c - t1 s, t1 c + t0 s) on adjacent pairs (2f, 2f+1),
+// c / s = rope_cs / rope_sn[row][f] -- applied to the Q fragment as it is loaded (free: once per workgroup) with the same
+// three fp32 operations the qkv projection's LDS-transposed epilogue used for it (bit-identical), so that the q third of
+// that GEMM takes the plain coalesced epilogue.  ROPE = 1 also rotates every K tile as it is staged (measured: the extra
+// loads of the staging phase cost the attention what the projection gains, profiles/r02_pmc.md); the default, ROPE = 2,
+// leaves K to the projection's epilogue (only the workgroups of the k column tile pay for it).
 // Variants that did not pay (double-buffered LDS, register prefetch of the next tile, 64 queries per wave, 256-query
 // workgroups) are recorded in profiles/r01_pmc.md and profiles/r02_pmc.md.
-template <int ABL = 0, bool SPLIT = false, bool ROPE = false>
+template <int ABL = 0, bool SPLIT = false, int ROPE = 0>   // ROPE: 0 none, 1 = q and k, 2 = q only (k rotated by the projection)
 __global__ __launch_bounds__(256, 4) void lg_attention_kernel(   // 4 workgroups per CU: at most 128 VGPRs
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld, float* __restrict__ out,
     int Lq, int Lk, int nqb, const int* __restrict__ qlen, const int* __restrict__ klen, const int* __restrict__ kv_map,
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256, 4) void lg_attention_kernel(   // 4 workgroups
             if (key < nk) {
                 rk[it] = *reinterpret_cast<const float4*>(kbase + (size_t)key * ld + sdq * 4);
                 rv[it] = *reinterpret_cast<const float4*>(vbase + (size_t)key * ld + sdq * 4);
-                if (ROPE) {   // dims 4 sdq .. 4 sdq + 3 = pairs f = 2 sdq, 2 sdq + 1
+                if (ROPE == 1) {   // dims 4 sdq .. 4 sdq + 3 = pairs f = 2 sdq, 2 sdq + 1
                     const size_t trow = ((size_t)kvseq * Lk + key) * 32 + 2 * sdq;
                     const float2 c2 = *reinterpret_cast<const float2*>(rope_cs + trow);
                     const float2 s2 = *reinterpret_cast<const float2*>(rope_sn + trow);
@@ -283,7 +284,7 @@ size_t lg_attention_part_bytes(int nseq, int Lq) {   // scratch of the split-key
 
 void launch_lg_attention(hipStream_t s, const float* q, const float* k, const float* v, int ld, float* out, int nseq, int Lq,
                          int Lk, const int* qlen, const int* klen, const int* kv_map, float* part, const float* rope_cs,
-                         const float* rope_sn) {
+                         const float* rope_sn, bool rope_k) {
     const int nqb = (Lq + AT_Q - 1) / AT_Q;
     // (sequence, head) units, padded to a multiple of 8: the kernels deal their blocks round-robin over the 8 XCDs and map
     // block -> (unit, query block) by unit = (t / nqb) * 8 + xcd, which is a bijection only for a multiple of 8 units
@@ -298,11 +299,14 @@ void launch_lg_attention(hipStream_t s, const float* q, const float* k, const fl
         while (ns < AT_SPLIT_MAX && units * ns * 2 <= 256 && Lk / (ns * 2) >= 2 * AT_K) ns *= 2;
         if (split_env > 1) ns = split_env < AT_SPLIT_MAX ? split_env : AT_SPLIT_MAX;
         if (ns > 1) {
-            if (rope)
-                hipLaunchKernelGGL((lg_attention_kernel<0, true, true>), dim3(nqb * units8, ns), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk,
+            if (rope && rope_k)
+                hipLaunchKernelGGL((lg_attention_kernel<0, true, 1>), dim3(nqb * units8, ns), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk,
+                                   nqb, qlen, klen, kv_map, 1, part, nseq, rope_cs, rope_sn);
+            else if (rope)
+                hipLaunchKernelGGL((lg_attention_kernel<0, true, 2>), dim3(nqb * units8, ns), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk,
                                    nqb, qlen, klen, kv_map, 1, part, nseq, rope_cs, rope_sn);
             else
-                hipLaunchKernelGGL((lg_attention_kernel<0, true, false>), dim3(nqb * units8, ns), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk,
+                hipLaunchKernelGGL((lg_attention_kernel<0, true, 0>), dim3(nqb * units8, ns), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk,
                                    nqb, qlen, klen, kv_map, 1, part, nseq, rope_cs, rope_sn);
             hipLaunchKernelGGL(lg_attention_combine_kernel, dim3((unsigned)(((size_t)nseq * Lq * 64 + 255) / 256)), dim3(256), 0, s, part,
                                ns, nseq, Lq, qlen, out);
@@ -316,10 +320,12 @@ void launch_lg_attention(hipStream_t s, const float* q, const float* k, const fl
     if (abl == 3) { hipLaunchKernelGGL((lg_attention_kernel<3>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0, nullptr, nseq, rope_cs, rope_sn); return; }
 #endif
     static const int prio = tune_int("RFE_ATT_PRIO", 1);   // s_setprio(1) around the MFMA clusters (+0.8 %); RFE_ATT_PRIO=0 disables
-    if (rope)
-        hipLaunchKernelGGL((lg_attention_kernel<0, false, true>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nullptr, nseq, rope_cs, rope_sn);
+    if (rope && rope_k)
+        hipLaunchKernelGGL((lg_attention_kernel<0, false, 1>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nullptr, nseq, rope_cs, rope_sn);
+    else if (rope)
+        hipLaunchKernelGGL((lg_attention_kernel<0, false, 2>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nullptr, nseq, rope_cs, rope_sn);
     else
-        hipLaunchKernelGGL((lg_attention_kernel<0, false, false>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nullptr, nseq, rope_cs, rope_sn);
+        hipLaunchKernelGGL((lg_attention_kernel<0, false, 0>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nullptr, nseq, rope_cs, rope_sn);
 }
 
 // ---------------------------------------------------------------- LayerNorm(512) + GELU(erf), in place

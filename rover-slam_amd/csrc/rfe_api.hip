@@ -114,6 +114,8 @@ extern "C" void rfe_destroy(rfe_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->aux) { rfe_destroy(c->aux); c->aux = nullptr; }
+    for (auto& e : c->ev_st) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     prof_collect(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
@@ -630,16 +632,17 @@ void lg_self_block(rfe_ctx* c, LgBuffers& b, const LgLayerDev& Lw, float* x, con
                    const int32_t* lens, int nseq, int L) {
     hipStream_t s = c->stream;
     const int rows = nseq * L;
-    // q,k,v = Wqkv x + b; the rotary of q and k is applied by the attention kernel on load (RFE_ROPE_IN_GEMM, tuning build:
-    // in the GEMM epilogue as in round 1 -- bit-identical, 14 % slower projection)
-    static const bool rope_in_gemm = tune_env("RFE_ROPE_IN_GEMM") != nullptr;
+    // q,k,v = Wqkv x + b.  Rotary: k in the GEMM epilogue (only the workgroups of the k column tile take the LDS-transposed
+    // epilogue), q by the attention kernel as it loads its Q fragment.  RFE_ROPE_MODE (tuning build): 0 = q and k in the GEMM
+    // (round 1), 1 = q and k in the attention kernel, 2 = default.  All three are bit-identical.
+    static const int rope_mode = tune_int("RFE_ROPE_MODE", 2);
     { ProfScope p(c, "lg_qkv");
       GemmArgs a = gemm_plain(x, 256, Lw.wqkv, 256, Lw.bqkv, b.qkv, 768, rows, 768, 256);
-      if (rope_in_gemm) { a.rope_cs = cs; a.rope_sn = sn; a.rope_ncols = 512; }
+      if (rope_mode != 1) { a.rope_cs = cs; a.rope_sn = sn; a.rope_ncols = 512; a.rope_n0 = rope_mode == 2 ? 256 : 0; }
       launch_gemm_nt(s, a); }
     { ProfScope p(c, "lg_attention");
       launch_lg_attention(s, b.qkv, b.qkv + 256, b.qkv + 512, 768, b.ctx, nseq, L, L, lens, lens, nullptr, lg_part(b, nseq, L),
-                          rope_in_gemm ? nullptr : cs, rope_in_gemm ? nullptr : sn); }
+                          rope_mode == 0 ? nullptr : cs, rope_mode == 0 ? nullptr : sn, rope_mode == 1); }
     if (c->opt_lg_fold) {
         lg_ffn(c, b, x, b.ctx, rows, Lw.w1f, Lw.b1f, Lw.lng, Lw.lnb, Lw.w2, Lw.b2);
     } else {
@@ -921,14 +924,30 @@ extern "C" int rfe_stereo_frame_dev(rfe_ctx* c, const uint8_t* imgL, const uint8
     int32_t* sadv = (int32_t*)p; p += b_sad;
     float* kn_prev = (float*)p; p += b_kn; float* kn_cur = (float*)p; p += b_kn;
     float* desc_prev = (float*)p; p += b_desc; int32_t* n_prev = (int32_t*)p;
-    // both views as ONE batch of 2 (the reference runs them on two threads, src/Frame.cc:142-147)
+    // Two lanes, like the reference's two extractor threads (src/Frame.cc:142-147): the LEFT view and the temporal LightGlue
+    // match form the critical path on the ctx stream; the RIGHT view and ComputeStereoMatches (which needs both views but
+    // nothing from LightGlue) run on a second lane -- an internal ctx with its own streams and workspace that shares the
+    // device weights -- and fill the chip next to the latency-bound single-pair LightGlue launches.
+    if (!c->aux) {
+        if ((rc = rfe_init(c->device, &c->aux))) return fail(c, rc, std::string("stereo_frame: second lane: ") + rfe_last_error(nullptr));
+        for (auto& e : c->ev_st) RFE_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    rfe_ctx* a = c->aux;
+    a->sp = c->sp; a->sp_hold = c->sp_hold; a->has_sp = true;    // same device copy (kept alive by both holders)
     RFE_HIP(c, hipMemcpy2DAsync(d_img, (size_t)W, imgL, (size_t)stride, (size_t)W, (size_t)H, hipMemcpyDeviceToDevice, s));
     RFE_HIP(c, hipMemcpy2DAsync(d_img + (size_t)H * W, (size_t)W, imgR, (size_t)stride, (size_t)W, (size_t)H, hipMemcpyDeviceToDevice, s));
-    if ((rc = sp_forward(c, d_img, H, W, W, 2, Kmax, thr, n, kxy, score, desc))) return rc;
+    RFE_HIP(c, hipEventRecord(c->ev_st[0], s));
+    RFE_HIP(c, hipStreamWaitEvent(a->stream, c->ev_st[0], 0));
+    if ((rc = sp_forward(a, d_img + (size_t)H * W, H, W, W, 1, Kmax, thr, n + 1, kxy + (size_t)Kmax * 2, score + Kmax, desc + (size_t)Kmax * 256)))
+        return fail(c, rc, a->err);
+    if ((rc = sp_forward(c, d_img, H, W, W, 1, Kmax, thr, n, kxy, score, desc))) return rc;
+    RFE_HIP(c, hipEventRecord(c->ev_st[1], s));                  // left features ready
+    RFE_HIP(c, hipStreamWaitEvent(a->stream, c->ev_st[1], 0));
     // Frame::ComputeStereoMatches (src/Frame.cc:1159-1446) on the device-resident features; counts stay on the device
-    { ProfScope ps(c, "stereo_match");
-      launch_stereo_match_counts(s, d_img, d_img + (size_t)H * W, H, W, W, kxy, kxy + (size_t)Kmax * 2, Kmax, n, desc,
+    { ProfScope ps(c, "stereo_match", a->stream);
+      launch_stereo_match_counts(a->stream, d_img, d_img + (size_t)H * W, H, W, W, kxy, kxy + (size_t)Kmax * 2, Kmax, n, desc,
                                  desc + (size_t)Kmax * 256, mb, mbf, uRight, depth, sadv); }
+    RFE_HIP(c, hipEventRecord(c->ev_st[2], a->stream));
     // temporal match: previous left view (set 0) against this left view (set 1), true image size like the Frame overload
     // of MatchingPoints_onnx (src/Matchers/SPmatcher.cc:457-542, :463-464)
     { ProfScope ps(c, "lg_misc"); launch_normalize_kpts(s, kxy, Kmax, H, W, kn_cur); }
@@ -948,6 +967,7 @@ extern "C" int rfe_stereo_frame_dev(rfe_ctx* c, const uint8_t* imgL, const uint8
       RFE_HIP(c, hipMemcpyAsync(desc_prev, desc, (size_t)Kmax * 1024, hipMemcpyDeviceToDevice, s));
       RFE_HIP(c, hipMemcpyAsync(n_prev, n, 4, hipMemcpyDeviceToDevice, s)); }
     c->st_have_prev = true;
+    RFE_HIP(c, hipStreamWaitEvent(s, c->ev_st[2], 0));           // join: the call is complete in ctx-stream order
     RFE_HIP(c, hipGetLastError());
     return RFE_OK;
 }

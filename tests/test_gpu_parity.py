@@ -28,6 +28,17 @@ def _dev(ctx, arr):
     return ctx.alloc(arr.nbytes).upload(arr)
 
 
+def test_options_api(ctx):
+    """Per-ctx options replace environment switches: RFE_OPT_LG_FOLD_WO defaults to 1, can be read back, unknown ids fail."""
+    from rover_slam_amd import capi
+    assert ctx.get_option(capi.OPT_LG_FOLD_WO) == 1
+    ctx.set_option(capi.OPT_LG_FOLD_WO, 0)
+    assert ctx.get_option(capi.OPT_LG_FOLD_WO) == 0
+    ctx.set_option(capi.OPT_LG_FOLD_WO, 1)
+    with pytest.raises(capi.RfeError, match="unknown option"):
+        ctx.set_option(12345, 1)
+
+
 # ------------------------------------------------------------------ kernel level
 @pytest.mark.parametrize("M,K,N", [(64, 32, 64), (200, 256, 65), (4800, 256, 256), (37, 512, 130)])
 def test_linear_bitexact(ctx, oracle, M, K, N):
