@@ -23,12 +23,14 @@ constexpr int BK = 32, LDT = BK + 1;
 // (tools/kbench/gemm_variants.hip: 119-132 TFLOP/s vs 110-125 for 128x128 double-buffered).
 // MB = 32-row MFMA blocks per wave (2 for throughput; 1 gives 64-row tiles for small, latency-bound problems:
 // a single 1024-keypoint pair has only M = 2048 rows, 16 tiles of 128 x 256 would use 16 of the 256 CUs).
-// TEPI: LDS-transposed whole-row epilogue (rotary variant); false = per-lane 4-byte stores.  The residual variant reads
-// R in the D layout (four rows of 128-B segments in flight per step) and adds it after bias / alpha like the oracle.
-template <int MB, int NB, bool TEPI, bool PFT = false>
+// RES: the residual variant reads R in the D layout (four rows of 128-B segments in flight per step) and adds it after bias /
+// alpha like the oracle.  (Round 1's LDS-transposed whole-row epilogue, which also applied the LightGlue rotary to q | k, is gone:
+// the rotary moved into the attention kernel's loads -- same arithmetic, same time overall, one epilogue fewer here.)
+// PFT: register prefetch of the next K tile under the MFMAs (always on for the 64-row latency tiles).
+template <int MB, int NB, bool RES, bool PFT = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     constexpr int BM = MB * 64, BN = NB * 64;
-    __shared__ float lds_ab[(BM + BN) * LDT];   // A tile | B tile; reused for the rotary tables in the epilogue
+    __shared__ float lds_ab[(BM + BN) * LDT];   // A tile | B tile
     float* const As = lds_ab;
     float* const Bs = lds_ab + BM * LDT;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -129,10 +131,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
         }
     }
 
-    // workgroups whose column tile holds no rotary columns (the q and v thirds of the qkv projection) take the direct epilogue
-    const bool wg_rope = g.rope_cs != nullptr && n0 < g.rope_ncols && n0 + BN > g.rope_n0;
-    if (!TEPI || (g.rend && g.R && !g.rope_cs) || (g.rope_cs && !wg_rope && !g.R)) {   // plain bias (+alpha, +ReLU, +residual) epilogue: 128-B coalesced accesses straight from the D layout
-        const float* Rz = (TEPI && g.R) ? g.R + (size_t)z * g.sR : nullptr;
+    {   // bias (+alpha, +ReLU, +residual) epilogue: 128-B coalesced accesses straight from the D layout
+        const float* Rz = (RES && g.R) ? g.R + (size_t)z * g.sR : nullptr;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -167,86 +167,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
                     }
                 }
             }
-        return;
-    }
-    // ---- epilogue: accumulators (lane = column) are transposed through the now free A/B LDS space in 32-row
-    // chunks so that residual loads and result stores are whole-row float4 accesses (4x fewer memory
-    // instructions than per-lane 4-byte accesses; the residual read alone cost 25 % of ffn2 before).
-    const float* R = g.R ? g.R + (size_t)z * g.sR : nullptr;
-    const bool rope = g.rope_cs != nullptr;
-    constexpr int CS = BN + 4;                 // chunk row stride (floats), keeps rows 16-byte aligned
-    static_assert(32 * CS <= (BM + BN) * LDT, "epilogue chunk must fit in the tile LDS");
-    float* const ch = lds_ab;
-    float* const tab = lds_ab + 32 * CS;       // rotary tables of the chunk rows: [32][32 cos | 32 sin]
-    static_assert(32 * CS + 32 * 64 <= (BM + BN) * LDT, "rotary table staging must fit");
-    const bool vec_ok = (g.ldc % 4 == 0) && (g.N % 4 == 0) && (!R || g.ldr % 4 == 0);
-#pragma unroll 1
-    for (int c4 = 0; c4 < 2 * MB; ++c4) {      // chunk = 32 rows: wave row wm = c4 / MB, M-block mb = c4 % MB
-        __syncthreads();
-        if (wm == c4 / MB) {
-            const int mb = c4 % MB;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    // the two M-blocks are distinct registers: select without dynamic indexing
-                    const float v = (MB > 1 && mb) ? acc[MB - 1][nb][r] : acc[0][nb][r];
-                    ch[row * CS + (wn * NB + nb) * 32 + i] = v * g.alpha;
-                }
-            }
-        }
-        const int mbase = m0 + c4 * 32;
-        if (rope) {
-            for (int idx = tid; idx < 32 * 16; idx += 256) {
-                const int row = idx >> 4, q4 = idx & 15;     // 16 float4 per row: 8 cos + 8 sin
-                int m = mbase + row; m = m < M ? m : M - 1;
-                const float* src = (q4 < 8 ? g.rope_cs : g.rope_sn) + (size_t)m * 32 + (q4 & 7) * 4;
-                *reinterpret_cast<float4*>(tab + row * 64 + q4 * 4) = *reinterpret_cast<const float4*>(src);
-            }
-        }
-        __syncthreads();
-        for (int idx = tid; idx < 32 * (BN / 4); idx += 256) {
-            const int row = idx / (BN / 4), q = idx % (BN / 4);
-            const int m = mbase + row, n = n0 + q * 4;
-            if (m >= M || n >= g.N) continue;
-            float4 v = *reinterpret_cast<const float4*>(ch + row * CS + q * 4);
-            if (rope && n < g.rope_ncols && n >= g.rope_n0) {   // LightGlue rotary: (t0,t1) -> (t0 c - t1 s, t1 c + t0 s), pairs (2f,2f+1), f = (n%64)/2
-                const int f = (n & 63) >> 1;
-                const float2 c2 = *reinterpret_cast<const float2*>(tab + row * 64 + f);
-                const float2 s2 = *reinterpret_cast<const float2*>(tab + row * 64 + 32 + f);
-                v = make_float4(v.x * c2.x - v.y * s2.x, v.y * c2.x + v.x * s2.x, v.z * c2.y - v.w * s2.y, v.w * c2.y + v.z * s2.y);
-            }
-            if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            float* dst = C + (size_t)m * g.ldc + n;
-            if (vec_ok && n + 3 < g.N) {
-                if (R) { const float4 rv = *reinterpret_cast<const float4*>(R + (size_t)m * g.ldr + n); v.x = rv.x + v.x; v.y = rv.y + v.y; v.z = rv.z + v.z; v.w = rv.w + v.w; }
-                *reinterpret_cast<float4*>(dst) = v;
-            } else {
-                const float* rp = R ? R + (size_t)m * g.ldr + n : nullptr;
-                dst[0] = rp ? rp[0] + v.x : v.x;
-                if (n + 1 < g.N) dst[1] = rp ? rp[1] + v.y : v.y;
-                if (n + 2 < g.N) dst[2] = rp ? rp[2] + v.z : v.z;
-                if (n + 3 < g.N) dst[3] = rp ? rp[3] + v.w : v.w;
-            }
-        }
     }
 }
 
 void launch_gemm_nt(hipStream_t s, const GemmArgs& g_in) {
-    static const int rend_on = tune_int("RFE_GEMM_REND", 1);   // A/B switch, see profiles/r01_pmc.md
     GemmArgs g = g_in;
-    g.rend = rend_on;
     const int batch = g.batch > 0 ? g.batch : 1;
     auto tiles = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * batch; };
-    static const bool force_tepi = tune_env("RFE_GEMM_TEPI") != nullptr;   // tuning switch
-    const bool tepi = force_tepi || g.R != nullptr || g.rope_cs != nullptr;
+    const bool res = g.R != nullptr;
     static const bool pft = tune_int("RFE_GEMM_PF", 1) != 0;   // register prefetch of the next K tile also on the 128-row tiles (+1 % on ffn1 / ffn2, profiles/r02_pmc.md); RFE_GEMM_PF=0 (tuning build) disables
 #define RFE_GEMM_GO(MB_, NB_, GRID)                                                                  \
     do {                                                                                             \
-        if (pft && MB_ == 2 && tepi) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, true, MB_ == 2>), GRID, dim3(256), 0, s, g);    \
-        else if (pft && MB_ == 2) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, false, MB_ == 2>), GRID, dim3(256), 0, s, g);       \
-        else if (tepi) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, true>), GRID, dim3(256), 0, s, g);    \
+        if (pft && MB_ == 2 && res) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, true, MB_ == 2>), GRID, dim3(256), 0, s, g);    \
+        else if (pft && MB_ == 2) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, false, MB_ == 2>), GRID, dim3(256), 0, s, g);     \
+        else if (res) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, true>), GRID, dim3(256), 0, s, g);    \
         else hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, false>), GRID, dim3(256), 0, s, g);        \
     } while (0)
     // largest tile that still gives every CU a workgroup; small problems (single-pair latency) fall to 64 x 64

@@ -10,17 +10,16 @@
 namespace rfe {
 
 // ---------------------------------------------------------------- posenc: theta = Wr . p ; cos/sin
-__global__ void lg_posenc_kernel(const float* __restrict__ kn, const float* __restrict__ wr, int rows,
-                                 float* __restrict__ cs, float* __restrict__ sn) {
+// table layout: [row][f] -> (cos, sin), so that the two pairs a staging thread rotates are one 16-byte load
+__global__ void lg_posenc_kernel(const float* __restrict__ kn, const float* __restrict__ wr, int rows, float2* __restrict__ csn) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= rows * 32) return;
     const int i = gid >> 5, f = gid & 31;
     const float th = fmaf(wr[2 * f + 1], kn[2 * i + 1], wr[2 * f] * kn[2 * i]);
-    cs[gid] = cosf(th);
-    sn[gid] = sinf(th);
+    csn[gid] = make_float2(cosf(th), sinf(th));
 }
-void launch_lg_posenc(hipStream_t s, const float* kn, const float* wr, int rows, float* cs, float* sn) {
-    hipLaunchKernelGGL(lg_posenc_kernel, dim3((rows * 32 + 255) / 256), dim3(256), 0, s, kn, wr, rows, cs, sn);
+void launch_lg_posenc(hipStream_t s, const float* kn, const float* wr, int rows, float* csn) {
+    hipLaunchKernelGGL(lg_posenc_kernel, dim3((rows * 32 + 255) / 256), dim3(256), 0, s, kn, wr, rows, reinterpret_cast<float2*>(csn));
 }
 
 // ---------------------------------------------------------------- fused attention
@@ -41,18 +40,18 @@ constexpr size_t AT_SPLIT_MAX_ROWS = 8192;    // only problems this small are la
 // a 2048-MFMA serial chain per wave): blockIdx.y selects one of gridDim.y key ranges, the workgroup writes its
 // unnormalised accumulators and (reference max, sum) to `part`, and lg_attention_combine_kernel merges the ranges.
 // ROPE: the LightGlue rotary encoding of the self blocks -- (t0, t1) -> (t0 c - t1 s, t1 c + t0 s) on adjacent pairs (2f, 2f+1),
-// c / s = rope_cs / rope_sn[row][f] -- applied to the Q fragment as it is loaded (free: once per workgroup) with the same
-// three fp32 operations the qkv projection's LDS-transposed epilogue used for it (bit-identical), so that the q third of
-// that GEMM takes the plain coalesced epilogue.  ROPE = 1 also rotates every K tile as it is staged (measured: the extra
-// loads of the staging phase cost the attention what the projection gains, profiles/r02_pmc.md); the default, ROPE = 2,
-// leaves K to the projection's epilogue (only the workgroups of the k column tile pay for it).
-// Variants that did not pay (double-buffered LDS, register prefetch of the next tile, 64 queries per wave, 256-query
-// workgroups) are recorded in profiles/r01_pmc.md and profiles/r02_pmc.md.
-template <int ABL = 0, bool SPLIT = false, int ROPE = 0>   // ROPE: 0 none, 1 = q and k, 2 = q only (k rotated by the projection)
+// (c, s) = rope_csn[row][f] -- is applied HERE, to the Q fragment as it is loaded and to every K tile as it is staged, with the
+// same three fp32 operations round 1's projection epilogue used (bit-identical results).  The qkv projection keeps the plain
+// coalesced epilogue (101 -> 122 TFLOP/s); the K rows are rotated once per staging workgroup (8 query blocks per (sequence,
+// head): redundant VALU work worth ~1 % of the MFMA time, one extra 16-byte load per staged K float4; the table is 256 B per
+// row and L2 resident).  Net effect on the step: none within noise (profiles/r02_pmc.md) -- kept because it removes the
+// LDS-transposed epilogue from the GEMM.  Variants that did not pay (double-buffered LDS, register prefetch of the next tile,
+// 64 queries per wave, 256-query workgroups, k rotated by the projection and q here) are recorded in profiles/r01_pmc.md / r02_pmc.md.
+template <int ABL = 0, bool SPLIT = false, bool ROPE = false>
 __global__ __launch_bounds__(256, 4) void lg_attention_kernel(   // 4 workgroups per CU: at most 128 VGPRs
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld, float* __restrict__ out,
     int Lq, int Lk, int nqb, const int* __restrict__ qlen, const int* __restrict__ klen, const int* __restrict__ kv_map,
-    int prio, float* __restrict__ part, int nseq_total, const float* __restrict__ rope_cs, const float* __restrict__ rope_sn) {
+    int prio, float* __restrict__ part, int nseq_total, const float* __restrict__ rope_csn) {
     constexpr bool DBUF = false;   // (the double-buffered variant measured 4 % slower; kept out of the build)
     __shared__ float Ks[1][AT_K * AT_LDK];
     __shared__ float Vs[1][AT_K * 64];
@@ -83,18 +82,15 @@ __global__ __launch_bounds__(256, 4) void lg_attention_kernel(   // 4 workgroups
     float qreg[32];
     if (ROPE) {   // lane (j, h) keeps component h of every pair: both components are loaded, the rotated one is kept
         const float2* qp2 = reinterpret_cast<const float2*>(q + qrow_c * ld + head * 64);
-        const float4* cp = reinterpret_cast<const float4*>(rope_cs + qrow_c * 32);
-        const float4* sp = reinterpret_cast<const float4*>(rope_sn + qrow_c * 32);
+        const float4* cp = reinterpret_cast<const float4*>(rope_csn + qrow_c * 64);
 #pragma unroll
-        for (int s4 = 0; s4 < 8; ++s4) {
-            const float4 c4 = cp[s4], n4 = sp[s4];
-            const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, ss[4] = {n4.x, n4.y, n4.z, n4.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float2 t = qp2[s4 * 4 + e];
-                const float r0 = t.x * cc[e] - t.y * ss[e], r1 = t.y * cc[e] + t.x * ss[e];
-                qreg[s4 * 4 + e] = (h ? r1 : r0) * kScale;
-            }
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const float4 cs = cp[s2];                      // (c, s) of pairs 2 s2 and 2 s2 + 1
+            const float2 t0 = qp2[2 * s2], t1 = qp2[2 * s2 + 1];
+            const float a0 = t0.x * cs.x - t0.y * cs.y, a1 = t0.y * cs.x + t0.x * cs.y;
+            const float b0 = t1.x * cs.z - t1.y * cs.w, b1 = t1.y * cs.z + t1.x * cs.w;
+            qreg[2 * s2] = (h ? a1 : a0) * kScale;
+            qreg[2 * s2 + 1] = (h ? b1 : b0) * kScale;
         }
     } else {
 #pragma unroll
@@ -118,12 +114,10 @@ __global__ __launch_bounds__(256, 4) void lg_attention_kernel(   // 4 workgroups
             if (key < nk) {
                 rk[it] = *reinterpret_cast<const float4*>(kbase + (size_t)key * ld + sdq * 4);
                 rv[it] = *reinterpret_cast<const float4*>(vbase + (size_t)key * ld + sdq * 4);
-                if (ROPE == 1) {   // dims 4 sdq .. 4 sdq + 3 = pairs f = 2 sdq, 2 sdq + 1
-                    const size_t trow = ((size_t)kvseq * Lk + key) * 32 + 2 * sdq;
-                    const float2 c2 = *reinterpret_cast<const float2*>(rope_cs + trow);
-                    const float2 s2 = *reinterpret_cast<const float2*>(rope_sn + trow);
+                if (ROPE) {   // dims 4 sdq .. 4 sdq + 3 = pairs f = 2 sdq, 2 sdq + 1
+                    const float4 cs = *reinterpret_cast<const float4*>(rope_csn + ((size_t)kvseq * Lk + key) * 64 + 4 * sdq);
                     const float4 t = rk[it];
-                    rk[it] = make_float4(t.x * c2.x - t.y * s2.x, t.y * c2.x + t.x * s2.x, t.z * c2.y - t.w * s2.y, t.w * c2.y + t.z * s2.y);
+                    rk[it] = make_float4(t.x * cs.x - t.y * cs.y, t.y * cs.x + t.x * cs.y, t.z * cs.z - t.w * cs.w, t.w * cs.z + t.z * cs.w);
                 }
             }
         }
@@ -283,14 +277,13 @@ size_t lg_attention_part_bytes(int nseq, int Lq) {   // scratch of the split-key
 }
 
 void launch_lg_attention(hipStream_t s, const float* q, const float* k, const float* v, int ld, float* out, int nseq, int Lq,
-                         int Lk, const int* qlen, const int* klen, const int* kv_map, float* part, const float* rope_cs,
-                         const float* rope_sn, bool rope_k) {
+                         int Lk, const int* qlen, const int* klen, const int* kv_map, float* part, const float* rope_csn) {
     const int nqb = (Lq + AT_Q - 1) / AT_Q;
     // (sequence, head) units, padded to a multiple of 8: the kernels deal their blocks round-robin over the 8 XCDs and map
     // block -> (unit, query block) by unit = (t / nqb) * 8 + xcd, which is a bijection only for a multiple of 8 units
     // (2P sequences always are; the per-frame self block of the stream mode runs on B sequences, e.g. 33)
     const int units8 = (4 * nseq + 7) / 8 * 8;
-    const bool rope = rope_cs != nullptr;
+    const bool rope = rope_csn != nullptr;
     // latency regime: fewer (sequence, head, query block) units than CUs -> split the keys until the chip is covered
     static const int split_env = tune_int("RFE_ATT_SPLIT", -1);   // 0/1 = off, n = force n ranges
     if (part && (size_t)nseq * Lq <= AT_SPLIT_MAX_ROWS && split_env != 0 && split_env != 1) {
@@ -299,15 +292,12 @@ void launch_lg_attention(hipStream_t s, const float* q, const float* k, const fl
         while (ns < AT_SPLIT_MAX && units * ns * 2 <= 256 && Lk / (ns * 2) >= 2 * AT_K) ns *= 2;
         if (split_env > 1) ns = split_env < AT_SPLIT_MAX ? split_env : AT_SPLIT_MAX;
         if (ns > 1) {
-            if (rope && rope_k)
-                hipLaunchKernelGGL((lg_attention_kernel<0, true, 1>), dim3(nqb * units8, ns), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk,
-                                   nqb, qlen, klen, kv_map, 1, part, nseq, rope_cs, rope_sn);
-            else if (rope)
-                hipLaunchKernelGGL((lg_attention_kernel<0, true, 2>), dim3(nqb * units8, ns), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk,
-                                   nqb, qlen, klen, kv_map, 1, part, nseq, rope_cs, rope_sn);
+            if (rope)
+                hipLaunchKernelGGL((lg_attention_kernel<0, true, true>), dim3(nqb * units8, ns), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk,
+                                   nqb, qlen, klen, kv_map, 1, part, nseq, rope_csn);
             else
-                hipLaunchKernelGGL((lg_attention_kernel<0, true, 0>), dim3(nqb * units8, ns), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk,
-                                   nqb, qlen, klen, kv_map, 1, part, nseq, rope_cs, rope_sn);
+                hipLaunchKernelGGL((lg_attention_kernel<0, true, false>), dim3(nqb * units8, ns), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk,
+                                   nqb, qlen, klen, kv_map, 1, part, nseq, rope_csn);
             hipLaunchKernelGGL(lg_attention_combine_kernel, dim3((unsigned)(((size_t)nseq * Lq * 64 + 255) / 256)), dim3(256), 0, s, part,
                                ns, nseq, Lq, qlen, out);
             return;
@@ -315,17 +305,15 @@ void launch_lg_attention(hipStream_t s, const float* q, const float* k, const fl
     }
 #ifdef RFE_TUNING
     const int abl = tune_int("RFE_DBG_ATT_ABL", 0);   // timing ablations (wrong results), tuning build only
-    if (abl == 1) { hipLaunchKernelGGL((lg_attention_kernel<1>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0, nullptr, nseq, rope_cs, rope_sn); return; }
-    if (abl == 2) { hipLaunchKernelGGL((lg_attention_kernel<2>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0, nullptr, nseq, rope_cs, rope_sn); return; }
-    if (abl == 3) { hipLaunchKernelGGL((lg_attention_kernel<3>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0, nullptr, nseq, rope_cs, rope_sn); return; }
+    if (abl == 1) { hipLaunchKernelGGL((lg_attention_kernel<1>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0, nullptr, nseq, rope_csn); return; }
+    if (abl == 2) { hipLaunchKernelGGL((lg_attention_kernel<2>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0, nullptr, nseq, rope_csn); return; }
+    if (abl == 3) { hipLaunchKernelGGL((lg_attention_kernel<3>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0, nullptr, nseq, rope_csn); return; }
 #endif
     static const int prio = tune_int("RFE_ATT_PRIO", 1);   // s_setprio(1) around the MFMA clusters (+0.8 %); RFE_ATT_PRIO=0 disables
-    if (rope && rope_k)
-        hipLaunchKernelGGL((lg_attention_kernel<0, false, 1>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nullptr, nseq, rope_cs, rope_sn);
-    else if (rope)
-        hipLaunchKernelGGL((lg_attention_kernel<0, false, 2>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nullptr, nseq, rope_cs, rope_sn);
+    if (rope)
+        hipLaunchKernelGGL((lg_attention_kernel<0, false, true>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nullptr, nseq, rope_csn);
     else
-        hipLaunchKernelGGL((lg_attention_kernel<0, false, 0>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nullptr, nseq, rope_cs, rope_sn);
+        hipLaunchKernelGGL((lg_attention_kernel<0, false, false>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nullptr, nseq, rope_csn);
 }
 
 // ---------------------------------------------------------------- LayerNorm(512) + GELU(erf), in place

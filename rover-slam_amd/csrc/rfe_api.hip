@@ -114,8 +114,6 @@ extern "C" void rfe_destroy(rfe_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    if (c->aux) { rfe_destroy(c->aux); c->aux = nullptr; }
-    for (auto& e : c->ev_st) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     prof_collect(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
@@ -576,7 +574,7 @@ extern "C" int rfe_extract_u8_bin(rfe_ctx* c, const uint8_t* img, int H, int W, 
 namespace {
 
 struct LgBuffers {
-    float *x, *kn, *cs, *sn, *qkv, *ctx, *msg, *h, *md, *z, *sim, *rowlse, *collse, *mx0, *apart;
+    float *x, *kn, *csn, *qkv, *ctx, *msg, *h, *md, *z, *sim, *rowlse, *collse, *mx0, *apart;
     int32_t *a0, *a1, *lens, *kvmap;
     char* extra;   // caller-sized scratch region carved after the fixed buffers
 };
@@ -585,7 +583,7 @@ size_t lg_ws_bytes(int P, int L, size_t extra_bytes = 0) {
     const size_t rows = (size_t)2 * P * L;
     size_t t = 0;
     t += al(rows * 256 * 4) * 4;  // x ctx msg md
-    t += al(rows * 2 * 4) + al(rows * 32 * 4) * 2 + al(rows * 768 * 4) + al(rows * 512 * 4) + al(rows * 4);
+    t += al(rows * 2 * 4) + al(rows * 64 * 4) + al(rows * 768 * 4) + al(rows * 512 * 4) + al(rows * 4);
     t += al((size_t)P * L * L * 4);
     t += al((size_t)P * L * 4) * 5;
     t += al((size_t)2 * P * 4) * 2;
@@ -597,7 +595,7 @@ void lg_carve(void* ws, int P, int L, LgBuffers& b, size_t extra_bytes = 0) {
     Bump a(ws);
     b.x = a.take<float>(rows * 256); b.ctx = a.take<float>(rows * 256); b.msg = a.take<float>(rows * 256);
     b.md = a.take<float>(rows * 256);
-    b.kn = a.take<float>(rows * 2); b.cs = a.take<float>(rows * 32); b.sn = a.take<float>(rows * 32);
+    b.kn = a.take<float>(rows * 2); b.csn = a.take<float>(rows * 64);
     b.qkv = a.take<float>(rows * 768); b.h = a.take<float>(rows * 512); b.z = a.take<float>(rows);
     b.sim = a.take<float>((size_t)P * L * L);
     b.rowlse = a.take<float>((size_t)P * L); b.collse = a.take<float>((size_t)P * L); b.mx0 = a.take<float>((size_t)P * L);
@@ -628,21 +626,13 @@ void lg_ffn(rfe_ctx* c, LgBuffers& b, float* x, const float* second, int rows, c
 }
 
 // self block on `nseq` sequences of L tokens held in x (in place); scratch: b.qkv, b.ctx, b.msg, b.h
-void lg_self_block(rfe_ctx* c, LgBuffers& b, const LgLayerDev& Lw, float* x, const float* cs, const float* sn,
-                   const int32_t* lens, int nseq, int L) {
+void lg_self_block(rfe_ctx* c, LgBuffers& b, const LgLayerDev& Lw, float* x, const float* csn, const int32_t* lens, int nseq, int L) {
     hipStream_t s = c->stream;
     const int rows = nseq * L;
-    // q,k,v = Wqkv x + b.  Rotary: k in the GEMM epilogue (only the workgroups of the k column tile take the LDS-transposed
-    // epilogue), q by the attention kernel as it loads its Q fragment.  RFE_ROPE_MODE (tuning build): 0 = q and k in the GEMM
-    // (round 1), 1 = q and k in the attention kernel, 2 = default.  All three are bit-identical.
-    static const int rope_mode = tune_int("RFE_ROPE_MODE", 2);
-    { ProfScope p(c, "lg_qkv");
-      GemmArgs a = gemm_plain(x, 256, Lw.wqkv, 256, Lw.bqkv, b.qkv, 768, rows, 768, 256);
-      if (rope_mode != 1) { a.rope_cs = cs; a.rope_sn = sn; a.rope_ncols = 512; a.rope_n0 = rope_mode == 2 ? 256 : 0; }
-      launch_gemm_nt(s, a); }
+    // q,k,v = Wqkv x + b (plain epilogue); the rotary of q and k is applied by the attention kernel as it loads them
+    { ProfScope p(c, "lg_qkv"); launch_gemm_nt(s, gemm_plain(x, 256, Lw.wqkv, 256, Lw.bqkv, b.qkv, 768, rows, 768, 256)); }
     { ProfScope p(c, "lg_attention");
-      launch_lg_attention(s, b.qkv, b.qkv + 256, b.qkv + 512, 768, b.ctx, nseq, L, L, lens, lens, nullptr, lg_part(b, nseq, L),
-                          rope_mode == 0 ? nullptr : cs, rope_mode == 0 ? nullptr : sn, rope_mode == 1); }
+      launch_lg_attention(s, b.qkv, b.qkv + 256, b.qkv + 512, 768, b.ctx, nseq, L, L, lens, lens, nullptr, lg_part(b, nseq, L), csn); }
     if (c->opt_lg_fold) {
         lg_ffn(c, b, x, b.ctx, rows, Lw.w1f, Lw.b1f, Lw.lng, Lw.lnb, Lw.w2, Lw.b2);
     } else {
@@ -652,17 +642,17 @@ void lg_self_block(rfe_ctx* c, LgBuffers& b, const LgLayerDev& Lw, float* x, con
 }
 
 // runs the 9 layers + assignment on already staged b.x / b.kn / b.lens / b.kvmap.
-// first_self_done: b.x already holds the output of layer 0's self block and b.cs / b.sn the rotary tables
+// first_self_done: b.x already holds the output of layer 0's self block and b.csn the rotary table
 // (stream mode computes them once per FRAME instead of once per pair side).
 int lg_forward(rfe_ctx* c, LgBuffers& b, int P, int L, float thr, int cap, int32_t* S, int32_t* pairs, float* ms,
                float* scores_opt, bool first_self_done = false) {
     hipStream_t s = c->stream;
     const LgWeightsDev& W = c->lg;
     const int rows = 2 * P * L, nseq = 2 * P;
-    if (!first_self_done) { ProfScope p(c, "lg_misc"); launch_lg_posenc(s, b.kn, W.wr, rows, b.cs, b.sn); }
+    if (!first_self_done) { ProfScope p(c, "lg_misc"); launch_lg_posenc(s, b.kn, W.wr, rows, b.csn); }
     for (int l = 0; l < LG_LAYERS; ++l) {
         const LgLayerDev& Lw = W.L[l];
-        if (l > 0 || !first_self_done) lg_self_block(c, b, Lw, b.x, b.cs, b.sn, b.lens, nseq, L);
+        if (l > 0 || !first_self_done) lg_self_block(c, b, Lw, b.x, b.csn, b.lens, nseq, L);
         // ---- cross block
         { ProfScope p(c, "lg_cross_qkv"); launch_gemm_nt(s, gemm_plain(b.x, 256, Lw.cwqkv, 256, Lw.cbqkv, b.qkv, 512, rows, 512, 256)); }
         { ProfScope p(c, "lg_attention"); launch_lg_attention(s, b.qkv, b.qkv, b.qkv + 256, 512, b.ctx, nseq, L, L, b.lens, b.lens, b.kvmap, lg_part(b, nseq, L)); }
@@ -810,8 +800,8 @@ extern "C" int rfe_extract_match_stream_dev(rfe_ctx* c, const uint8_t* img, int 
     if (!S || !pairs || !ms) return fail(c, RFE_ERR_INVALID, "stream: null match output");
     const int P = B - 1, L = ((Kmax + 3) / 4) * 4;
     const size_t kn_bytes = al((size_t)B * Kmax * 8);        // normalised keypoints of all B frames
-    const size_t rot_bytes = al((size_t)B * L * 32 * 4);      // per-FRAME rotary tables (cos, sin)
-    const size_t extra_bytes = kn_bytes + 2 * rot_bytes;
+    const size_t rot_bytes = al((size_t)B * L * 64 * 4);      // per-FRAME rotary table (cos, sin pairs)
+    const size_t extra_bytes = kn_bytes + rot_bytes;
     if ((rc = ensure_ws(c, &c->ws_lg, &c->ws_lg_bytes, lg_ws_bytes(P, L, extra_bytes)))) return rc;
     LgBuffers b;
     lg_carve(c->ws_lg, P, L, b, extra_bytes);
@@ -827,22 +817,20 @@ extern "C" int rfe_extract_match_stream_dev(rfe_ctx* c, const uint8_t* img, int 
     // Every interior frame is side 1 of pair i-1 and side 0 of pair i, and layer 0's self block depends on
     // the frame alone: run it (and the positional encoding) once per FRAME, then scatter into the pair layout.
     float* xf = b.md;                        // [B, L, 256]: md ([2P, L, 256], B <= 2P) is only used by the assignment at the end
-    float* csf = (float*)(b.extra + kn_bytes);              // [B*L, 32] each, own scratch (the similarity buffer
-    float* snf = (float*)(b.extra + kn_bytes + rot_bytes);  //  [P, L, L] is too small for them when L < 64 (P+1)/P)
+    float* csnf = (float*)(b.extra + kn_bytes);             // [B*L, 32, 2], own scratch (the similarity buffer [P, L, L] is too small
+                                                            //  for it when L < 64 (P+1)/P)
     { ProfScope p(c, "lg_misc");
       launch_normalize_kpts(s, kxy, (int64_t)B * Kmax, H, W, kn_all);
-      launch_lg_posenc(s, kn_all, c->lg.wr, B * L, csf, snf);
+      launch_lg_posenc(s, kn_all, c->lg.wr, B * L, csnf);
       launch_copy_f32(s, desc, xf, (int64_t)B * L * 256);
       hipLaunchKernelGGL(lg_setup_kernel, dim3((2 * P + 255) / 256), dim3(256), 0, s, n, n + 1, P, Kmax, Kmax, b.lens, b.kvmap); }
-    lg_self_block(c, b, c->lg.L[0], xf, csf, snf, n, B, L);
+    lg_self_block(c, b, c->lg.L[0], xf, csnf, n, B, L);
     { ProfScope p(c, "lg_misc");
       const size_t half = (size_t)P * L;
       launch_copy_f32(s, xf, b.x, (int64_t)half * 256);
       launch_copy_f32(s, xf + (size_t)L * 256, b.x + half * 256, (int64_t)half * 256);
-      launch_copy_f32(s, csf, b.cs, (int64_t)half * 32);
-      launch_copy_f32(s, csf + (size_t)L * 32, b.cs + half * 32, (int64_t)half * 32);
-      launch_copy_f32(s, snf, b.sn, (int64_t)half * 32);
-      launch_copy_f32(s, snf + (size_t)L * 32, b.sn + half * 32, (int64_t)half * 32); }
+      launch_copy_f32(s, csnf, b.csn, (int64_t)half * 64);
+      launch_copy_f32(s, csnf + (size_t)L * 64, b.csn + half * 64, (int64_t)half * 64); }
     RFE_HIP(c, hipGetLastError());
     return lg_forward(c, b, P, L, filter_thr, Kmax, S, pairs, ms, nullptr, true);
 }
@@ -924,30 +912,17 @@ extern "C" int rfe_stereo_frame_dev(rfe_ctx* c, const uint8_t* imgL, const uint8
     int32_t* sadv = (int32_t*)p; p += b_sad;
     float* kn_prev = (float*)p; p += b_kn; float* kn_cur = (float*)p; p += b_kn;
     float* desc_prev = (float*)p; p += b_desc; int32_t* n_prev = (int32_t*)p;
-    // Two lanes, like the reference's two extractor threads (src/Frame.cc:142-147): the LEFT view and the temporal LightGlue
-    // match form the critical path on the ctx stream; the RIGHT view and ComputeStereoMatches (which needs both views but
-    // nothing from LightGlue) run on a second lane -- an internal ctx with its own streams and workspace that shares the
-    // device weights -- and fill the chip next to the latency-bound single-pair LightGlue launches.
-    if (!c->aux) {
-        if ((rc = rfe_init(c->device, &c->aux))) return fail(c, rc, std::string("stereo_frame: second lane: ") + rfe_last_error(nullptr));
-        for (auto& e : c->ev_st) RFE_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
-    rfe_ctx* a = c->aux;
-    a->sp = c->sp; a->sp_hold = c->sp_hold; a->has_sp = true;    // same device copy (kept alive by both holders)
+    // both views as ONE batch of 2 (the reference runs them on two threads, src/Frame.cc:142-147).  Measured alternative: the
+    // right view + stereo match on a second lane (own streams / workspace) next to left view + LightGlue -- 3.52 ms per stereo
+    // frame against 3.26 ms for this form: two batch-1 extractions are no faster than one batch of 2, and the co-running
+    // kernels slow the latency-bound LightGlue chain (profiles/r02_pmc.md)
     RFE_HIP(c, hipMemcpy2DAsync(d_img, (size_t)W, imgL, (size_t)stride, (size_t)W, (size_t)H, hipMemcpyDeviceToDevice, s));
     RFE_HIP(c, hipMemcpy2DAsync(d_img + (size_t)H * W, (size_t)W, imgR, (size_t)stride, (size_t)W, (size_t)H, hipMemcpyDeviceToDevice, s));
-    RFE_HIP(c, hipEventRecord(c->ev_st[0], s));
-    RFE_HIP(c, hipStreamWaitEvent(a->stream, c->ev_st[0], 0));
-    if ((rc = sp_forward(a, d_img + (size_t)H * W, H, W, W, 1, Kmax, thr, n + 1, kxy + (size_t)Kmax * 2, score + Kmax, desc + (size_t)Kmax * 256)))
-        return fail(c, rc, a->err);
-    if ((rc = sp_forward(c, d_img, H, W, W, 1, Kmax, thr, n, kxy, score, desc))) return rc;
-    RFE_HIP(c, hipEventRecord(c->ev_st[1], s));                  // left features ready
-    RFE_HIP(c, hipStreamWaitEvent(a->stream, c->ev_st[1], 0));
+    if ((rc = sp_forward(c, d_img, H, W, W, 2, Kmax, thr, n, kxy, score, desc))) return rc;
     // Frame::ComputeStereoMatches (src/Frame.cc:1159-1446) on the device-resident features; counts stay on the device
-    { ProfScope ps(c, "stereo_match", a->stream);
-      launch_stereo_match_counts(a->stream, d_img, d_img + (size_t)H * W, H, W, W, kxy, kxy + (size_t)Kmax * 2, Kmax, n, desc,
+    { ProfScope ps(c, "stereo_match");
+      launch_stereo_match_counts(s, d_img, d_img + (size_t)H * W, H, W, W, kxy, kxy + (size_t)Kmax * 2, Kmax, n, desc,
                                  desc + (size_t)Kmax * 256, mb, mbf, uRight, depth, sadv); }
-    RFE_HIP(c, hipEventRecord(c->ev_st[2], a->stream));
     // temporal match: previous left view (set 0) against this left view (set 1), true image size like the Frame overload
     // of MatchingPoints_onnx (src/Matchers/SPmatcher.cc:457-542, :463-464)
     { ProfScope ps(c, "lg_misc"); launch_normalize_kpts(s, kxy, Kmax, H, W, kn_cur); }
@@ -967,7 +942,6 @@ extern "C" int rfe_stereo_frame_dev(rfe_ctx* c, const uint8_t* imgL, const uint8
       RFE_HIP(c, hipMemcpyAsync(desc_prev, desc, (size_t)Kmax * 1024, hipMemcpyDeviceToDevice, s));
       RFE_HIP(c, hipMemcpyAsync(n_prev, n, 4, hipMemcpyDeviceToDevice, s)); }
     c->st_have_prev = true;
-    RFE_HIP(c, hipStreamWaitEvent(s, c->ev_st[2], 0));           // join: the call is complete in ctx-stream order
     RFE_HIP(c, hipGetLastError());
     return RFE_OK;
 }

@@ -77,11 +77,6 @@ struct GemmArgs {
     long long sA, sA2, sB, sC, sR;    // batch strides (grid.z)
     const int* m_valid;               // optional per-batch valid row count (rows >= m_valid skipped)
     int batch;
-    const float* rope_cs;             // optional fused rotary epilogue: cos/sin tables [M][32], applied to
-    const float* rope_sn;             //   columns n < rope_ncols in adjacent pairs (2f, 2f+1), f = (n%64)/2
-    int rope_ncols;                   //   ... and n >= rope_n0
-    int rope_n0;
-    int rend;                         // residual added in the direct (D-layout) epilogue
 };
 
 }  // namespace rfe
@@ -105,8 +100,6 @@ struct rfe_ctx {
     void* ws_tmp = nullptr; size_t ws_tmp_bytes = 0; // test hooks
     void* ws_st = nullptr; size_t ws_st_bytes = 0;   // stereo stream state: staged views, previous left view's features
     int st_H = 0, st_W = 0, st_K = 0; bool st_have_prev = false;
-    rfe_ctx* aux = nullptr;              // second lane of the stereo stream: the right view + stereo match run here, concurrently
-    hipEvent_t ev_st[3] = {nullptr, nullptr, nullptr};   //   with the left view + LightGlue on the main lane (shares the weights)
     // profiling
     bool prof = false;
     std::string prof_filter;          // non-empty: only this stage records events
@@ -161,13 +154,12 @@ void launch_descmap_norm(hipStream_t s, float* dmap, int64_t cells);
 void launch_desc_sample(hipStream_t s, const float* dmap, int B, int Hc, int Wc, int H, int W,
                         const int32_t* n, const int32_t* kxy, int Kmax, float* desc, uint8_t* desc_bin /*optional u8 [B,Kmax,256] = desc > 0*/);
 // lg_kernels.hip
-void launch_lg_posenc(hipStream_t s, const float* kn, const float* wr, int rows, float* cs, float* sn);
+void launch_lg_posenc(hipStream_t s, const float* kn, const float* wr, int rows, float* csn /*[rows,32] (cos, sin) pairs*/);
 void launch_lg_attention(hipStream_t s, const float* q, const float* k, const float* v, int ld /*row stride of q,k,v*/,
                          float* out, int nseq, int Lq, int Lk, const int* qlen, const int* klen,
                          const int* kv_map /*seq -> kv seq index, or null = identity*/,
                          float* part /*lg_attention_part_bytes(nseq, Lq) of scratch for the split-key variant, or null*/,
-                         const float* rope_cs = nullptr, const float* rope_sn = nullptr /*rotary tables [nseq*Lq, 32] of the self blocks*/,
-                         bool rope_k = false /*true: rotate q and k here; false: q only (k was rotated by the projection)*/);
+                         const float* rope_csn = nullptr /*self blocks: rotary table [nseq*Lq, 32] of (cos, sin) pairs, applied to q and k on load*/);
 size_t lg_attention_part_bytes(int nseq, int Lq);
 void launch_lg_ln_gelu(hipStream_t s, float* h, const float* g, const float* b, int64_t rows);
 void launch_lg_assign(hipStream_t s, const float* sim, const float* z0, const float* z1, int P, int L,
