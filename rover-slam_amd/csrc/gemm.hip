@@ -27,7 +27,7 @@ constexpr int BK = 32, LDT = BK + 1;
 // alpha like the oracle.  (Round 1's LDS-transposed whole-row epilogue, which also applied the LightGlue rotary to q | k, is gone:
 // the rotary moved into the attention kernel's loads -- same arithmetic, same time overall, one epilogue fewer here.)
 // PFT: register prefetch of the next K tile under the MFMAs (always on for the 64-row latency tiles).
-template <int MB, int NB, bool RES, bool PFT = false>
+template <int MB, int NB, bool RES, bool PFT = false, bool LNA = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     constexpr int BM = MB * 64, BN = NB * 64;
     __shared__ float lds_ab[(BM + BN) * LDT];   // A tile | B tile
@@ -82,6 +82,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
         int row = lrow + 32 * it; row = row < nlast ? row : nlast;
         boff[it] = row * g.ldb + lkq * 4;
     }
+    // LNA: LayerNorm statistics of this thread's A rows from the producer's partial sums (one pass: var = E[x^2] - mean^2)
+    float ln_mean[A_IT], ln_rstd[A_IT];
+    if (LNA) {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            int row = lrow + 32 * it; row = row < mlast ? row : mlast;
+            const float* sp = g.stats_in + ((size_t)(m0 + row) + (size_t)z * g.M) * g.stats_p * 2;
+            float s1 = 0.f, s2 = 0.f;
+            for (int p = 0; p < g.stats_p; ++p) { s1 += sp[2 * p]; s2 += sp[2 * p + 1]; }
+            const float inv = 1.0f / (float)g.K, mean = s1 * inv;
+            float var = s2 * inv - mean * mean;
+            var = var > 0.f ? var : 0.f;
+            ln_mean[it] = mean; ln_rstd[it] = 1.0f / sqrtf(var + 1e-5f);
+        }
+    }
     float* const da = As + lrow * LDT + lkq * 4;
     float* const db = Bs + lrow * LDT + lkq * 4;
     const float* const ap = As + (wm * MB * 32 + i) * LDT + h;
@@ -92,8 +107,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     // loop of the current one (16 VGPRs).  The throughput tiles rely on the other resident workgroups instead
     // (register prefetch measured slower there).
     constexpr bool PF = (MB == 1) || PFT;
-    float4 ra[A_IT], rb[B_IT];
+    float4 ra[A_IT], rb[B_IT], rg, rbeta;
     auto load_tile = [&](int k0) {
+        if (LNA) { rg = *reinterpret_cast<const float4*>(g.ln_g + k0 + lkq * 4); rbeta = *reinterpret_cast<const float4*>(g.ln_b + k0 + lkq * 4); }
         if (A2t && k0 >= g.K1) {
             const float* base = A2t + (k0 - g.K1);
 #pragma unroll
@@ -112,7 +128,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
         if (!PF) load_tile(k0);
         __syncthreads();   // previous tile fully consumed
 #pragma unroll
-        for (int it = 0; it < A_IT; ++it) { float* d = da + it * 32 * LDT; d[0] = ra[it].x; d[1] = ra[it].y; d[2] = ra[it].z; d[3] = ra[it].w; }
+        for (int it = 0; it < A_IT; ++it) {
+            float4 v = ra[it];
+            if (LNA) {   // same operation order as the stand-alone LayerNorm + GELU kernel: ((a - mean) * rstd) * g + b, then 0.5 v (1 + erf(v / sqrt 2))
+                float e[4] = {v.x, v.y, v.z, v.w};
+                const float gg[4] = {rg.x, rg.y, rg.z, rg.w}, bb[4] = {rbeta.x, rbeta.y, rbeta.z, rbeta.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float t = (e[q] - ln_mean[it]) * ln_rstd[it] * gg[q] + bb[q];
+                    e[q] = 0.5f * t * (1.0f + erff(t * 0.70710678118654752f));
+                }
+                v = make_float4(e[0], e[1], e[2], e[3]);
+            }
+            float* d = da + it * 32 * LDT; d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) { float* d = db + it * 32 * LDT; d[0] = rb[it].x; d[1] = rb[it].y; d[2] = rb[it].z; d[3] = rb[it].w; }
         __syncthreads();
@@ -168,26 +197,73 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
                 }
             }
     }
+    if (g.stats_out) {
+        // Per-row (sum, sum of squares) of this wave's NB*32 stored columns.  A lane holds T = MB*16 rows (one value per row after
+        // the in-lane sum over its NB columns); the 32 lanes of a half-wave hold the same rows for 32 different columns.  Butterfly
+        // that halves the rows kept per lane at every step (T/2, ..., 1 exchanges instead of 5 T): lane i ends with row i's total.
+        constexpr int T = MB * 16;
+        float s1[T], s2[T];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int n = n0 + (wn * NB + nb) * 32 + i;
+                    float v = acc[mb][nb][r] * g.alpha;
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    if (n >= g.N) v = 0.f;
+                    a1 += v; a2 = fmaf(v, v, a2);
+                }
+                s1[mb * 16 + r] = a1; s2[mb * 16 + r] = a2;
+            }
+#pragma unroll
+        for (int o = T / 2; o >= 1; o >>= 1) {
+            const bool up = (i & o) != 0;
+#pragma unroll
+            for (int j = 0; j < o; ++j) {
+                const float k1 = up ? s1[j + o] : s1[j], t1 = up ? s1[j] : s1[j + o];
+                const float k2 = up ? s2[j + o] : s2[j], t2 = up ? s2[j] : s2[j + o];
+                s1[j] = k1 + __shfl_xor(t1, o);
+                s2[j] = k2 + __shfl_xor(t2, o);
+            }
+        }
+        if (T < 32) { s1[0] += __shfl_xor(s1[0], 16); s2[0] += __shfl_xor(s2[0], 16); }   // 16 rows on 32 lanes: lane bit 4 still to fold
+        // lane i (< T) of half h now holds local row t = i: mb = t / 16, r = t % 16 -> tile row (r & 3) + 8 (r >> 2) + 4 h
+        if (i < T) {
+            const int r = i & 15;
+            const int m = m0 + (wm * MB + (i >> 4)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m < M) {
+                const int P = (int)gridDim.x * 2;
+                float* sp = g.stats_out + (((size_t)m + (size_t)z * g.M) * P + blockIdx.x * 2 + wn) * 2;
+                sp[0] = s1[0]; sp[1] = s2[0];
+            }
+        }
+    }
 }
 
-void launch_gemm_nt(hipStream_t s, const GemmArgs& g_in) {
+int launch_gemm_nt(hipStream_t s, const GemmArgs& g_in) {
     GemmArgs g = g_in;
     const int batch = g.batch > 0 ? g.batch : 1;
     auto tiles = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * batch; };
-    const bool res = g.R != nullptr;
+    const bool res = g.R != nullptr, lna = g.stats_in != nullptr;
     static const bool pft = tune_int("RFE_GEMM_PF", 1) != 0;   // register prefetch of the next K tile also on the 128-row tiles (+1 % on ffn1 / ffn2, profiles/r02_pmc.md); RFE_GEMM_PF=0 (tuning build) disables
 #define RFE_GEMM_GO(MB_, NB_, GRID)                                                                  \
     do {                                                                                             \
-        if (pft && MB_ == 2 && res) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, true, MB_ == 2>), GRID, dim3(256), 0, s, g);    \
+        if (lna) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, true, false, true>), GRID, dim3(256), 0, s, g);   /* LN + GELU on A: residual variant, no prefetch (registers) */ \
+        else if (pft && MB_ == 2 && res) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, true, MB_ == 2>), GRID, dim3(256), 0, s, g);    \
         else if (pft && MB_ == 2) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, false, MB_ == 2>), GRID, dim3(256), 0, s, g);     \
         else if (res) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, true>), GRID, dim3(256), 0, s, g);    \
         else hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, false>), GRID, dim3(256), 0, s, g);        \
     } while (0)
     // largest tile that still gives every CU a workgroup; small problems (single-pair latency) fall to 64 x 64
-    if (g.N % 256 == 0 && tiles(128, 256) >= 256) RFE_GEMM_GO(2, 4, dim3(g.N / 256, (g.M + 127) / 128, batch));
-    else if (tiles(128, 128) >= 256 || g.M > 8192) RFE_GEMM_GO(2, 2, dim3((g.N + 127) / 128, (g.M + 127) / 128, batch));
-    else if (tiles(64, 128) >= 256) RFE_GEMM_GO(1, 2, dim3((g.N + 127) / 128, (g.M + 63) / 64, batch));
-    else RFE_GEMM_GO(1, 1, dim3((g.N + 63) / 64, (g.M + 63) / 64, batch));
+    int ntiles;
+    if (g.N % 256 == 0 && tiles(128, 256) >= 256) { ntiles = g.N / 256; RFE_GEMM_GO(2, 4, dim3(g.N / 256, (g.M + 127) / 128, batch)); }
+    else if (tiles(128, 128) >= 256 || g.M > 8192) { ntiles = (g.N + 127) / 128; RFE_GEMM_GO(2, 2, dim3((g.N + 127) / 128, (g.M + 127) / 128, batch)); }
+    else if (tiles(64, 128) >= 256) { ntiles = (g.N + 127) / 128; RFE_GEMM_GO(1, 2, dim3((g.N + 127) / 128, (g.M + 63) / 64, batch)); }
+    else { ntiles = (g.N + 63) / 64; RFE_GEMM_GO(1, 1, dim3((g.N + 63) / 64, (g.M + 63) / 64, batch)); }
+    return g.stats_out ? 2 * ntiles : 0;
 }
 
 }  // namespace rfe

@@ -574,7 +574,7 @@ extern "C" int rfe_extract_u8_bin(rfe_ctx* c, const uint8_t* img, int H, int W, 
 namespace {
 
 struct LgBuffers {
-    float *x, *kn, *csn, *qkv, *ctx, *msg, *h, *md, *z, *sim, *rowlse, *collse, *mx0, *apart;
+    float *x, *kn, *csn, *lnstat, *qkv, *ctx, *msg, *h, *md, *z, *sim, *rowlse, *collse, *mx0, *apart;
     int32_t *a0, *a1, *lens, *kvmap;
     char* extra;   // caller-sized scratch region carved after the fixed buffers
 };
@@ -583,7 +583,7 @@ size_t lg_ws_bytes(int P, int L, size_t extra_bytes = 0) {
     const size_t rows = (size_t)2 * P * L;
     size_t t = 0;
     t += al(rows * 256 * 4) * 4;  // x ctx msg md
-    t += al(rows * 2 * 4) + al(rows * 64 * 4) + al(rows * 768 * 4) + al(rows * 512 * 4) + al(rows * 4);
+    t += al(rows * 2 * 4) + al(rows * 64 * 4) + al(rows * 32 * 4) + al(rows * 768 * 4) + al(rows * 512 * 4) + al(rows * 4);
     t += al((size_t)P * L * L * 4);
     t += al((size_t)P * L * 4) * 5;
     t += al((size_t)2 * P * 4) * 2;
@@ -595,7 +595,7 @@ void lg_carve(void* ws, int P, int L, LgBuffers& b, size_t extra_bytes = 0) {
     Bump a(ws);
     b.x = a.take<float>(rows * 256); b.ctx = a.take<float>(rows * 256); b.msg = a.take<float>(rows * 256);
     b.md = a.take<float>(rows * 256);
-    b.kn = a.take<float>(rows * 2); b.csn = a.take<float>(rows * 64);
+    b.kn = a.take<float>(rows * 2); b.csn = a.take<float>(rows * 64); b.lnstat = a.take<float>(rows * 32);   // <= 16 partial pairs per row
     b.qkv = a.take<float>(rows * 768); b.h = a.take<float>(rows * 512); b.z = a.take<float>(rows);
     b.sim = a.take<float>((size_t)P * L * L);
     b.rowlse = a.take<float>((size_t)P * L); b.collse = a.take<float>((size_t)P * L); b.mx0 = a.take<float>((size_t)P * L);
@@ -614,14 +614,21 @@ float* lg_part(const LgBuffers& b, int nseq, int L) { return (b.apart && lg_atte
 void lg_ffn(rfe_ctx* c, LgBuffers& b, float* x, const float* second, int rows, const float* w1, const float* b1, const float* g,
             const float* be, const float* w2, const float* b2) {
     hipStream_t s = c->stream;
+    // LayerNorm(512) + GELU between the two Linears is fused across them: ffn.0's epilogue leaves per-row partial sums next to the
+    // raw h, ffn.3 normalises while it stages its A tiles -- h crosses HBM once in each direction instead of twice (268 MB per block
+    // saved, one launch fewer).  RFE_LN_FUSE=0 (tuning build): the stand-alone lg_ln_gelu pass of round 1.
+    static const bool ln_fuse = tune_int("RFE_LN_FUSE", 1) != 0;
+    int P = 0;
     { ProfScope p(c, "lg_ffn1");   // A = [x | second]: second is the message, or the attention context when Wo is folded into W1
       GemmArgs a = gemm_plain(x, 256, w1, 512, b1, b.h, 512, rows, 512, 512);
       a.A2 = second; a.lda2 = 256; a.K1 = 256;
-      launch_gemm_nt(s, a); }
-    { ProfScope p(c, "lg_ln_gelu"); launch_lg_ln_gelu(s, b.h, g, be, rows); }
+      if (ln_fuse) a.stats_out = b.lnstat;
+      P = launch_gemm_nt(s, a); }
+    if (!ln_fuse) { ProfScope p(c, "lg_ln_gelu"); launch_lg_ln_gelu(s, b.h, g, be, rows); }
     { ProfScope p(c, "lg_ffn2");
       GemmArgs a = gemm_plain(b.h, 512, w2, 512, b2, x, 256, rows, 256, 512);
       a.R = x; a.ldr = 256;
+      if (ln_fuse) { a.stats_in = b.lnstat; a.stats_p = P; a.ln_g = g; a.ln_b = be; }
       launch_gemm_nt(s, a); }
 }
 

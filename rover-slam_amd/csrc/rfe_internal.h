@@ -77,6 +77,11 @@ struct GemmArgs {
     long long sA, sA2, sB, sC, sR;    // batch strides (grid.z)
     const int* m_valid;               // optional per-batch valid row count (rows >= m_valid skipped)
     int batch;
+    // LayerNorm(N) + GELU fused across two GEMMs (LightGlue ffn.0 -> LN -> GELU -> ffn.3): the producer's epilogue writes per-row
+    // partial (sum, sum of squares) of what it stores -- one pair per (column tile, wave column): stats_out [M][P][2], P returned by
+    // launch_gemm_nt --, the consumer normalises its A operand while staging it: gelu(((a - mean) * rstd) * ln_g[k] + ln_b[k])
+    float* stats_out;
+    const float* stats_in; int stats_p; const float* ln_g; const float* ln_b;
 };
 
 }  // namespace rfe
@@ -142,7 +147,7 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
 void launch_conv1ab_fused(hipStream_t s, const uint8_t* img, int stride, int B, int H, int W, const float* w1a,
                           const float* b1a, const float* wp, const float* bias, float* out);
 // gemm.hip
-void launch_gemm_nt(hipStream_t s, const GemmArgs& g);
+int launch_gemm_nt(hipStream_t s, const GemmArgs& g);   // returns the number of partial-statistics pairs per row it wrote (0 without stats_out)
 // sp_post.hip
 void launch_softmax65_d2s(hipStream_t s, const float* logits, int ld, int B, int Hc, int Wc, float* score);
 void launch_nms(hipStream_t s, const float* score, int B, int H, int W, int border, float* tmp_ss,
