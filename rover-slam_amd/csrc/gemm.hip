@@ -18,6 +18,17 @@ namespace rfe {
 
 constexpr int BK = 32, LDT = BK + 1;
 
+// GELU(erf) with a short branch-free erf: Abramowitz-Stegun 7.1.26, |erf error| <= 1.5e-7 (libm erff: <= 1 ulp = 6e-8), about a
+// third of the instructions of the library erff (ffn.3 with the fused LayerNorm + GELU: 3.30 -> 3.13 ms per step).  Over the 20-case
+// tolerance study the match-score deviation from the oracle is unchanged (<= 1.9e-4, lists identical): profiles/r02_ab_notes.md.
+__device__ __forceinline__ float gelu_short(float t) {
+    const float x = t * 0.70710678118654752f, ax = fabsf(x);
+    const float k = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    const float poly = fmaf(fmaf(fmaf(fmaf(1.061405429f, k, -1.453152027f), k, 1.421413741f), k, -0.284496736f), k, 0.254829592f) * k;
+    const float er = 1.0f - poly * __builtin_amdgcn_exp2f(-(ax * ax) * 1.44269504088896341f);
+    return 0.5f * t * (1.0f + copysignf(er, x));
+}
+
 // NB = 32-column MFMA blocks per wave: wave tile 64 x (NB*32), workgroup tile 128 x (NB*64).
 // NB = 4 (128x256 tile, 49 KB LDS, 3 workgroups/CU) measured best for N % 256 == 0
 // (tools/kbench/gemm_variants.hip: 119-132 TFLOP/s vs 110-125 for 128x128 double-buffered).
@@ -42,7 +53,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     int M = g.M;
     if (g.m_valid) { M = g.m_valid[z]; if (M > g.M) M = g.M; }
     if (m0 >= M) return;
-    if (g.stagger) stagger_priority(blockIdx.y * gridDim.x + blockIdx.x);
 
     const float* A = g.A + (size_t)z * g.sA;
     const float* A2 = g.A2 ? g.A2 + (size_t)z * g.sA2 : nullptr;
@@ -108,6 +118,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     // loop of the current one (16 VGPRs).  The throughput tiles rely on the other resident workgroups instead
     // (register prefetch measured slower there).
     constexpr bool PF = (MB == 1) || PFT;
+    constexpr bool LNI = LNA && PF && MB == 2;   // LN + GELU of the PREFETCHED tile interleaved with the second half of the MFMA loop
     float4 ra[A_IT], rb[B_IT], rg, rbeta;
     auto load_tile = [&](int k0) {
         if (LNA) { rg = *reinterpret_cast<const float4*>(g.ln_g + k0 + lkq * 4); rbeta = *reinterpret_cast<const float4*>(g.ln_b + k0 + lkq * 4); }
@@ -124,20 +135,29 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) rb[it] = *reinterpret_cast<const float4*>(base + boff[it]);
     };
+    // LN + GELU of one staged element, same operation order as the stand-alone kernel: ((a - mean) * rstd) * g + b, then GELU
+    auto ln_elem = [&](float a, int it, float gq, float bq) { return gelu_short((a - ln_mean[it]) * ln_rstd[it] * gq + bq); };
+    auto ln_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it)
+            ra[it] = make_float4(ln_elem(ra[it].x, it, rg.x, rbeta.x), ln_elem(ra[it].y, it, rg.y, rbeta.y),
+                                 ln_elem(ra[it].z, it, rg.z, rbeta.z), ln_elem(ra[it].w, it, rg.w, rbeta.w));
+    };
     if (PF) load_tile(0);
+    if (LNI) ln_tile();   // first tile: nothing to hide it under
     for (int k0 = 0; k0 < g.K; k0 += BK) {
         if (!PF) load_tile(k0);
         __syncthreads();   // previous tile fully consumed
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             float4 v = ra[it];
-            if (LNA) {   // same operation order as the stand-alone LayerNorm + GELU kernel: ((a - mean) * rstd) * g + b, then 0.5 v (1 + erf(v / sqrt 2))
+            if (LNA && !LNI) {   // same operation order as the stand-alone LayerNorm + GELU kernel: ((a - mean) * rstd) * g + b, then 0.5 v (1 + erf(v / sqrt 2))
                 float e[4] = {v.x, v.y, v.z, v.w};
                 const float gg[4] = {rg.x, rg.y, rg.z, rg.w}, bb[4] = {rbeta.x, rbeta.y, rbeta.z, rbeta.w};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float t = (e[q] - ln_mean[it]) * ln_rstd[it] * gg[q] + bb[q];
-                    e[q] = 0.5f * t * (1.0f + erff(t * 0.70710678118654752f));
+                    e[q] = gelu_short(t);
                 }
                 v = make_float4(e[0], e[1], e[2], e[3]);
             }
@@ -158,6 +178,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
+            if (LNI && s >= BK / 4) {
+                // the tile prefetched before this loop has landed by now (>= 64 MFMAs = 4096 cycles after its loads were issued):
+                // its LayerNorm + GELU -- VALU work, 2 of the 16 elements of this thread per k-step -- runs in the shadow of the
+                // MFMAs of the remaining k-steps instead of on the staging path in front of the barrier
+                constexpr int per = (A_IT * 4) / (BK / 4);
+#pragma unroll
+                for (int u = 0; u < per; ++u) {
+                    const int e = (s - BK / 4) * per + u, it = e >> 2, q = e & 3;
+                    float* comp = q == 0 ? &ra[it].x : q == 1 ? &ra[it].y : q == 2 ? &ra[it].z : &ra[it].w;
+                    const float gq = q == 0 ? rg.x : q == 1 ? rg.y : q == 2 ? rg.z : rg.w;
+                    const float bq = q == 0 ? rbeta.x : q == 1 ? rbeta.y : q == 2 ? rbeta.z : rbeta.w;
+                    *comp = ln_elem(*comp, it, gq, bq);
+                }
+            }
         }
     }
 
@@ -249,12 +283,12 @@ int launch_gemm_nt(hipStream_t s, const GemmArgs& g_in) {
     const int batch = g.batch > 0 ? g.batch : 1;
     auto tiles = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * batch; };
     const bool res = g.R != nullptr, lna = g.stats_in != nullptr;
-    static const int stagger = tune_int("RFE_GEMM_STAGGER", 0);   // tuning switch: static per-workgroup wave priorities
-    g.stagger = stagger;
+    static const bool lni = tune_int("RFE_LN_INTERLEAVE", 1) != 0;   // tuning switch
     static const bool pft = tune_int("RFE_GEMM_PF", 1) != 0;   // register prefetch of the next K tile also on the 128-row tiles (+1 % on ffn1 / ffn2, profiles/r02_pmc.md); RFE_GEMM_PF=0 (tuning build) disables
 #define RFE_GEMM_GO(MB_, NB_, GRID)                                                                  \
     do {                                                                                             \
-        if (lna) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, true, false, true>), GRID, dim3(256), 0, s, g);   /* LN + GELU on A: residual variant, no prefetch (registers) */ \
+        if (lna && lni && MB_ == 2) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, true, MB_ == 2, true>), GRID, dim3(256), 0, s, g);   /* LN + GELU on A under the MFMAs */ \
+        else if (lna) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, true, false, true>), GRID, dim3(256), 0, s, g);   /* LN + GELU on A at staging */ \
         else if (pft && MB_ == 2 && res) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, true, MB_ == 2>), GRID, dim3(256), 0, s, g);    \
         else if (pft && MB_ == 2) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, false, MB_ == 2>), GRID, dim3(256), 0, s, g);     \
         else if (res) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, true>), GRID, dim3(256), 0, s, g);    \

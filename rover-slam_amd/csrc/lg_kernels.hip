@@ -59,7 +59,6 @@ __global__ __launch_bounds__(256, 4) void lg_attention_kernel(   // 4 workgroups
     // (sequence, head) run on the same XCD so its K/V (512 KB) is fetched into one L2 only.
     const int Lb = blockIdx.x, xcd = Lb & 7, t_ = Lb >> 3;
     const int qb = t_ % nqb, unit = (t_ / nqb) * 8 + xcd;
-    if (prio == 2) stagger_priority(Lb);
     if (unit >= 4 * nseq_total) return;   // the grid is padded to a multiple of 8 (sequence, head) units so that the decode stays bijective
     const int seq = unit >> 2, head = unit & 3;
     const int kvseq = kv_map ? kv_map[seq] : seq;
@@ -162,10 +161,10 @@ __global__ __launch_bounds__(256, 4) void lg_attention_kernel(   // 4 workgroups
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[r] = 0.f;
             const float* ka = Ks[buf] + (sub * 32 + j) * AT_LDK + h;
-            if (prio == 1) __builtin_amdgcn_s_setprio(1);
+            if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int s = 0; s < 32; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[2 * s], qreg[s], st, 0, 0, 0);
-            if (prio == 1) __builtin_amdgcn_s_setprio(0);
+            if (prio) __builtin_amdgcn_s_setprio(0);
             // ---- online softmax over this lane's 16 keys (+ the other half-wave's 16)
             if (!(ABL & 1)) {
             // only the last key tile can contain keys >= nk
@@ -199,14 +198,14 @@ __global__ __launch_bounds__(256, 4) void lg_attention_kernel(   // 4 workgroups
             } else { l_run = 1.f; }
             // ---- O^T[d][query] += sum_key V[key][d] * P[key][query]; k-step r uses key(r,h)
             const float* va = Vs[buf] + (sub * 32 + 4 * h) * 64 + j;
-            if (prio == 1) __builtin_amdgcn_s_setprio(1);
+            if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kr = (r & 3) + 8 * (r >> 2);
                 o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[kr * 64], st[r], o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[kr * 64 + 32], st[r], o1, 0, 0, 0);
             }
-            if (prio == 1) __builtin_amdgcn_s_setprio(0);
+            if (prio) __builtin_amdgcn_s_setprio(0);
         }
         if (DBUF) {
             if (more) stash(buf ^ 1);
@@ -310,7 +309,7 @@ void launch_lg_attention(hipStream_t s, const float* q, const float* k, const fl
     if (abl == 2) { hipLaunchKernelGGL((lg_attention_kernel<2>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0, nullptr, nseq, rope_csn); return; }
     if (abl == 3) { hipLaunchKernelGGL((lg_attention_kernel<3>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0, nullptr, nseq, rope_csn); return; }
 #endif
-    static const int prio = tune_int("RFE_ATT_PRIO", 1);   // 1: s_setprio(1) around the MFMA clusters (+0.8 %); 2: static per-workgroup priorities (stagger_priority); 0: none
+    static const int prio = tune_int("RFE_ATT_PRIO", 1);   // s_setprio(1) around the MFMA clusters (+0.8 %); RFE_ATT_PRIO=0 disables
     if (rope)
         hipLaunchKernelGGL((lg_attention_kernel<0, false, true>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nullptr, nseq, rope_csn);
     else

@@ -23,24 +23,6 @@ inline const char* tune_env(const char*) { return nullptr; }
 #endif
 inline int tune_int(const char* name, int dflt) { const char* e = tune_env(name); return e ? atoi(e) : dflt; }
 
-// Static wave priority that differs between the workgroups sharing a CU.  Co-resident workgroups of one launch run the same
-// code from the same start time and the round-robin issue arbitration keeps them in step: they reach their staging phase (global
-// loads, LDS writes, barrier) together and the matrix pipe idles while all of them wait.  With distinct priorities the pipe goes
-// to the highest-priority ready wave, the others fall behind by a phase and fill its staging gaps (MI355X guide, "two waves per
-// SIMD", item 4).  `slot` should differ between the workgroups a CU holds at the same time: blocks are dealt round-robin to the
-// 8 XCDs and then across the CUs of an XCD, so after dropping the XCD bits neighbours in either dispatch order get distinct values.
-#if defined(__HIPCC__)
-__device__ __forceinline__ void stagger_priority(unsigned linear_block) {
-    const unsigned t = linear_block >> 3;
-    switch (((t >> 5) + t) & 3u) {
-        case 0: __builtin_amdgcn_s_setprio(0); break;
-        case 1: __builtin_amdgcn_s_setprio(1); break;
-        case 2: __builtin_amdgcn_s_setprio(2); break;
-        default: __builtin_amdgcn_s_setprio(3); break;
-    }
-}
-#endif
-
 // ---------------------------------------------------------------- SuperPoint layer table
 // names follow the reference's dead libtorch header include/SuperPoint.h:24-41
 struct SpLayer { int cin, cout, k; };
@@ -100,7 +82,6 @@ struct GemmArgs {
     // launch_gemm_nt --, the consumer normalises its A operand while staging it: gelu(((a - mean) * rstd) * ln_g[k] + ln_b[k])
     float* stats_out;
     const float* stats_in; int stats_p; const float* ln_g; const float* ln_b;
-    int stagger;                      // static per-workgroup wave priorities (stagger_priority)
 };
 
 }  // namespace rfe

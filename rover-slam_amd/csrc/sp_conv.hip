@@ -31,8 +31,6 @@ int conv_ck() {
     return ck;
 }
 
-static int conv_stagger() { static const int v = tune_int("RFE_CONV_STAGGER", 0); return v; }   // tuning switch: static per-workgroup wave priorities
-
 size_t packed_conv3x3_count(int cin, int cout) { return (size_t)cout * cin * 9; }
 
 // [Cout/64][Cin/CK][CK*9][64] : element (ct, ch, kl, j) = w[ct*64+j][ch*CK + kl/9][(kl%9)/3][kl%3]
@@ -134,12 +132,11 @@ __device__ __forceinline__ void conv_store(const f32x16 (&acc)[2][2], float* __r
 template <int CIN, bool POOL, bool RELU, int TAG, int CK>
 __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
-    float* __restrict__ out, int H, int W, int COUT, int stagger) {
+    float* __restrict__ out, int H, int W, int COUT) {
     constexpr int KCH = CK * 9;
     __shared__ __attribute__((aligned(16))) float lds[CK * PLANE + KCH * NT];
     float* lds_in = lds;
     float* lds_w = lds + CK * PLANE;
-    if (stagger) stagger_priority((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -370,9 +367,8 @@ __global__ __launch_bounds__(256, 4) void conv3x3_small_kernel(
 template <int CK>
 __global__ __launch_bounds__(256, 2) void conv1ab_fused_kernel(
     const uint8_t* __restrict__ img, int stride, const float* __restrict__ w1a /*[9][64]*/, const float* __restrict__ b1a,
-    const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ out, int H, int W, int stagger) {
+    const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ out, int H, int W) {
     constexpr int CIN = 64, COUT = 64, KCH = CK * 9;
-    if (stagger) stagger_priority((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
     constexpr int MH = TH + 4, MW = TW + 4;   // image tile with a 2-pixel halo
     __shared__ __attribute__((aligned(16))) float lds[CK * PLANE + KCH * NT + MH * MW];
     float* lds_in = lds;
@@ -447,15 +443,15 @@ void launch_conv1ab_fused(hipStream_t s, const uint8_t* img, int stride, int B, 
                           const float* b1a, const float* wp, const float* bias, float* out) {
     dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B);
     if (conv_ck() == 8)
-        hipLaunchKernelGGL((conv1ab_fused_kernel<8>), grid, dim3(256), 0, s, img, stride, w1a, b1a, wp, bias, out, H, W, conv_stagger());
+        hipLaunchKernelGGL((conv1ab_fused_kernel<8>), grid, dim3(256), 0, s, img, stride, w1a, b1a, wp, bias, out, H, W);
     else
-        hipLaunchKernelGGL((conv1ab_fused_kernel<16>), grid, dim3(256), 0, s, img, stride, w1a, b1a, wp, bias, out, H, W, conv_stagger());
+        hipLaunchKernelGGL((conv1ab_fused_kernel<16>), grid, dim3(256), 0, s, img, stride, w1a, b1a, wp, bias, out, H, W);
 }
 
 #define RFE_CONV_LAUNCH(CIN, POOL, RELU, TAG)                                                                            \
     do {                                                                                                                \
-        if (ck8) hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, POOL, RELU, TAG, 8>), grid, dim3(256), 0, s, in, wp, bias, out, H, W, cout, conv_stagger()); \
-        else hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, POOL, RELU, TAG, 16>), grid, dim3(256), 0, s, in, wp, bias, out, H, W, cout, conv_stagger());   \
+        if (ck8) hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, POOL, RELU, TAG, 8>), grid, dim3(256), 0, s, in, wp, bias, out, H, W, cout); \
+        else hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, POOL, RELU, TAG, 16>), grid, dim3(256), 0, s, in, wp, bias, out, H, W, cout);   \
     } while (0)
 
 // tag: SuperPoint layer id (L_1B .. L_DA) for the production path, 0 for the generic test hook
