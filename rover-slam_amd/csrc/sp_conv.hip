@@ -128,11 +128,26 @@ __device__ __forceinline__ void conv_store(const f32x16 (&acc)[2][2], float* __r
     }
 }
 
+// XCD-aware block decode (1-D grid): blocks are dealt round-robin to the 8 XCDs, each with its own L2.  The nct output-channel
+// tiles of one pixel tile read the same input tile: they are made consecutive on ONE XCD (linear = ((u / 8) * nct + ct) * 8 + u % 8
+// for pixel tile u), so the haloed input tile is fetched into one L2 instead of nct of them (conv3b: 2, the 256-channel heads: 4).
+struct ConvBlock { int b, bx, by, ct; bool valid; };
+__device__ __forceinline__ ConvBlock conv_decode(int nct, int gx, int gy, int ntiles) {
+    const int L = blockIdx.x, xcd = L & 7, t = L >> 3;
+    ConvBlock k;
+    k.ct = t % nct;
+    const int u = (t / nct) * 8 + xcd;
+    k.valid = u < ntiles;
+    k.bx = u % gx; k.by = (u / gx) % gy; k.b = u / (gx * gy);
+    return k;
+}
+static inline unsigned conv_grid(int gx, int gy, int B, int nct) { return (unsigned)(((gx * gy * B + 7) / 8) * 8 * nct); }
+
 // TAG only gives each SuperPoint layer its own kernel symbol (per-layer rows in rocprofv3 --stats)
 template <int CIN, bool POOL, bool RELU, int TAG, int CK>
 __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
-    float* __restrict__ out, int H, int W, int COUT) {
+    float* __restrict__ out, int H, int W, int COUT, int gx, int gy, int ntiles) {
     constexpr int KCH = CK * 9;
     __shared__ __attribute__((aligned(16))) float lds[CK * PLANE + KCH * NT];
     float* lds_in = lds;
@@ -142,9 +157,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, h = lane >> 5;
-    const int nct = COUT / NT;
-    const int b = blockIdx.z / nct, ct = blockIdx.z % nct;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const ConvBlock blk = conv_decode(COUT / NT, gx, gy, ntiles);
+    if (!blk.valid) return;
+    const int b = blk.b, ct = blk.ct;
+    const int x0 = blk.bx * TW, y0 = blk.by * TH;
     const int co0 = ct * NT;
 
     f32x16 acc[2][2];
@@ -204,10 +220,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
 // WSTRIDE: LDS row stride of the staged planes in words, 0 = TCOLS + 2.  An A-fragment read touches 16 consecutive words of
 // row R (lanes 0-15) and of row R + 1 (lanes 16-31): the two runs fall on disjoint banks only when the stride is 16 mod 32
 // (48 for the 16-wide tile, 112 for the 80-wide one); stride 18 / 82 makes lanes 30-31 collide with lanes 0-1 on every read.
+// Measured (profiles/r02_ab_notes.md): the conflict-free strides cost a workgroup per CU of occupancy (39.9 KB LDS) and lose
+// more than the conflicts do (heads 0.87 -> 0.92 ms), so the product uses the unpadded stride.
 template <int CIN, bool RELU, int TAG, int CK, int NW, int TROWS, int TCOLS, int WSTRIDE = 0>
 __global__ __launch_bounds__(NW * 64, NW == 3 ? 4 : 2) void conv3x3_blk16_kernel(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
-    float* __restrict__ out, int H, int W, int COUT) {
+    float* __restrict__ out, int H, int W, int COUT, int gx, int gy, int ntiles) {
     constexpr int KCH = CK * 9, NTHR = NW * 64;
     constexpr int WIH_ = TROWS + 2, WIW_ = TCOLS + 2, WTWS_ = WSTRIDE ? WSTRIDE : WIW_, WPLANE_ = WIH_ * WTWS_, WCOLS = TCOLS / 16;
     static_assert(WTWS_ >= WIW_, "row stride must hold the haloed row");
@@ -218,9 +236,10 @@ __global__ __launch_bounds__(NW * 64, NW == 3 ? 4 : 2) void conv3x3_blk16_kernel
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, h = lane >> 5;
-    const int nct = COUT / NT;
-    const int b = blockIdx.z / nct, ct = blockIdx.z % nct;
-    const int x0 = blockIdx.x * TCOLS, y0 = blockIdx.y * TROWS;
+    const ConvBlock blk = conv_decode(COUT / NT, gx, gy, ntiles);
+    if (!blk.valid) return;
+    const int b = blk.b, ct = blk.ct;
+    const int x0 = blk.bx * TCOLS, y0 = blk.by * TROWS;
     const int co0 = ct * NT;
     const int wr0 = (wave / WCOLS) * 4, wc0 = (wave % WCOLS) * 16;   // this wave's 4 x 16 pixel patch inside the tile
 
@@ -285,7 +304,7 @@ constexpr int STH = 4, SIH = STH + 2, SPLANE = SIH * TWS, SNT = 32;
 template <int CIN, bool RELU, int CK>
 __global__ __launch_bounds__(256, 4) void conv3x3_small_kernel(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
-    float* __restrict__ out, int H, int W, int COUT) {
+    float* __restrict__ out, int H, int W, int COUT, int gx, int gy, int ntiles) {
     constexpr int KCH = CK * 9;
     __shared__ __attribute__((aligned(16))) float lds[CK * SPLANE + KCH * SNT];
     float* lds_in = lds;
@@ -293,9 +312,10 @@ __global__ __launch_bounds__(256, 4) void conv3x3_small_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, h = lane >> 5;
-    const int nct = COUT / SNT;
-    const int b = blockIdx.z / nct, ct = blockIdx.z % nct;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * STH;
+    const ConvBlock blk = conv_decode(COUT / SNT, gx, gy, ntiles);
+    if (!blk.valid) return;
+    const int b = blk.b, ct = blk.ct;
+    const int x0 = blk.bx * TW, y0 = blk.by * STH;
     const int co0 = ct * SNT;
 
     f32x16 acc;
@@ -450,23 +470,24 @@ void launch_conv1ab_fused(hipStream_t s, const uint8_t* img, int stride, int B, 
 
 #define RFE_CONV_LAUNCH(CIN, POOL, RELU, TAG)                                                                            \
     do {                                                                                                                \
-        if (ck8) hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, POOL, RELU, TAG, 8>), grid, dim3(256), 0, s, in, wp, bias, out, H, W, cout); \
-        else hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, POOL, RELU, TAG, 16>), grid, dim3(256), 0, s, in, wp, bias, out, H, W, cout);   \
+        if (ck8) hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, POOL, RELU, TAG, 8>), dim3(conv_grid(gx, gy, B, cout / NT)), dim3(256), 0, s, in, wp, bias, out, H, W, cout, gx, gy, gx * gy * B); \
+        else hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, POOL, RELU, TAG, 16>), dim3(conv_grid(gx, gy, B, cout / NT)), dim3(256), 0, s, in, wp, bias, out, H, W, cout, gx, gy, gx * gy * B);   \
     } while (0)
 
 // tag: SuperPoint layer id (L_1B .. L_DA) for the production path, 0 for the generic test hook
 void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin, const float* wp,
                     const float* bias, int cout, bool relu, bool pool, float* out, int tag) {
-    dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B * (cout / NT));
+    const int gx = (W + TW - 1) / TW, gy = (H + TH - 1) / TH;
     const bool ck8 = conv_ck() == 8;
     // latency regime: too few 8 x 32 x 64 tiles to occupy the chip -> 4 x 32 x 32 tiles (4x the workgroups)
     static const int small_thr = tune_int("RFE_CONV_SMALL", 512);   // 0 disables
-    if (ck8 && !pool && (long long)grid.x * grid.y * grid.z < small_thr && (cin == 64 || cin == 128)) {
-        dim3 gs((W + TW - 1) / TW, (H + STH - 1) / STH, B * (cout / SNT));
-        if (cin == 128 && relu) hipLaunchKernelGGL((conv3x3_small_kernel<128, true, 8>), gs, dim3(256), 0, s, in, wp, bias, out, H, W, cout);
-        else if (cin == 128) hipLaunchKernelGGL((conv3x3_small_kernel<128, false, 8>), gs, dim3(256), 0, s, in, wp, bias, out, H, W, cout);
-        else if (relu) hipLaunchKernelGGL((conv3x3_small_kernel<64, true, 8>), gs, dim3(256), 0, s, in, wp, bias, out, H, W, cout);
-        else hipLaunchKernelGGL((conv3x3_small_kernel<64, false, 8>), gs, dim3(256), 0, s, in, wp, bias, out, H, W, cout);
+    if (ck8 && !pool && (long long)gx * gy * B * (cout / NT) < small_thr && (cin == 64 || cin == 128)) {
+        const int sx = (W + TW - 1) / TW, sy = (H + STH - 1) / STH;
+        const dim3 gs(conv_grid(sx, sy, B, cout / SNT));
+        if (cin == 128 && relu) hipLaunchKernelGGL((conv3x3_small_kernel<128, true, 8>), gs, dim3(256), 0, s, in, wp, bias, out, H, W, cout, sx, sy, sx * sy * B);
+        else if (cin == 128) hipLaunchKernelGGL((conv3x3_small_kernel<128, false, 8>), gs, dim3(256), 0, s, in, wp, bias, out, H, W, cout, sx, sy, sx * sy * B);
+        else if (relu) hipLaunchKernelGGL((conv3x3_small_kernel<64, true, 8>), gs, dim3(256), 0, s, in, wp, bias, out, H, W, cout, sx, sy, sx * sy * B);
+        else hipLaunchKernelGGL((conv3x3_small_kernel<64, false, 8>), gs, dim3(256), 0, s, in, wp, bias, out, H, W, cout, sx, sy, sx * sy * B);
         return;
     }
     static const bool no_wide = tune_env("RFE_CONV_NO_WIDE") != nullptr;   // tuning / test switch
@@ -477,30 +498,20 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
     if (!no_wide && ck8 && !pool && relu && cin == 128 && (tag == L_4A || tag == L_4B || tag == L_PA || tag == L_DA)) {
         const bool heads = tag == L_PA || tag == L_DA;
         if ((tall == 1 || (tall == -1 && heads)) && W % 16 == 0 && H % 12 == 0) {
-            dim3 gt(W / 16, H / 12, B * (cout / NT));
-            static const int pad = tune_int("RFE_CONV_PAD", 0);   // tuning switch: conflict-free LDS row stride
-            if (pad) {
-                switch (tag) {
-                    case L_4A: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4A, 8, 3, 12, 16, 48>), gt, dim3(192), 0, s, in, wp, bias, out, H, W, cout); return;
-                    case L_4B: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4B, 8, 3, 12, 16, 48>), gt, dim3(192), 0, s, in, wp, bias, out, H, W, cout); return;
-                    case L_PA: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_PA, 8, 3, 12, 16, 48>), gt, dim3(192), 0, s, in, wp, bias, out, H, W, cout); return;
-                    default: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_DA, 8, 3, 12, 16, 48>), gt, dim3(192), 0, s, in, wp, bias, out, H, W, cout); return;
-                }
-            }
+            const int tx = W / 16, ty = H / 12;
+            const dim3 gt(conv_grid(tx, ty, B, cout / NT));
             switch (tag) {
-                case L_4A: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4A, 8, 3, 12, 16>), gt, dim3(192), 0, s, in, wp, bias, out, H, W, cout); return;
-                case L_4B: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4B, 8, 3, 12, 16>), gt, dim3(192), 0, s, in, wp, bias, out, H, W, cout); return;
-                case L_PA: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_PA, 8, 3, 12, 16>), gt, dim3(192), 0, s, in, wp, bias, out, H, W, cout); return;
-                default: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_DA, 8, 3, 12, 16>), gt, dim3(192), 0, s, in, wp, bias, out, H, W, cout); return;
+                case L_4A: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4A, 8, 3, 12, 16>), gt, dim3(192), 0, s, in, wp, bias, out, H, W, cout, tx, ty, tx * ty * B); return;
+                case L_4B: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4B, 8, 3, 12, 16>), gt, dim3(192), 0, s, in, wp, bias, out, H, W, cout, tx, ty, tx * ty * B); return;
+                case L_PA: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_PA, 8, 3, 12, 16>), gt, dim3(192), 0, s, in, wp, bias, out, H, W, cout, tx, ty, tx * ty * B); return;
+                default: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_DA, 8, 3, 12, 16>), gt, dim3(192), 0, s, in, wp, bias, out, H, W, cout, tx, ty, tx * ty * B); return;
             }
         }
         if ((tall == 2 || tall == -1) && W % 80 == 0 && !heads) {
-            dim3 gw(W / 80, (H + 3) / 4, B * (cout / NT));
-            static const int padw = tune_int("RFE_CONV_PAD", 0);
-            if (padw && tag == L_4A) hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4A, 8, 5, 4, 80, 112>), gw, dim3(320), 0, s, in, wp, bias, out, H, W, cout);
-            else if (padw) hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4B, 8, 5, 4, 80, 112>), gw, dim3(320), 0, s, in, wp, bias, out, H, W, cout);
-            else if (tag == L_4A) hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4A, 8, 5, 4, 80>), gw, dim3(320), 0, s, in, wp, bias, out, H, W, cout);
-            else hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4B, 8, 5, 4, 80>), gw, dim3(320), 0, s, in, wp, bias, out, H, W, cout);
+            const int wx = W / 80, wy = (H + 3) / 4;
+            const dim3 gw(conv_grid(wx, wy, B, cout / NT));
+            if (tag == L_4A) hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4A, 8, 5, 4, 80>), gw, dim3(320), 0, s, in, wp, bias, out, H, W, cout, wx, wy, wx * wy * B);
+            else hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4B, 8, 5, 4, 80>), gw, dim3(320), 0, s, in, wp, bias, out, H, W, cout, wx, wy, wx * wy * B);
             return;
         }
     }
