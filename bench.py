@@ -83,21 +83,23 @@ def stage_flops(name, B, lens, launches=None):
     return None
 
 
-STAGE_KERNEL = {"lg_attention": "lg_attention_kernel", "conv1ab": "conv1ab_fused_kernel"}
+STAGE_KERNEL = {"lg_attention": ("lg_attention_kernel (self + cross", "lg_attention_kernel"), "conv1ab": ("conv1ab_fused_kernel",)}
 
 
 def pmc_traffic(stage):
     """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes of this same
     bench command (profiles/rNN_pmc_traffic.json, made by tools/profile_round.sh + tools/rocpd_pmc.py):
     (2*FETCH_SIZE + WRITE_SIZE)*1024 as the MI355X guide prescribes.  None when no PMC pass covers it."""
-    key = STAGE_KERNEL.get(stage)
+    keys = STAGE_KERNEL.get(stage)
     for rnd in ("r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
-        if not key or not os.path.exists(path):
+        if not keys or not os.path.exists(path):
             continue
-        for name, v in json.load(open(path))["kernels"].items():
-            if key in name:
-                return v["traffic_bytes"], f"profiles/{rnd}_pmc_traffic.json:" + name
+        kernels = json.load(open(path))["kernels"]
+        for key in keys:        # round 2 profiles hold one call-weighted entry for the attention's self (rotary) and cross variants
+            for name, v in kernels.items():
+                if key in name:
+                    return v["traffic_bytes"], f"profiles/{rnd}_pmc_traffic.json:" + name
     return None, None
 
 
