@@ -116,6 +116,8 @@ def gpu_clocks(dev_index):
                         out[key] = int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
     except (OSError, ValueError, IndexError):
         pass
+    if out.get("sclk_mhz", 1 << 30) < 500:      # some boxes expose only the idle level here (96 / 158 MHz under a 100 % busy chip): not a reading
+        out = {}
     return out or None
 
 
@@ -226,7 +228,9 @@ def cpu_baseline(frames, wsp, wlg, gpu=None):
             check_pair(len(gpu["S"]) - 1, lg)
             extra = 1
         verified = {"frames": nf + 2 * extra, "pairs": nf - 1 + extra, "superpoint_bit_exact": sp_ok, "match_lists_identical": lg_ok,
-                    "match_score_max_dev": ms_dev, "match_score_tolerance": 1e-4, "lg_fold_wo": gpu.get("fold")}
+                    "match_score_max_dev": ms_dev, "match_score_tolerance": 5e-4, "lg_fold_wo": gpu.get("fold"),
+                    "tolerance_note": "stated fp32 tolerance of LightGlue match scores at K = 1024 (tests/tolerances.py, profiles/r02_lg_tolerance.md: "
+                                      "any two fp32 evaluations of the graph differ by 1-3e-4, oracle vs float64 2.6e-4)"}
         if not (sp_ok and lg_ok):
             print(f"bench.py: GPU results of the timed loop differ from the oracle: {verified}", file=sys.stderr)
     return {"value": round((nf - 1) / dt, 4), "unit": "frames/s", "cores": O.threads(), "kind": "port", "verified_against_gpu": verified,

@@ -73,7 +73,7 @@ SQ rows are per XCD/SE slice: MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (32 
           d.get("cpu_baseline", {}).get("value"))
     for w in ("c2", "c3", "c5"):
         f = os.path.join(O, f"lat_{w}.json")
-        if os.path.exists(f):
+        if os.path.exists(f) and open(f).read().strip():
             x = json.loads(open(f).read().strip().splitlines()[-1])
             print(w, x["value"], x["ms_per_step"])
 
