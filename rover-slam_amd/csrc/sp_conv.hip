@@ -190,6 +190,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
         s_goff[it] = (slot && gy >= 0 && gy < H && gx >= 0 && gx < W) ? (gy * W + gx) * CIN + cq * 4 : -1;
     }
 
+    // The input of TWO consecutive chunks (2 x 32 B of every pixel = half a 128-B line of an NHWC row with 64 channels) is
+    // fetched together on the even pass and the second half waits in registers for the odd pass: every line of the tile is
+    // requested from L2 in half as many passes (the resident tiles of an XCD, 128 x 44 KB per pass, do not fit its 4 MB L2, so
+    // each pass over a line used to be a fresh fetch), and the odd passes have no global input load on their staging path.
+    constexpr bool PAIR = (CIN / CK) % 2 == 0;   // (a single 16-channel chunk in the generic test instantiation: no pairing)
+    float4 v_odd[S_IT];
     for (int ch = 0; ch < CIN / CK; ++ch) {
         __syncthreads();
         // ---- stage input tile: NHWC global -> channel-planar LDS (zero padding materialised)
@@ -197,7 +203,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
         for (int it = 0; it < S_IT; ++it) {
             if (s_loff[it] < 0) continue;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (s_goff[it] >= 0) v = *reinterpret_cast<const float4*>(in_b + s_goff[it] + ch * CK);
+            if (!PAIR) {
+                if (s_goff[it] >= 0) v = *reinterpret_cast<const float4*>(in_b + s_goff[it] + ch * CK);
+            } else if ((ch & 1) == 0) {
+                v_odd[it] = v;
+                if (s_goff[it] >= 0) {
+                    v = *reinterpret_cast<const float4*>(in_b + s_goff[it] + ch * CK);
+                    v_odd[it] = *reinterpret_cast<const float4*>(in_b + s_goff[it] + (ch + 1) * CK);
+                }
+            } else {
+                v = v_odd[it];
+            }
             float* d = lds_in + s_loff[it];
             d[0] = v.x; d[PLANE] = v.y; d[2 * PLANE] = v.z; d[3 * PLANE] = v.w;
         }
