@@ -53,7 +53,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     int M = g.M;
     if (g.m_valid) { M = g.m_valid[z]; if (M > g.M) M = g.M; }
     if (m0 >= M) return;
-    if (g.stagger) stagger_start(blockIdx.y * gridDim.x + blockIdx.x, g.stagger, 2);
 
     const float* A = g.A + (size_t)z * g.sA;
     const float* A2 = g.A2 ? g.A2 + (size_t)z * g.sA2 : nullptr;
@@ -285,8 +284,7 @@ int launch_gemm_nt(hipStream_t s, const GemmArgs& g_in) {
     auto tiles = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * batch; };
     const bool res = g.R != nullptr, lna = g.stats_in != nullptr;
     static const bool lni = tune_int("RFE_LN_INTERLEAVE", 1) != 0;   // tuning switch
-    static const int stagger = tune_int("RFE_GEMM_SLEEP", 0);         // tuning experiment
-    g.stagger = stagger;
+
     static const bool pft = tune_int("RFE_GEMM_PF", 1) != 0;   // register prefetch of the next K tile also on the 128-row tiles (+1 % on ffn1 / ffn2, profiles/r02_pmc.md); RFE_GEMM_PF=0 (tuning build) disables
 #define RFE_GEMM_GO(MB_, NB_, GRID)                                                                  \
     do {                                                                                             \

@@ -59,7 +59,6 @@ __global__ __launch_bounds__(256, 4) void lg_attention_kernel(   // 4 workgroups
     // (sequence, head) run on the same XCD so its K/V (512 KB) is fetched into one L2 only.
     const int Lb = blockIdx.x, xcd = Lb & 7, t_ = Lb >> 3;
     const int qb = t_ % nqb, unit = (t_ / nqb) * 8 + xcd;
-    if (prio > 1) stagger_start(Lb, prio - 1, 4);
     if (unit >= 4 * nseq_total) return;   // the grid is padded to a multiple of 8 (sequence, head) units so that the decode stays bijective
     const int seq = unit >> 2, head = unit & 3;
     const int kvseq = kv_map ? kv_map[seq] : seq;

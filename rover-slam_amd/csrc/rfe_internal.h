@@ -23,17 +23,6 @@ inline const char* tune_env(const char*) { return nullptr; }
 #endif
 inline int tune_int(const char* name, int dflt) { const char* e = tune_env(name); return e ? atoi(e) : dflt; }
 
-// One-time start offset between the workgroups that share a CU (tuning experiment): co-resident workgroups of a launch start
-// together and, sharing the matrix pipe fairly, stay in step -- they reach their staging phases together.  A short sleep at
-// start, different per slot, puts them out of phase once; nothing restores the symmetry afterwards.
-#if defined(__HIPCC__)
-__device__ __forceinline__ void stagger_start(unsigned linear_block, int units /*of 512 cycles*/, unsigned slots) {
-    const unsigned t = linear_block >> 3;
-    const unsigned slot = ((t >> 5) + t) % slots;
-    for (unsigned i = 0; i < slot * (unsigned)units; ++i) __builtin_amdgcn_s_sleep(8);
-}
-#endif
-
 // ---------------------------------------------------------------- SuperPoint layer table
 // names follow the reference's dead libtorch header include/SuperPoint.h:24-41
 struct SpLayer { int cin, cout, k; };
@@ -93,7 +82,6 @@ struct GemmArgs {
     // launch_gemm_nt --, the consumer normalises its A operand while staging it: gelu(((a - mean) * rstd) * ln_g[k] + ln_b[k])
     float* stats_out;
     const float* stats_in; int stats_p; const float* ln_g; const float* ln_b;
-    int stagger;                      // tuning experiment: one-time start offset (units of 512 cycles per slot)
 };
 
 }  // namespace rfe

@@ -508,22 +508,13 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
     }
     static const bool no_wide = tune_env("RFE_CONV_NO_WIDE") != nullptr;   // tuning / test switch
     // 60 x 80 grid, measured (TFLOP/s, batch 33): 8x32 tile 94 (conv4) / 103 (heads); wide 4x80 tile 97 / 94 (the 256-channel
-    // heads re-stage the larger input tile four times); 12x16 tile of 3-wave workgroups 83 / 108.
+    // heads re-stage the larger input tile four times); 12x16 tile of 3-wave workgroups 83 / 108; 20x16 tile of 5-wave
+    // workgroups (round 2): conv4 unchanged, heads 0.85 -> 1.05 ms.
     // -> conv4a/4b take the wide tile, convPa/Da the 12x16 tile.  RFE_CONV_TALL: 0 = 8x32 everywhere, 1 = 12x16 everywhere, 2 = wide for conv4 only
     static const int tall = tune_int("RFE_CONV_TALL", -1);
     if (!no_wide && ck8 && !pool && relu && cin == 128 && (tag == L_4A || tag == L_4B || tag == L_PA || tag == L_DA)) {
         const bool heads = tag == L_PA || tag == L_DA;
-        if ((tall == 3 || (tall == 4 && heads)) && W % 16 == 0 && H % 20 == 0) {   // 20 x 16 tile, 5 waves: the weight chunk is staged for 320 pixels instead of 192
-            const int tx = W / 16, ty = H / 20;
-            const dim3 gt(conv_grid(tx, ty, B, cout / NT));
-            switch (tag) {
-                case L_4A: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4A, 8, 5, 20, 16>), gt, dim3(320), 0, s, in, wp, bias, out, H, W, cout, tx, ty, tx * ty * B); return;
-                case L_4B: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4B, 8, 5, 20, 16>), gt, dim3(320), 0, s, in, wp, bias, out, H, W, cout, tx, ty, tx * ty * B); return;
-                case L_PA: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_PA, 8, 5, 20, 16>), gt, dim3(320), 0, s, in, wp, bias, out, H, W, cout, tx, ty, tx * ty * B); return;
-                default: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_DA, 8, 5, 20, 16>), gt, dim3(320), 0, s, in, wp, bias, out, H, W, cout, tx, ty, tx * ty * B); return;
-            }
-        }
-        if ((tall == 1 || ((tall == -1 || tall == 4) && heads)) && W % 16 == 0 && H % 12 == 0) {
+        if ((tall == 1 || (tall == -1 && heads)) && W % 16 == 0 && H % 12 == 0) {
             const int tx = W / 16, ty = H / 12;
             const dim3 gt(conv_grid(tx, ty, B, cout / NT));
             switch (tag) {
@@ -533,7 +524,7 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
                 default: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_DA, 8, 3, 12, 16>), gt, dim3(192), 0, s, in, wp, bias, out, H, W, cout, tx, ty, tx * ty * B); return;
             }
         }
-        if ((tall == 2 || tall == -1 || tall == 4) && W % 80 == 0 && !heads) {
+        if ((tall == 2 || tall == -1) && W % 80 == 0 && !heads) {
             const int wx = W / 80, wy = (H + 3) / 4;
             const dim3 gw(conv_grid(wx, wy, B, cout / NT));
             if (tag == L_4A) hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4A, 8, 5, 4, 80>), gw, dim3(320), 0, s, in, wp, bias, out, H, W, cout, wx, wy, wx * wy * B);
