@@ -29,94 +29,6 @@ __device__ __forceinline__ float gelu_short(float t) {
     return 0.5f * t * (1.0f + copysignf(er, x));
 }
 
-// bias (+alpha, +ReLU, +residual) epilogue straight from the D layout (128-B coalesced accesses) and the optional per-row partial
-// statistics; shared by the single- and the double-buffered kernel
-template <int MB, int NB, bool RES>
-__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MB][NB], const GemmArgs& g, float* C, int M, int m0, int n0, int z, int wm,
-                                              int wn, int i, int h) {
-    {   // bias (+alpha, +ReLU, +residual) epilogue: 128-B coalesced accesses straight from the D layout
-        const float* Rz = (RES && g.R) ? g.R + (size_t)z * g.sR : nullptr;
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                float rv[4][NB];
-                if (Rz) {
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        int m = m0 + (wm * MB + mb) * 32 + rr + 8 * rq + 4 * h;
-                        m = m < M ? m : M - 1;
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) {
-                            int n = n0 + (wn * NB + nb) * 32 + i;
-                            n = n < g.N ? n : g.N - 1;
-                            rv[rr][nb] = Rz[(size_t)m * g.ldr + n];
-                        }
-                    }
-                }
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int r = rq * 4 + rr;
-                    const int m = m0 + (wm * MB + mb) * 32 + rr + 8 * rq + 4 * h;
-                    if (m >= M) continue;
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        const int n = n0 + (wn * NB + nb) * 32 + i;
-                        if (n >= g.N) continue;
-                        float v = acc[mb][nb][r] * g.alpha;
-                        if (g.relu) v = fmaxf(v, 0.f);
-                        if (Rz) v = rv[rr][nb] + v;
-                        C[(size_t)m * g.ldc + n] = v;
-                    }
-                }
-            }
-    }
-    if (g.stats_out) {
-        // Per-row (sum, sum of squares) of this wave's NB*32 stored columns.  A lane holds T = MB*16 rows (one value per row after
-        // the in-lane sum over its NB columns); the 32 lanes of a half-wave hold the same rows for 32 different columns.  Butterfly
-        // that halves the rows kept per lane at every step (T/2, ..., 1 exchanges instead of 5 T): lane i ends with row i's total.
-        constexpr int T = MB * 16;
-        float s1[T], s2[T];
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const int n = n0 + (wn * NB + nb) * 32 + i;
-                    float v = acc[mb][nb][r] * g.alpha;
-                    if (g.relu) v = fmaxf(v, 0.f);
-                    if (n >= g.N) v = 0.f;
-                    a1 += v; a2 = fmaf(v, v, a2);
-                }
-                s1[mb * 16 + r] = a1; s2[mb * 16 + r] = a2;
-            }
-#pragma unroll
-        for (int o = T / 2; o >= 1; o >>= 1) {
-            const bool up = (i & o) != 0;
-#pragma unroll
-            for (int j = 0; j < o; ++j) {
-                const float k1 = up ? s1[j + o] : s1[j], t1 = up ? s1[j] : s1[j + o];
-                const float k2 = up ? s2[j + o] : s2[j], t2 = up ? s2[j] : s2[j + o];
-                s1[j] = k1 + __shfl_xor(t1, o);
-                s2[j] = k2 + __shfl_xor(t2, o);
-            }
-        }
-        if (T < 32) { s1[0] += __shfl_xor(s1[0], 16); s2[0] += __shfl_xor(s2[0], 16); }   // 16 rows on 32 lanes: lane bit 4 still to fold
-        // lane i (< T) of half h now holds local row t = i: mb = t / 16, r = t % 16 -> tile row (r & 3) + 8 (r >> 2) + 4 h
-        if (i < T) {
-            const int r = i & 15;
-            const int m = m0 + (wm * MB + (i >> 4)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (m < M) {
-                const int P = (int)gridDim.x * 2;
-                float* sp = g.stats_out + (((size_t)m + (size_t)z * g.M) * P + blockIdx.x * 2 + wn) * 2;
-                sp[0] = s1[0]; sp[1] = s2[0];
-            }
-        }
-    }
-}
-
 // NB = 32-column MFMA blocks per wave: wave tile 64 x (NB*32), workgroup tile 128 x (NB*64).
 // NB = 4 (128x256 tile, 49 KB LDS, 3 workgroups/CU) measured best for N % 256 == 0
 // (tools/kbench/gemm_variants.hip: 119-132 TFLOP/s vs 110-125 for 128x128 double-buffered).
@@ -283,113 +195,87 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
         }
     }
 
-    gemm_epilogue<MB, NB, RES>(acc, g, C, M, m0, n0, z, wm, wn, i, h);
-}
-
-// Double-buffered variant of the 128 x (NB*64) throughput tile: K tiles of 16, two LDS buffers (2 x 26 KB for NB = 4, still two
-// workgroups per CU), ONE barrier per K tile.  While the MFMAs of tile k run out of buffer k & 1, the same instruction stream writes
-// tile k+1 (prefetched into registers during tile k-1) into the other buffer and issues the global loads of tile k+2: the LDS writes
-// and the loads sit in the shadow of the MFMAs instead of between two barriers.  Same k-ascending accumulation order -> bit-identical
-// results to gemm_nt_kernel.
-template <int NB, bool RES>
-__global__ __launch_bounds__(256, 2) void gemm_nt_db_kernel(GemmArgs g) {
-    constexpr int MB = 2, BM = 128, BN = NB * 64, BKD = 16, LDD = BKD + 1;
-    __shared__ float lds_ab[2][(BM + BN) * LDD];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int i = lane & 31, h = lane >> 5;
-    const int z = blockIdx.z;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    int M = g.M;
-    if (g.m_valid) { M = g.m_valid[z]; if (M > g.M) M = g.M; }
-    if (m0 >= M) return;
-    const float* A = g.A + (size_t)z * g.sA;
-    const float* A2 = g.A2 ? g.A2 + (size_t)z * g.sA2 : nullptr;
-    const float* B = g.B + (size_t)z * g.sB;
-    float* C = g.C + (size_t)z * g.sC;
-
-    f32x16 acc[MB][NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int n = n0 + (wn * NB + nb) * 32 + i;
-        const float bv = (g.bias && n < g.N) ? g.bias[n] : 0.f;
+    {   // bias (+alpha, +ReLU, +residual) epilogue: 128-B coalesced accesses straight from the D layout
+        const float* Rz = (RES && g.R) ? g.R + (size_t)z * g.sR : nullptr;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = bv;
+            for (int rq = 0; rq < 4; ++rq) {
+                float rv[4][NB];
+                if (Rz) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        int m = m0 + (wm * MB + mb) * 32 + rr + 8 * rq + 4 * h;
+                        m = m < M ? m : M - 1;
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            int n = n0 + (wn * NB + nb) * 32 + i;
+                            n = n < g.N ? n : g.N - 1;
+                            rv[rr][nb] = Rz[(size_t)m * g.ldr + n];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int r = rq * 4 + rr;
+                    const int m = m0 + (wm * MB + mb) * 32 + rr + 8 * rq + 4 * h;
+                    if (m >= M) continue;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const int n = n0 + (wn * NB + nb) * 32 + i;
+                        if (n >= g.N) continue;
+                        float v = acc[mb][nb][r] * g.alpha;
+                        if (g.relu) v = fmaxf(v, 0.f);
+                        if (Rz) v = rv[rr][nb] + v;
+                        C[(size_t)m * g.ldc + n] = v;
+                    }
+                }
+            }
     }
-    // staging: thread -> (row = tid/4 + 64*it, 4 consecutive k of the 16); edge rows clamped
-    constexpr int A_IT = BM / 64, B_IT = BN / 64;
-    const int lrow = tid >> 2, lkq = tid & 3;
-    int mlast = M - 1 - m0; mlast = mlast < BM - 1 ? mlast : BM - 1;
-    int nlast = g.N - 1 - n0; nlast = nlast < BN - 1 ? nlast : BN - 1;
-    const float* const At = A + (size_t)m0 * g.lda;
-    const float* const A2t = A2 ? A2 + (size_t)m0 * g.lda2 : nullptr;
-    const float* const Bt = B + (size_t)n0 * g.ldb;
-    int aoff[A_IT], a2off[A_IT], boff[B_IT];
+    if (g.stats_out) {
+        // Per-row (sum, sum of squares) of this wave's NB*32 stored columns.  A lane holds T = MB*16 rows (one value per row after
+        // the in-lane sum over its NB columns); the 32 lanes of a half-wave hold the same rows for 32 different columns.  Butterfly
+        // that halves the rows kept per lane at every step (T/2, ..., 1 exchanges instead of 5 T): lane i ends with row i's total.
+        constexpr int T = MB * 16;
+        float s1[T], s2[T];
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-        int row = lrow + 64 * it; row = row < mlast ? row : mlast;
-        aoff[it] = row * g.lda + lkq * 4;
-        a2off[it] = row * g.lda2 + lkq * 4;
-    }
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-    for (int it = 0; it < B_IT; ++it) {
-        int row = lrow + 64 * it; row = row < nlast ? row : nlast;
-        boff[it] = row * g.ldb + lkq * 4;
-    }
-    float4 ra[A_IT], rb[B_IT];
-    const int klast = g.K - BKD;
-    auto load_tile = [&](int k0) {
-        k0 = k0 < klast ? k0 : klast;            // past the end: reload the last tile (never consumed), no branch in the loop
-        if (A2t && k0 >= g.K1) {
-            const float* base = A2t + (k0 - g.K1);
+            for (int r = 0; r < 16; ++r) {
+                float a1 = 0.f, a2 = 0.f;
 #pragma unroll
-            for (int it = 0; it < A_IT; ++it) ra[it] = *reinterpret_cast<const float4*>(base + a2off[it]);
-        } else {
-            const float* base = At + k0;
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int n = n0 + (wn * NB + nb) * 32 + i;
+                    float v = acc[mb][nb][r] * g.alpha;
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    if (n >= g.N) v = 0.f;
+                    a1 += v; a2 = fmaf(v, v, a2);
+                }
+                s1[mb * 16 + r] = a1; s2[mb * 16 + r] = a2;
+            }
 #pragma unroll
-            for (int it = 0; it < A_IT; ++it) ra[it] = *reinterpret_cast<const float4*>(base + aoff[it]);
+        for (int o = T / 2; o >= 1; o >>= 1) {
+            const bool up = (i & o) != 0;
+#pragma unroll
+            for (int j = 0; j < o; ++j) {
+                const float k1 = up ? s1[j + o] : s1[j], t1 = up ? s1[j] : s1[j + o];
+                const float k2 = up ? s2[j + o] : s2[j], t2 = up ? s2[j] : s2[j + o];
+                s1[j] = k1 + __shfl_xor(t1, o);
+                s2[j] = k2 + __shfl_xor(t2, o);
+            }
         }
-        const float* base = Bt + k0;
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) rb[it] = *reinterpret_cast<const float4*>(base + boff[it]);
-    };
-    auto stash = [&](int buf) {
-        float* const da = lds_ab[buf] + lrow * LDD + lkq * 4;
-        float* const db = lds_ab[buf] + BM * LDD + lrow * LDD + lkq * 4;
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) { float* d = da + it * 64 * LDD; d[0] = ra[it].x; d[1] = ra[it].y; d[2] = ra[it].z; d[3] = ra[it].w; }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) { float* d = db + it * 64 * LDD; d[0] = rb[it].x; d[1] = rb[it].y; d[2] = rb[it].z; d[3] = rb[it].w; }
-    };
-    load_tile(0);
-    stash(0);
-    load_tile(BKD);
-    __syncthreads();
-    int buf = 0;
-    for (int k0 = 0; k0 < g.K; k0 += BKD) {
-        const float* const ap = lds_ab[buf] + (wm * MB * 32 + i) * LDD + h;
-        const float* const bp = lds_ab[buf] + BM * LDD + (wn * NB * 32 + i) * LDD + h;
-#pragma unroll
-        for (int s = 0; s < BKD / 2; ++s) {
-            float a[MB], b[NB];
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) a[mb] = ap[mb * 32 * LDD + 2 * s];
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) b[nb] = bp[nb * 32 * LDD + 2 * s];
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
-            if (s == 1) stash(buf ^ 1);                 // tile k0 + 16 (in registers since the previous iteration) -> the other buffer
-            if (s == 4) load_tile(k0 + 2 * BKD);        // tile k0 + 32 -> registers, lands during the next iteration
+        if (T < 32) { s1[0] += __shfl_xor(s1[0], 16); s2[0] += __shfl_xor(s2[0], 16); }   // 16 rows on 32 lanes: lane bit 4 still to fold
+        // lane i (< T) of half h now holds local row t = i: mb = t / 16, r = t % 16 -> tile row (r & 3) + 8 (r >> 2) + 4 h
+        if (i < T) {
+            const int r = i & 15;
+            const int m = m0 + (wm * MB + (i >> 4)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m < M) {
+                const int P = (int)gridDim.x * 2;
+                float* sp = g.stats_out + (((size_t)m + (size_t)z * g.M) * P + blockIdx.x * 2 + wn) * 2;
+                sp[0] = s1[0]; sp[1] = s2[0];
+            }
         }
-        __syncthreads();
-        buf ^= 1;
     }
-    gemm_epilogue<MB, NB, RES>(acc, g, C, M, m0, n0, z, wm, wn, i, h);
 }
 
 int launch_gemm_nt(hipStream_t s, const GemmArgs& g_in) {
@@ -398,15 +284,11 @@ int launch_gemm_nt(hipStream_t s, const GemmArgs& g_in) {
     auto tiles = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * batch; };
     const bool res = g.R != nullptr, lna = g.stats_in != nullptr;
     static const bool lni = tune_int("RFE_LN_INTERLEAVE", 1) != 0;   // tuning switch
-    static const bool db = tune_int("RFE_GEMM_DB", 0) != 0;           // tuning switch: double-buffered K = 16 tiles, one barrier per tile
 
     static const bool pft = tune_int("RFE_GEMM_PF", 1) != 0;   // register prefetch of the next K tile also on the 128-row tiles (+1 % on ffn1 / ffn2, profiles/r02_pmc.md); RFE_GEMM_PF=0 (tuning build) disables
 #define RFE_GEMM_GO(MB_, NB_, GRID)                                                                  \
     do {                                                                                             \
-        if (db && MB_ == 2 && !lna && g.K % 16 == 0 && g.K >= 32) {                                                    \
-            if (res) hipLaunchKernelGGL((gemm_nt_db_kernel<NB_, true>), GRID, dim3(256), 0, s, g);                          \
-            else hipLaunchKernelGGL((gemm_nt_db_kernel<NB_, false>), GRID, dim3(256), 0, s, g);                             \
-        } else if (lna && lni && MB_ == 2) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, true, MB_ == 2, true>), GRID, dim3(256), 0, s, g);   /* LN + GELU on A under the MFMAs */ \
+        if (lna && lni && MB_ == 2) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, true, MB_ == 2, true>), GRID, dim3(256), 0, s, g);   /* LN + GELU on A under the MFMAs */ \
         else if (lna) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, true, false, true>), GRID, dim3(256), 0, s, g);   /* LN + GELU on A at staging */ \
         else if (pft && MB_ == 2 && res) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, true, MB_ == 2>), GRID, dim3(256), 0, s, g);    \
         else if (pft && MB_ == 2) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, false, MB_ == 2>), GRID, dim3(256), 0, s, g);     \
