@@ -296,6 +296,11 @@ int launch_gemm_nt(hipStream_t s, const GemmArgs& g_in) {
         else hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, false>), GRID, dim3(256), 0, s, g);        \
     } while (0)
     // largest tile that still gives every CU a workgroup; small problems (single-pair latency) fall to 64 x 64
+    // The LayerNorm statistics are only produced by the 128-row throughput tiles: in the latency regime (64-row tiles, one
+    // workgroup per CU) the fused normalisation puts the erf on the critical path and measured slower than the stand-alone pass
+    // (one pair: ffn.0 + ffn.3 + LN 0.74 -> 0.89 ms); the caller falls back to it when 0 comes back.
+    const bool big = (g.N % 256 == 0 && tiles(128, 256) >= 256) || tiles(128, 128) >= 256 || g.M > 8192;
+    if (!big) g.stats_out = nullptr;
     int ntiles;
     if (g.N % 256 == 0 && tiles(128, 256) >= 256) { ntiles = g.N / 256; RFE_GEMM_GO(2, 4, dim3(g.N / 256, (g.M + 127) / 128, batch)); }
     else if (tiles(128, 128) >= 256 || g.M > 8192) { ntiles = (g.N + 127) / 128; RFE_GEMM_GO(2, 2, dim3((g.N + 127) / 128, (g.M + 127) / 128, batch)); }

@@ -616,7 +616,8 @@ void lg_ffn(rfe_ctx* c, LgBuffers& b, float* x, const float* second, int rows, c
     hipStream_t s = c->stream;
     // LayerNorm(512) + GELU between the two Linears is fused across them: ffn.0's epilogue leaves per-row partial sums next to the
     // raw h, ffn.3 normalises while it stages its A tiles -- h crosses HBM once in each direction instead of twice (268 MB per block
-    // saved, one launch fewer).  RFE_LN_FUSE=0 (tuning build): the stand-alone lg_ln_gelu pass of round 1.
+    // saved, one launch fewer).  Throughput tiles only: launch_gemm_nt returns 0 partials for small problems, which keep the
+    // stand-alone lg_ln_gelu pass (as does RFE_LN_FUSE=0 in the tuning build).
     static const bool ln_fuse = tune_int("RFE_LN_FUSE", 1) != 0;
     int P = 0;
     { ProfScope p(c, "lg_ffn1");   // A = [x | second]: second is the message, or the attention context when Wo is folded into W1
@@ -624,11 +625,11 @@ void lg_ffn(rfe_ctx* c, LgBuffers& b, float* x, const float* second, int rows, c
       a.A2 = second; a.lda2 = 256; a.K1 = 256;
       if (ln_fuse) a.stats_out = b.lnstat;
       P = launch_gemm_nt(s, a); }
-    if (!ln_fuse) { ProfScope p(c, "lg_ln_gelu"); launch_lg_ln_gelu(s, b.h, g, be, rows); }
+    if (P == 0) { ProfScope p(c, "lg_ln_gelu"); launch_lg_ln_gelu(s, b.h, g, be, rows); }   // small problems (and RFE_LN_FUSE=0): stand-alone pass
     { ProfScope p(c, "lg_ffn2");
       GemmArgs a = gemm_plain(b.h, 512, w2, 512, b2, x, 256, rows, 256, 512);
       a.R = x; a.ldr = 256;
-      if (ln_fuse) { a.stats_in = b.lnstat; a.stats_p = P; a.ln_g = g; a.ln_b = be; }
+      if (P > 0) { a.stats_in = b.lnstat; a.stats_p = P; a.ln_g = g; a.ln_b = be; }
       launch_gemm_nt(s, a); }
 }
 
