@@ -95,7 +95,9 @@ int rfe_memcpy_d2h(rfe_ctx* ctx, void* dst_host, const void* src_dev, size_t byt
 
 /* ---- SuperPoint ----
  * img:   u8 grayscale, B frames of H x W, row pitch `stride` bytes, frame pitch stride*H
- *        (H, W multiples of 8; the reference asserts CV_8UC1, SPextractor.cc:525)
+ *        (any H, W >= 8, as the reference graph's dynamic axes allow: the three 2x2 max-pools floor, keypoints come from
+ *        the 8*(H/8) x 8*(W/8) top-left frame -- KITTI's 1241 x 376 gives a 1240 x 376 score map; the reference asserts
+ *        CV_8UC1, SPextractor.cc:525)
  * Kmax:  capacity per frame (the export-time max_num_keypoints of the reference graph)
  * thr:   detection threshold (0.0005 in the LightGlue-ONNX SuperPoint export)
  * n:     [B]            number of keypoints per frame
@@ -218,8 +220,8 @@ int rfe_k_conv3x3(rfe_ctx* ctx, const float* in_dev, int B, int H, int W, int Ci
 int rfe_k_linear(rfe_ctx* ctx, const float* a_dev, int M, int K, const float* w_nk_host,
                  const float* bias_host, int N, int relu, float* out_dev);
 int rfe_k_scoremap(rfe_ctx* ctx, const uint8_t* img_dev, int H, int W, int stride, int B,
-                   float* scoremap_dev /*[B,H,W] pre-NMS*/, float* nms_dev /*[B,H,W] post-NMS+border*/,
-                   float* descmap_dev /*[B,H/8,W/8,256]*/);
+                   float* scoremap_dev /*[B,Hs,Ws] pre-NMS, Hs = 8*(H/8), Ws = 8*(W/8)*/,
+                   float* nms_dev /*[B,Hs,Ws] post-NMS+border*/, float* descmap_dev /*[B,H/8,W/8,256]*/);
 int rfe_k_lightglue_taps(rfe_ctx* ctx, const float* k0n, const float* k1n, const float* d0,
                          const float* d1, int M, int N, float* x0_dev, float* x1_dev,
                          float* scores_dev /*[M,N]*/);

@@ -168,12 +168,13 @@ def superpoint(weights, img_u8, kmax=1024, thr=0.0005, nms_radius=4, border=4, d
     assert w.size == sp_weight_count()
     img = np.ascontiguousarray(img_u8, dtype=np.uint8)
     H, W = img.shape
+    Hs, Ws = H // 8 * 8, W // 8 * 8          # score-map frame (= the image when H, W are multiples of 8)
     kxy = np.zeros((kmax, 2), np.int32)
     score = np.zeros((kmax,), np.float32)
     desc = np.zeros((kmax, 256), np.float32)
     dbg = {}
     if debug:
-        dbg = dict(scoremap=np.empty((H, W), np.float32), nms=np.empty((H, W), np.float32),
+        dbg = dict(scoremap=np.empty((Hs, Ws), np.float32), nms=np.empty((Hs, Ws), np.float32),
                    descmap=np.empty((H // 8, W // 8, 256), np.float32),
                    feat=np.empty((H // 8, W // 8, 128), np.float32))
     n = lib().rfo_superpoint(wp, img.ctypes.data_as(C.POINTER(C.c_uint8)), H, W, kmax, thr, nms_radius, border,

@@ -253,7 +253,11 @@ static int cand_cmp(const void* a, const void* b) {
 int rfo_superpoint(const float* wts, const uint8_t* img, int H, int W, int Kmax, float thr,
                    int nms_radius, int border, int32_t* kxy, float* score, float* desc,
                    float* dbg_scoremap, float* dbg_nms, float* dbg_descmap, float* dbg_feat) {
-    const int Hc = H / 8, Wc = W / 8;
+    /* Any H, W >= 8, like the ONNX graph (dynamic axes): the three 2x2/2 max-pools floor, so the feature grid is Hc x Wc =
+     * floor(H/8) x floor(W/8) and everything after the heads lives on the Hs x Ws = 8Hc x 8Wc score map (= the image when H, W
+     * are multiples of 8; e.g. KITTI 1241 x 376 -> 155 x 47 cells, score map 1240 x 376). */
+    const int Hc = H / 2 / 2 / 2, Wc = W / 2 / 2 / 2;
+    const int Himg = H, Wimg = W;
 #define WOFF(l) (wts + rfo_sp_layer_offset((l), 0))
 #define BOFF(l) (wts + rfo_sp_layer_offset((l), 1))
     size_t n0 = (size_t)H * W;
@@ -263,10 +267,10 @@ int rfo_superpoint(const float* wts, const uint8_t* img, int H, int W, int Kmax,
     for (size_t i = 0; i < n0; ++i) a[i] = (float)img[i] * 0.003921568859368563f;
     rfo_conv3x3(a, H, W, 1, WOFF(0), BOFF(0), 64, 1, 0, b);
     rfo_conv3x3(b, H, W, 64, WOFF(1), BOFF(1), 64, 1, 1, a);
-    rfo_conv3x3(a, H / 2, W / 2, 64, WOFF(2), BOFF(2), 64, 1, 0, b);
-    rfo_conv3x3(b, H / 2, W / 2, 64, WOFF(3), BOFF(3), 64, 1, 1, a);
-    rfo_conv3x3(a, H / 4, W / 4, 64, WOFF(4), BOFF(4), 128, 1, 0, b);
-    rfo_conv3x3(b, H / 4, W / 4, 128, WOFF(5), BOFF(5), 128, 1, 1, a);
+    rfo_conv3x3(a, Himg / 2, Wimg / 2, 64, WOFF(2), BOFF(2), 64, 1, 0, b);
+    rfo_conv3x3(b, Himg / 2, Wimg / 2, 64, WOFF(3), BOFF(3), 64, 1, 1, a);
+    rfo_conv3x3(a, Himg / 2 / 2, Wimg / 2 / 2, 64, WOFF(4), BOFF(4), 128, 1, 0, b);
+    rfo_conv3x3(b, Himg / 2 / 2, Wimg / 2 / 2, 128, WOFF(5), BOFF(5), 128, 1, 1, a);
     rfo_conv3x3(a, Hc, Wc, 128, WOFF(6), BOFF(6), 128, 1, 0, b);
     rfo_conv3x3(b, Hc, Wc, 128, WOFF(7), BOFF(7), 128, 1, 0, a); /* a = feat [Hc,Wc,128] */
     if (dbg_feat) memcpy(dbg_feat, a, sizeof(float) * (size_t)Hc * Wc * 128);
@@ -275,6 +279,8 @@ int rfo_superpoint(const float* wts, const uint8_t* img, int H, int W, int Kmax,
     float* logits = (float*)malloc(sizeof(float) * (size_t)cells * 65);
     rfo_conv3x3(a, Hc, Wc, 128, WOFF(8), BOFF(8), 256, 1, 0, pa);
     rfo_linear(pa, cells, 256, WOFF(9), BOFF(9), 65, logits);
+    H = 8 * Hc; W = 8 * Wc;      /* from here on: the score map's frame */
+    n0 = (size_t)H * W;
     float* smap = (float*)malloc(sizeof(float) * n0);
     float* nmap = (float*)malloc(sizeof(float) * n0);
     rfo_softmax65_d2s(logits, Hc, Wc, smap);

@@ -47,8 +47,11 @@ constexpr size_t AT_SPLIT_MAX_ROWS = 8192;    // only problems this small are la
 // row and L2 resident).  Net effect on the step: none within noise (profiles/r02_pmc.md) -- kept because it removes the
 // LDS-transposed epilogue from the GEMM.  Variants that did not pay (double-buffered LDS, register prefetch of the next tile,
 // 64 queries per wave, 256-query workgroups, k rotated by the projection and q here) are recorded in profiles/r01_pmc.md / r02_pmc.md.
-template <int ABL = 0, bool SPLIT = false, bool ROPE = false>
-__global__ __launch_bounds__(256, 4) void lg_attention_kernel(   // 4 workgroups per CU: at most 128 VGPRs
+// PFK (split variant only): the next K/V tile is fetched into registers right after the current one is published, i.e. under the
+// MFMAs.  The split variant runs one workgroup per CU, so nothing else hides the global round trip of every tile (the throughput
+// variant has 4 co-resident workgroups and measured slower with the prefetch: 146 VGPRs -> 3 workgroups, profiles/r02_ab_notes.md).
+template <int ABL = 0, bool SPLIT = false, bool ROPE = false, bool PFK = false>
+__global__ __launch_bounds__(256, PFK ? 2 : 4) void lg_attention_kernel(   // 4 workgroups per CU: at most 128 VGPRs
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld, float* __restrict__ out,
     int Lq, int Lk, int nqb, const int* __restrict__ qlen, const int* __restrict__ klen, const int* __restrict__ kv_map,
     int prio, float* __restrict__ part, int nseq_total, const float* __restrict__ rope_csn) {
@@ -143,10 +146,16 @@ __global__ __launch_bounds__(256, 4) void lg_attention_kernel(   // 4 workgroups
         kbeg = (int)blockIdx.y * per;
         kend = kbeg + per < nk ? kbeg + per : nk;
     }
+    if (PFK && kbeg < kend) fetch(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += AT_K) {
         const bool more = DBUF && (k0 + AT_K < kend);
         if (DBUF) {
             if (more) fetch(k0 + AT_K);
+        } else if (PFK) {
+            __syncthreads();
+            stash(0);
+            __syncthreads();
+            if (k0 + AT_K < kend) fetch(k0 + AT_K);
         } else if (!(ABL & 2) || k0 == 0) {
             __syncthreads();
             fetch(k0);
@@ -292,7 +301,14 @@ void launch_lg_attention(hipStream_t s, const float* q, const float* k, const fl
         while (ns < AT_SPLIT_MAX && units * ns * 2 <= 256 && Lk / (ns * 2) >= 2 * AT_K) ns *= 2;
         if (split_env > 1) ns = split_env < AT_SPLIT_MAX ? split_env : AT_SPLIT_MAX;
         if (ns > 1) {
-            if (rope)
+            static const bool pfk = tune_int("RFE_ATT_SPLIT_PF", 1) != 0;
+            if (rope && pfk)
+                hipLaunchKernelGGL((lg_attention_kernel<0, true, true, true>), dim3(nqb * units8, ns), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk,
+                                   nqb, qlen, klen, kv_map, 1, part, nseq, rope_csn);
+            else if (pfk)
+                hipLaunchKernelGGL((lg_attention_kernel<0, true, false, true>), dim3(nqb * units8, ns), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk,
+                                   nqb, qlen, klen, kv_map, 1, part, nseq, rope_csn);
+            else if (rope)
                 hipLaunchKernelGGL((lg_attention_kernel<0, true, true>), dim3(nqb * units8, ns), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk,
                                    nqb, qlen, klen, kv_map, 1, part, nseq, rope_csn);
             else

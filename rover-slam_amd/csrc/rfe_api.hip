@@ -453,7 +453,7 @@ GemmArgs gemm_plain(const float* A, int lda, const float* Bw, int ldb, const flo
 int sp_check(rfe_ctx* c, int H, int W, int B, int Kmax) {
     if (!c) return RFE_ERR_INVALID;
     if (!c->has_sp) return fail(c, RFE_ERR_NO_WEIGHTS, "SuperPoint weights not loaded (rfe_load_weights / rfe_set_weights)");
-    if (H <= 0 || W <= 0 || (H % 8) || (W % 8) || B <= 0) return fail(c, RFE_ERR_INVALID, "extract: H and W must be positive multiples of 8, B > 0");
+    if (H < 8 || W < 8 || B <= 0) return fail(c, RFE_ERR_INVALID, "extract: H and W must be at least 8, B > 0");
     if (Kmax <= 0 || Kmax > 4096) return fail(c, RFE_ERR_INVALID, "extract: Kmax must be in 1..4096");
     return RFE_OK;
 }
@@ -468,7 +468,10 @@ int sp_forward_maps(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, in
     sp_carve(c->ws_sp, B, H, W, b);
     hipStream_t s = c->stream;
     const SpWeightsDev& w = c->sp;
-    const int Hc = H / 8, Wc = W / 8, cells = B * Hc * Wc;
+    // Any H, W >= 8 (the ONNX graph has dynamic axes): every 2x2/2 max-pool floors, so the levels are H1 = H/2, H2 = H1/2,
+    // Hc = H2/2 and the score map / NMS / selection live on the 8Hc x 8Wc frame (= the image when H, W are multiples of 8;
+    // KITTI 1241 x 376 -> 155 x 47 cells, score map 1240 x 376).  The workspace carve (sized from B*H*W) is an upper bound.
+    const int H1 = H / 2, W1 = W / 2, H2 = H1 / 2, W2 = W1 / 2, Hc = H2 / 2, Wc = W2 / 2, cells = B * Hc * Wc;
     if (sp_unfused_conv1()) {
         { ProfScope p(c, "conv1a"); launch_conv1a_u8(s, img, stride, B, H, W, w.conv1a_w, w.bias[L_1A], b.a1); }
         { ProfScope p(c, "conv1b"); launch_conv3x3(s, b.a1, B, H, W, 64, w.packed[L_1B], w.bias[L_1B], 64, true, true, b.p1, L_1B); }
@@ -476,10 +479,10 @@ int sp_forward_maps(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, in
         ProfScope p(c, "conv1ab");
         launch_conv1ab_fused(s, img, stride, B, H, W, w.conv1a_w, w.bias[L_1A], w.packed[L_1B], w.bias[L_1B], b.p1);
     }
-    { ProfScope p(c, "conv2a"); launch_conv3x3(s, b.p1, B, H / 2, W / 2, 64, w.packed[L_2A], w.bias[L_2A], 64, true, false, b.a2, L_2A); }
-    { ProfScope p(c, "conv2b"); launch_conv3x3(s, b.a2, B, H / 2, W / 2, 64, w.packed[L_2B], w.bias[L_2B], 64, true, true, b.p2, L_2B); }
-    { ProfScope p(c, "conv3a"); launch_conv3x3(s, b.p2, B, H / 4, W / 4, 64, w.packed[L_3A], w.bias[L_3A], 128, true, false, b.a3, L_3A); }
-    { ProfScope p(c, "conv3b"); launch_conv3x3(s, b.a3, B, H / 4, W / 4, 128, w.packed[L_3B], w.bias[L_3B], 128, true, true, b.p3, L_3B); }
+    { ProfScope p(c, "conv2a"); launch_conv3x3(s, b.p1, B, H1, W1, 64, w.packed[L_2A], w.bias[L_2A], 64, true, false, b.a2, L_2A); }
+    { ProfScope p(c, "conv2b"); launch_conv3x3(s, b.a2, B, H1, W1, 64, w.packed[L_2B], w.bias[L_2B], 64, true, true, b.p2, L_2B); }
+    { ProfScope p(c, "conv3a"); launch_conv3x3(s, b.p2, B, H2, W2, 64, w.packed[L_3A], w.bias[L_3A], 128, true, false, b.a3, L_3A); }
+    { ProfScope p(c, "conv3b"); launch_conv3x3(s, b.a3, B, H2, W2, 128, w.packed[L_3B], w.bias[L_3B], 128, true, true, b.p3, L_3B); }
     { ProfScope p(c, "conv4a"); launch_conv3x3(s, b.p3, B, Hc, Wc, 128, w.packed[L_4A], w.bias[L_4A], 128, true, false, b.a4, L_4A); }
     { ProfScope p(c, "conv4b"); launch_conv3x3(s, b.a4, B, Hc, Wc, 128, w.packed[L_4B], w.bias[L_4B], 128, true, false, b.f4, L_4B); }
     // The two heads only share their input f4.  The descriptor head (convDa, convDb, L2 norm: MFMA work) runs on the
@@ -498,7 +501,7 @@ int sp_forward_maps(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, in
     { ProfScope p(c, "convPb"); launch_gemm_nt(s, gemm_plain(b.pa, 256, w.packed[L_PB], 256, w.bias[L_PB], b.logits, 65, cells, 65, 256)); }
     { ProfScope p(c, "sp_post");
       launch_softmax65_d2s(s, b.logits, 65, B, Hc, Wc, b.smap);
-      launch_nms(s, b.smap, B, H, W, 4, b.ss, b.mask, b.supp, b.nmap); }
+      launch_nms(s, b.smap, B, 8 * Hc, 8 * Wc, 4, b.ss, b.mask, b.supp, b.nmap); }
     if (fork && join) RFE_HIP(c, hipStreamWaitEvent(s, c->ev_join, 0));
     forked = fork && !join;
     RFE_HIP(c, hipGetLastError());
@@ -511,10 +514,11 @@ int sp_forward(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, int B, 
     bool forked;
     int rc = sp_forward_maps(c, img, H, W, stride, B, b, false, forked);
     if (rc) return rc;
+    const int Hc = H / 2 / 2 / 2, Wc = W / 2 / 2 / 2, Hs = 8 * Hc, Ws = 8 * Wc;   // score-map frame, see sp_forward_maps
     { ProfScope p(c, "sp_select");
-      launch_select(c->stream, b.nmap, B, H, W, Kmax, thr, b.cand_score, b.cand_idx, n, kxy, score, (int32_t*)b.ss /*NMS scratch, free by now*/);
+      launch_select(c->stream, b.nmap, B, Hs, Ws, Kmax, thr, b.cand_score, b.cand_idx, n, kxy, score, (int32_t*)b.ss /*NMS scratch, free by now*/);
       if (forked) RFE_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));   // descriptor map ready
-      launch_desc_sample(c->stream, b.dmap, B, H / 8, W / 8, H, W, n, kxy, Kmax, desc, desc_bin); }
+      launch_desc_sample(c->stream, b.dmap, B, Hc, Wc, Hs, Ws, n, kxy, Kmax, desc, desc_bin); }
     RFE_HIP(c, hipGetLastError());
     return RFE_OK;
 }
@@ -1156,7 +1160,7 @@ extern "C" int rfe_k_scoremap(rfe_ctx* c, const uint8_t* img, int H, int W, int 
     SpBuffers b;
     bool forked;
     if ((rc = sp_forward_maps(c, img, H, W, stride, B, b, true, forked))) return rc;
-    const size_t hw = (size_t)B * H * W;
+    const size_t hw = (size_t)B * (H / 8 * 8) * (W / 8 * 8);   // maps are on the score-map frame: [B, 8*(H/8), 8*(W/8)]
     if (scoremap) RFE_HIP(c, hipMemcpyAsync(scoremap, b.smap, hw * 4, hipMemcpyDeviceToDevice, c->stream));
     if (nms) RFE_HIP(c, hipMemcpyAsync(nms, b.nmap, hw * 4, hipMemcpyDeviceToDevice, c->stream));
     if (descmap) RFE_HIP(c, hipMemcpyAsync(descmap, b.dmap, hw / 64 * 256 * 4, hipMemcpyDeviceToDevice, c->stream));

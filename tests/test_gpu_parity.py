@@ -76,15 +76,17 @@ def test_conv3x3_bitexact(ctx, oracle, H, W, Cin, Cout, relu, pool):
 
 
 # ------------------------------------------------------------------ SuperPoint
-@pytest.mark.parametrize("H,W", [(64, 96), (120, 160), (72, 200)])
+@pytest.mark.parametrize("H,W", [(64, 96), (120, 160), (72, 200), (77, 101), (63, 130), (100, 150)])
 def test_superpoint_maps_bitexact(ctx, oracle, H, W):
+    """includes sizes that are not multiples of 8 (and of 2, 4): floor pooling, maps on the 8*(H/8) x 8*(W/8) frame"""
     from rover_slam_amd import capi
     frames, _ = synth.make_frames(2, H, W, seed=H + W)
     dimg = _dev(ctx, frames)
-    ds, dn, dd = ctx.alloc(2 * H * W * 4), ctx.alloc(2 * H * W * 4), ctx.alloc(2 * (H // 8) * (W // 8) * 256 * 4)
+    Hs, Ws = H // 8 * 8, W // 8 * 8
+    ds, dn, dd = ctx.alloc(2 * Hs * Ws * 4), ctx.alloc(2 * Hs * Ws * 4), ctx.alloc(2 * (H // 8) * (W // 8) * 256 * 4)
     ctx._chk(capi.lib.rfe_k_scoremap(ctx.h, dimg.ptr, H, W, W, 2, ds.ptr, dn.ptr, dd.ptr))
-    smap = ds.download((2, H, W), np.float32)
-    nmap = dn.download((2, H, W), np.float32)
+    smap = ds.download((2, Hs, Ws), np.float32)
+    nmap = dn.download((2, Hs, Ws), np.float32)
     dmap = dd.download((2, H // 8, W // 8, 256), np.float32)
     w = Wt.make_superpoint(seed=7)
     for i in range(2):
@@ -96,7 +98,7 @@ def test_superpoint_maps_bitexact(ctx, oracle, H, W):
         d.free()
 
 
-@pytest.mark.parametrize("H,W,kmax", [(120, 160, 4096), (120, 160, 100), (64, 96, 33), (240, 320, 512)])
+@pytest.mark.parametrize("H,W,kmax", [(120, 160, 4096), (120, 160, 100), (64, 96, 33), (240, 320, 512), (125, 163, 4096), (93, 201, 64)])
 def test_extract_bitexact_vs_oracle(ctx, oracle, H, W, kmax):
     frames, _ = synth.make_frames(3, H, W, seed=kmax)
     n, kxy, score, desc = ctx.extract(frames, kmax=kmax)
@@ -226,6 +228,24 @@ def test_extract_fullsize_topk_vs_golden(ctx, golden_dir):
         assert n[0] == 1024 and {tuple(k) for k in kxy[0]} == set(where)
         perm = [where[tuple(k)] for k in kxy[0]]
         assert np.abs(score[0] - g["score"][perm]).max() < 5e-6 and np.abs(desc[0] - g["desc"][perm]).max() < 2e-6
+
+
+def test_extract_kitti_size_vs_oracle_and_golden(ctx, oracle, golden_dir):
+    """KITTI's 1241 x 376 (not a multiple of 8; the reference graph has dynamic axes): bit-exact against the oracle, and against the
+    independent HF fixture sp_f (top-k of 7790 candidates) / sp_g (101 x 151, all candidates)."""
+    w = Wt.make_superpoint(seed=7)
+    for tag in ("f", "g"):
+        g = np.load(f"{golden_dir}/sp_{tag}.npz")
+        kmax = int(g["kmax"])
+        n, kxy, score, desc = ctx.extract(g["image"], kmax=kmax)
+        r = oracle.superpoint(w, g["image"], kmax=kmax)
+        assert n[0] == r["n"] == int(g["n"])
+        k = r["n"]
+        assert np.array_equal(kxy[0, :k], r["kxy"][:k]) and np.array_equal(score[0, :k], r["score"][:k]) and np.array_equal(desc[0, :k], r["desc"][:k])
+        where = {tuple(q): i for i, q in enumerate(g["kxy"])}
+        assert {tuple(q) for q in kxy[0, :k]} == set(where)
+        perm = [where[tuple(q)] for q in kxy[0, :k]]
+        assert np.abs(score[0, :k] - g["score"][perm]).max() < 5e-6 and np.abs(desc[0, :k] - g["desc"][perm]).max() < 2e-6
 
 
 def test_lightglue_ragged_batch(ctx, oracle):
@@ -361,8 +381,8 @@ def test_error_paths(ctx):
     with pytest.raises(capi.RfeError, match="weights not loaded"):
         c.extract(img)
     c.set_weights(capi.KIND_SUPERPOINT, Wt.make_superpoint(seed=7))
-    with pytest.raises(capi.RfeError, match="multiples of 8"):
-        c.extract(np.zeros((1, 60, 100), np.uint8))
+    with pytest.raises(capi.RfeError, match="at least 8"):
+        c.extract(np.zeros((1, 7, 100), np.uint8))
     with pytest.raises(capi.RfeError, match="wrong float count"):
         c.set_weights(capi.KIND_LIGHTGLUE, np.zeros(10, np.float32))
     with pytest.raises(capi.RfeError):

@@ -62,6 +62,29 @@ def test_superpoint_oracle_vs_golden_fullsize_topk(oracle, golden_dir, tag):
     assert np.array_equal(np.lexsort((flat, -r["score"].astype(np.float64))), np.arange(1024))
 
 
+@pytest.mark.parametrize("tag", ["f", "g"])
+def test_superpoint_oracle_vs_golden_sizes_not_multiple_of_8(oracle, golden_dir, tag):
+    """The reference graph has dynamic axes, so any image size goes through it (KITTI: 1241 x 376).  The max-pools floor and the
+    score map is the 8*(H/8) x 8*(W/8) top-left frame: f = 376 x 1241 through the top-k path, g = 101 x 151 with all
+    candidates kept (row-major order, compared one to one)."""
+    g = np.load(f"{golden_dir}/sp_{tag}.npz")
+    H, W = g["image"].shape
+    assert H % 8 or W % 8
+    w = Wt.make_superpoint(seed=int(g["seed"]), dustbin_bias=float(g["dustbin_bias"]))
+    r = oracle.superpoint(w, g["image"], kmax=int(g["kmax"]), debug=True)
+    assert r["scoremap"].shape == (H // 8 * 8, W // 8 * 8) and r["descmap"].shape[:2] == (H // 8, W // 8)
+    n = int(g["n"])
+    assert r["n"] == n
+    where = {tuple(k): i for i, k in enumerate(g["kxy"])}
+    assert {tuple(k) for k in r["kxy"][:n]} == set(where)
+    perm = [where[tuple(k)] for k in r["kxy"][:n]]
+    if n == int(g["candidates"]):
+        assert perm == list(range(n))          # below Kmax: both row-major
+    assert np.abs(r["score"][:n] - g["score"][perm]).max() < 5e-6
+    assert np.abs(r["desc"][:n] - g["desc"][perm]).max() < 2e-6
+    assert r["kxy"][:n, 0].max() < W // 8 * 8 - 4 and r["kxy"][:n, 1].max() < H // 8 * 8 - 4     # border of the score-map frame
+
+
 @pytest.mark.parametrize("tag", ["c", "d"])
 def test_lightglue_oracle_vs_golden_fullsize(oracle, golden_dir, tag):
     """M = N = 1024 and the ragged 700 x 1024 pair (HF runs it padded + masked, the oracle on the true lengths)."""

@@ -16,6 +16,7 @@ against a second, unrelated code base.  Differences handled here:
 
 usage: python tools/gen_golden.py            (writes tests/golden/sp_{a,b,c}.npz, lg_{a,b}.npz: small cases)
        python tools/gen_golden.py fullsize   (writes sp_{d,e}.npz, lg_{c,d}.npz: the sizes bench.py runs, top-k path, ragged pair)
+       python tools/gen_golden.py oddsize    (writes sp_{f,g}.npz: 376 x 1241 and 101 x 151, sizes that are not multiples of 8)
 """
 import os
 import sys
@@ -73,8 +74,10 @@ def run_hf_superpoint(m, img_u8):
 def run_hf_superpoint_topk(m, img_u8, kmax):
     """Top-k path (count > Kmax, which every bench frame takes): HF's own functions in HF's own order -- pixel scores +
     simple_nms, threshold, border removal, torch.topk, descriptor sampling -- driven one by one so that
-    remove_keypoints_from_borders gets the true image size (inside the model it is called with (8H, 8W) and never removes
-    the right / bottom border, which would change WHICH keypoints make the top k)."""
+    remove_keypoints_from_borders gets the true score-map size (inside the model it is called with (8H, 8W) and never removes
+    the right / bottom border, which would change WHICH keypoints make the top k).  The score map is 8*(H/8) x 8*(W/8), the
+    frame the published SuperPoint (and the LightGlue-ONNX export the reference loads) blanks the 4-px border on; it equals the
+    image when H and W are multiples of 8."""
     from transformers.models.superpoint import modeling_superpoint as MS
     H, W = img_u8.shape
     x = torch.from_numpy(img_u8.astype(np.float32) * np.float32(1.0 / 255.0))[None, None]
@@ -84,7 +87,8 @@ def run_hf_superpoint_topk(m, img_u8, kmax):
         scores = dec._get_pixel_scores(feat)
         kp = torch.nonzero(scores[0] > dec.keypoint_threshold)
         sc = scores[0][tuple(kp.t())]
-        kp, sc = MS.remove_keypoints_from_borders(kp, sc, dec.border_removal_distance, H, W)
+        assert scores.shape[1:] == (H // 8 * 8, W // 8 * 8)
+        kp, sc = MS.remove_keypoints_from_borders(kp, sc, dec.border_removal_distance, scores.shape[1], scores.shape[2])
         ncand = int(kp.shape[0])
         kp, sc = MS.top_k_keypoints(kp, sc, kmax)
         kxy = torch.flip(kp, [1]).to(sc.dtype)
@@ -223,8 +227,25 @@ def main_fullsize():
         print(f"lg_{tag}: {M} x {N} matches={len(hf['pairs'])}")
 
 
+def main_oddsize():
+    """Image sizes that are not multiples of 8 (the reference graph has dynamic axes; KITTI is 1241 x 376): sp_f = 376 x 1241 through
+    the top-k path, sp_g = 101 x 151 with every candidate kept.  The pools floor, the score map is 8*(H/8) x 8*(W/8)."""
+    os.makedirs(GOLD, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    wsp = Wt.make_superpoint(seed=7)
+    for tag, (H, W), kmax, seed in (("f", (376, 1241), 1024, 31), ("g", (101, 151), 4096, 32)):
+        img = R.synth.make_frames(1, H, W, seed=seed)[0][0]
+        hf = run_hf_superpoint_topk(hf_superpoint(wsp, kmax), img, kmax)
+        np.savez_compressed(os.path.join(GOLD, f"sp_{tag}.npz"), image=img, seed=7, dustbin_bias=0.0, kmax=kmax, n=hf["n"],
+                            candidates=hf["candidates"], kxy=hf["kxy"], score=hf["score"], desc=hf["desc"])
+        print(f"sp_{tag}: {img.shape} n={hf['n']} of {hf['candidates']} candidates")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "fullsize":
         main_fullsize()
+    elif len(sys.argv) > 1 and sys.argv[1] == "oddsize":
+        main_oddsize()
     else:
         main()

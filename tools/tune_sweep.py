@@ -35,9 +35,12 @@ def main():
             except Exception:
                 print(f"{name}: FAILED rc={r.returncode} {r.stderr.strip().splitlines()[-1][:300] if r.stderr.strip() else ''}", flush=True)
                 continue
-            st = d["stages"]
+            if "stages_ms_per_step" in d:        # latency workloads (--extra '--workload c3'): flat stage table
+                st = {k: {"ms_per_step": v} for k, v in d["stages_ms_per_step"].items()}
+            else:
+                st = d["stages"]
             rows.append((name, d["value"], d["ms_per_step"], {k: st[k]["ms_per_step"] for k in STAGES if k in st}))
-            print(f"{name:24s} {d['value']:8.2f} f/s {d['ms_per_step']:7.3f} ms | " + " ".join(f"{k}={st[k]['ms_per_step']:.3f}" for k in STAGES if k in st), flush=True)
+            print(f"{name:24s} {d['value']:8.2f} {d['unit']} {d['ms_per_step']:7.4f} ms | " + " ".join(f"{k}={st[k]['ms_per_step']:.4f}" for k in STAGES if k in st), flush=True)
 
 
 if __name__ == "__main__":
