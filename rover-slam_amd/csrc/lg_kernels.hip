@@ -407,34 +407,6 @@ __global__ __launch_bounds__(256) void lg_rowlse_kernel(const float* __restrict_
     if (lane == 0) rowlse[(size_t)p * L + i] = mx + logf(s);
 }
 
-// column log-sum-exp: block = 32 columns x 8 row groups
-__global__ __launch_bounds__(256) void lg_collse_kernel(const float* __restrict__ sim, int L, const int* __restrict__ m,
-                                                        const int* __restrict__ n, float* __restrict__ collse) {
-    __shared__ float red[8][33];
-    const int p = blockIdx.y, c = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const int jj = blockIdx.x * 32 + c;
-    const int mm = m[p], nn = n[p];
-    const float* base = sim + (size_t)p * L * L;
-    float mx = -INFINITY;
-    if (jj < nn) for (int i = rg; i < mm; i += 8) mx = fmaxf(mx, base[(size_t)i * L + jj]);
-    red[rg][c] = mx;
-    __syncthreads();
-    float gm = red[0][c];
-#pragma unroll
-    for (int g = 1; g < 8; ++g) gm = fmaxf(gm, red[g][c]);
-    __syncthreads();
-    float s = 0.f;
-    if (jj < nn) for (int i = rg; i < mm; i += 8) s += expf(base[(size_t)i * L + jj] - gm);
-    red[rg][c] = s;
-    __syncthreads();
-    if (rg == 0 && jj < nn) {
-        float t = 0.f;
-#pragma unroll
-        for (int g = 0; g < 8; ++g) t += red[g][c];
-        collse[(size_t)p * L + jj] = gm + logf(t);
-    }
-}
-
 __device__ __forceinline__ float lg_score(float sv, float lr, float lc, float l0, float l1) {
     return ((sv - lr) + (sv - lc)) + (l0 + l1);
 }
@@ -464,20 +436,44 @@ __global__ __launch_bounds__(256) void lg_rowarg_kernel(const float* __restrict_
     if (lane == 0) { a0[(size_t)p * L + i] = bi == 0x7fffffff ? 0 : bi; mx0[(size_t)p * L + i] = best; }
 }
 
-__global__ __launch_bounds__(256) void lg_colarg_kernel(const float* __restrict__ sim, const float* __restrict__ z0,
-                                                        const float* __restrict__ z1, const float* __restrict__ rowlse,
-                                                        const float* __restrict__ collse, int L, const int* __restrict__ m,
-                                                        const int* __restrict__ n, int32_t* __restrict__ a1) {
-    __shared__ float rb[8][33];
-    __shared__ int ri[8][33];
-    const int p = blockIdx.y, c = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const int jj = blockIdx.x * 32 + c;
+// Column pass, fused: column log-sum-exp AND column argmax (first maximum) of the score matrix in one launch -- a workgroup owns a
+// stripe of CW columns x all rows (CW * 4 B per row; 128 KB at L = 1024, CW = 32) and walks it three times (max, sum of exp, argmax
+// of the scores), the second and third walk hitting L2.  Needs only rowlse; collse goes out for the row argmax that follows.
+// <32, 8>: throughput shape (L/32 workgroups per pair).  <16, 64>: one or a few pairs -- 1024 threads, 64 workgroups per 1024
+// columns, 16 rows per thread instead of 128 (single pair at K = 1024: 46 + 20 us for the two separate kernels -> one short launch).
+template <int CW, int RG>
+__global__ __launch_bounds__(CW * RG) void lg_col_kernel(const float* __restrict__ sim, const float* __restrict__ z0,
+                                                         const float* __restrict__ z1, const float* __restrict__ rowlse, int L,
+                                                         const int* __restrict__ m, const int* __restrict__ n,
+                                                         float* __restrict__ collse, int32_t* __restrict__ a1) {
+    __shared__ float rb[RG][CW + 1];
+    __shared__ int ri[RG][CW + 1];
+    const int p = blockIdx.y, c = threadIdx.x % CW, rg = threadIdx.x / CW;
+    const int jj = blockIdx.x * CW + c;
     const int mm = m[p], nn = n[p];
     const float* base = sim + (size_t)p * L * L;
+    float mx = -INFINITY;
+    if (jj < nn) for (int i = rg; i < mm; i += RG) mx = fmaxf(mx, base[(size_t)i * L + jj]);
+    rb[rg][c] = mx;
+    __syncthreads();
+    float gm = rb[0][c];
+#pragma unroll 8
+    for (int g = 1; g < RG; ++g) gm = fmaxf(gm, rb[g][c]);
+    __syncthreads();
+    float sum = 0.f;
+    if (jj < nn) for (int i = rg; i < mm; i += RG) sum += expf(base[(size_t)i * L + jj] - gm);
+    rb[rg][c] = sum;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll 8
+    for (int g = 0; g < RG; ++g) t += rb[g][c];       // every thread of a column: the same sum in the same order
+    const float lc = gm + logf(t);
+    __syncthreads();
     float best = -INFINITY; int bi = 0x7fffffff;
     if (jj < nn) {
-        const float lc = collse[(size_t)p * L + jj], l1 = z1[(size_t)p * L + jj];
-        for (int i = rg; i < mm; i += 8) {
+        if (rg == 0) collse[(size_t)p * L + jj] = lc;
+        const float l1 = z1[(size_t)p * L + jj];
+        for (int i = rg; i < mm; i += RG) {
             const float sc = lg_score(base[(size_t)i * L + jj], rowlse[(size_t)p * L + i], lc, z0[(size_t)p * L + i], l1);
             if (sc > best) { best = sc; bi = i; }
         }
@@ -485,8 +481,7 @@ __global__ __launch_bounds__(256) void lg_colarg_kernel(const float* __restrict_
     rb[rg][c] = best; ri[rg][c] = bi;
     __syncthreads();
     if (rg == 0 && jj < nn) {
-#pragma unroll
-        for (int g = 1; g < 8; ++g) {
+        for (int g = 1; g < RG; ++g) {
             const float ob = rb[g][c]; const int oi = ri[g][c];
             if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
         }
@@ -534,9 +529,11 @@ void launch_lg_assign(hipStream_t s, const float* sim, const float* z0, const fl
                       const int* m, const int* n, float thr, float* scores_opt, float* rowlse, float* collse,
                       int32_t* a0, float* mx0, int32_t* a1, int32_t* S, int32_t* pairs, float* ms) {
     hipLaunchKernelGGL(lg_rowlse_kernel, dim3((L + 3) / 4, P), dim3(256), 0, s, sim, L, m, n, rowlse);
-    hipLaunchKernelGGL(lg_collse_kernel, dim3((L + 31) / 32, P), dim3(256), 0, s, sim, L, m, n, collse);
+    if ((long long)P * ((L + 31) / 32) < 128)   // a few pairs: narrower stripes, 4x the threads per workgroup
+        hipLaunchKernelGGL((lg_col_kernel<16, 64>), dim3((L + 15) / 16, P), dim3(1024), 0, s, sim, z0, z1, rowlse, L, m, n, collse, a1);
+    else
+        hipLaunchKernelGGL((lg_col_kernel<32, 8>), dim3((L + 31) / 32, P), dim3(256), 0, s, sim, z0, z1, rowlse, L, m, n, collse, a1);
     hipLaunchKernelGGL(lg_rowarg_kernel, dim3((L + 3) / 4, P), dim3(256), 0, s, sim, z0, z1, rowlse, collse, L, m, n, a0, mx0, scores_opt);
-    hipLaunchKernelGGL(lg_colarg_kernel, dim3((L + 31) / 32, P), dim3(256), 0, s, sim, z0, z1, rowlse, collse, L, m, n, a1);
     hipLaunchKernelGGL(lg_mutual_kernel, dim3(P), dim3(256), 0, s, a0, mx0, a1, L, cap, m, n, thr, S, pairs, ms);
 }
 

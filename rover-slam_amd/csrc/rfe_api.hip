@@ -703,20 +703,43 @@ __global__ void lg_setup_kernel(const int32_t* m, const int32_t* n, int P, int M
     kvmap[i] = i < P ? i + P : i - P;
 }
 
-// stage device inputs [P,Mmax,*]/[P,Nmax,*] into the padded side-major token layout
+// stage device inputs [P,Mmax,*]/[P,Nmax,*] into the padded side-major token layout: descriptors -> x, normalised keypoints -> kn,
+// rows past the input capacity zeroed, clamped lengths + cross-attention map -- one launch (it replaced two memsets, four strided
+// device-to-device copies and the set-up kernel: eight enqueues per call on the single-pair latency path)
+__global__ __launch_bounds__(256) void lg_stage_kernel(const float* __restrict__ k0n, const float* __restrict__ k1n,
+                                                       const float* __restrict__ d0, const float* __restrict__ d1,
+                                                       const int32_t* __restrict__ m, const int32_t* __restrict__ n, int P, int Mmax,
+                                                       int Nmax, int L, float* __restrict__ x, float* __restrict__ kn,
+                                                       int32_t* __restrict__ lens, int32_t* __restrict__ kvmap) {
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < 2 * P; i += 256) {
+            int v = i < P ? m[i] : n[i - P];
+            const int cap = i < P ? Mmax : Nmax;
+            v = v < 0 ? 0 : (v > cap ? cap : v);
+            lens[i] = v;
+            kvmap[i] = i < P ? i + P : i - P;
+        }
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // side-major: row = (side * P + pair) * L + i
+    if (row >= (int64_t)2 * P * L) return;
+    const int lane = threadIdx.x & 63;
+    const int i = (int)(row % L), sp = (int)(row / L), side = sp >= P, pair = side ? sp - P : sp;
+    const int cap = side ? Nmax : Mmax;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 kv = make_float2(0.f, 0.f);
+    if (i < cap) {
+        const size_t src = (size_t)pair * cap + i;
+        v = reinterpret_cast<const float4*>((side ? d1 : d0) + src * 256)[lane];
+        if (lane == 0) kv = reinterpret_cast<const float2*>(side ? k1n : k0n)[src];
+    }
+    reinterpret_cast<float4*>(x + row * 256)[lane] = v;
+    if (lane == 0) reinterpret_cast<float2*>(kn)[row] = kv;
+}
+
 int lg_stage(rfe_ctx* c, LgBuffers& b, const float* k0n, const float* k1n, const float* d0, const float* d1,
              const int32_t* m, const int32_t* n, int P, int Mmax, int Nmax, int L) {
-    hipStream_t s = c->stream;
-    const size_t rows = (size_t)2 * P * L;
-    if (Mmax != L || Nmax != L) {
-        RFE_HIP(c, hipMemsetAsync(b.x, 0, rows * 256 * 4, s));
-        RFE_HIP(c, hipMemsetAsync(b.kn, 0, rows * 2 * 4, s));
-    }
-    RFE_HIP(c, hipMemcpy2DAsync(b.x, (size_t)L * 1024, d0, (size_t)Mmax * 1024, (size_t)Mmax * 1024, P, hipMemcpyDeviceToDevice, s));
-    RFE_HIP(c, hipMemcpy2DAsync(b.x + (size_t)P * L * 256, (size_t)L * 1024, d1, (size_t)Nmax * 1024, (size_t)Nmax * 1024, P, hipMemcpyDeviceToDevice, s));
-    RFE_HIP(c, hipMemcpy2DAsync(b.kn, (size_t)L * 8, k0n, (size_t)Mmax * 8, (size_t)Mmax * 8, P, hipMemcpyDeviceToDevice, s));
-    RFE_HIP(c, hipMemcpy2DAsync(b.kn + (size_t)P * L * 2, (size_t)L * 8, k1n, (size_t)Nmax * 8, (size_t)Nmax * 8, P, hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(lg_setup_kernel, dim3((2 * P + 255) / 256), dim3(256), 0, s, m, n, P, Mmax, Nmax, b.lens, b.kvmap);
+    const int64_t rows = (int64_t)2 * P * L;
+    hipLaunchKernelGGL(lg_stage_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c->stream, k0n, k1n, d0, d1, m, n, P, Mmax, Nmax, L,
+                       b.x, b.kn, b.lens, b.kvmap);
     return RFE_OK;
 }
 
@@ -828,16 +851,18 @@ extern "C" int rfe_extract_match_stream_dev(rfe_ctx* c, const uint8_t* img, int 
     }
     // Every interior frame is side 1 of pair i-1 and side 0 of pair i, and layer 0's self block depends on
     // the frame alone: run it (and the positional encoding) once per FRAME, then scatter into the pair layout.
-    float* xf = b.md;                        // [B, L, 256]: md ([2P, L, 256], B <= 2P) is only used by the assignment at the end
-    float* csnf = (float*)(b.extra + kn_bytes);             // [B*L, 32, 2], own scratch (the similarity buffer [P, L, L] is too small
-                                                            //  for it when L < 64 (P+1)/P)
+    // B = 2 (one pair): the per-frame layout IS the pair layout, the block runs in place and nothing is scattered
+    float* xf = P == 1 ? b.x : b.md;         // [B, L, 256]: md ([2P, L, 256], B <= 2P) is only used by the assignment at the end
+    float* csnf = P == 1 ? b.csn : (float*)(b.extra + kn_bytes);   // [B*L, 32, 2], own scratch (the similarity buffer [P, L, L] is too small
+                                                                   //  for it when L < 64 (P+1)/P)
     { ProfScope p(c, "lg_misc");
       launch_normalize_kpts(s, kxy, (int64_t)B * Kmax, H, W, kn_all);
       launch_lg_posenc(s, kn_all, c->lg.wr, B * L, csnf);
       launch_copy_f32(s, desc, xf, (int64_t)B * L * 256);
       hipLaunchKernelGGL(lg_setup_kernel, dim3((2 * P + 255) / 256), dim3(256), 0, s, n, n + 1, P, Kmax, Kmax, b.lens, b.kvmap); }
     lg_self_block(c, b, c->lg.L[0], xf, csnf, n, B, L);
-    { ProfScope p(c, "lg_misc");
+    if (P > 1) {
+      ProfScope p(c, "lg_misc");
       const size_t half = (size_t)P * L;
       launch_copy_f32(s, xf, b.x, (int64_t)half * 256);
       launch_copy_f32(s, xf + (size_t)L * 256, b.x + half * 256, (int64_t)half * 256);
@@ -903,6 +928,16 @@ extern "C" int rfe_stereo_match(rfe_ctx* c, const uint8_t* imgL, const uint8_t* 
 // =====================================================================================
 __global__ void st_zero_count_kernel(int32_t* S) { S[0] = 0; }
 
+// this left view becomes the previous one: normalised keypoints, descriptors and count in one launch
+__global__ __launch_bounds__(256) void st_save_kernel(const float* __restrict__ kn, const float* __restrict__ desc, const int32_t* __restrict__ n,
+                                                      int Kmax, float* __restrict__ kn_prev, float* __restrict__ desc_prev, int32_t* __restrict__ n_prev) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row == 0 && lane == 0) n_prev[0] = n[0];
+    if (row >= Kmax) return;
+    reinterpret_cast<float4*>(desc_prev + (size_t)row * 256)[lane] = reinterpret_cast<const float4*>(desc + (size_t)row * 256)[lane];
+    if (lane == 0) reinterpret_cast<float2*>(kn_prev)[row] = reinterpret_cast<const float2*>(kn)[row];
+}
+
 extern "C" int rfe_stereo_frame_dev(rfe_ctx* c, const uint8_t* imgL, const uint8_t* imgR, int H, int W, int stride, int Kmax,
                                     float thr, float filter_thr, float mb, float mbf, int reset, int32_t* n, int32_t* kxy,
                                     float* score, float* desc, float* uRight, float* depth, int32_t* S, int32_t* pairs,
@@ -950,9 +985,7 @@ extern "C" int rfe_stereo_frame_dev(rfe_ctx* c, const uint8_t* imgL, const uint8
         hipLaunchKernelGGL(st_zero_count_kernel, dim3(1), dim3(1), 0, s, S);
     }
     { ProfScope ps(c, "lg_misc");   // this left view becomes the previous one
-      RFE_HIP(c, hipMemcpyAsync(kn_prev, kn_cur, (size_t)Kmax * 8, hipMemcpyDeviceToDevice, s));
-      RFE_HIP(c, hipMemcpyAsync(desc_prev, desc, (size_t)Kmax * 1024, hipMemcpyDeviceToDevice, s));
-      RFE_HIP(c, hipMemcpyAsync(n_prev, n, 4, hipMemcpyDeviceToDevice, s)); }
+      hipLaunchKernelGGL(st_save_kernel, dim3((Kmax + 3) / 4), dim3(256), 0, s, kn_cur, desc, n, Kmax, kn_prev, desc_prev, n_prev); }
     c->st_have_prev = true;
     RFE_HIP(c, hipGetLastError());
     return RFE_OK;
