@@ -31,6 +31,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the host driver of this pool only supports dmabuf IPC; RCCL between processes fails without it (hipIpcGetMemHandle: invalid
+# argument).  Exported by the image already -- set here too so that a torchrun launch from a clean environment works.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 H, W, KMAX = 480, 640, 1024
 FRAMES_PER_GPU = 32
