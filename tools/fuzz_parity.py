@@ -28,6 +28,8 @@ def main(seconds=60.0, seed=0):
         if kind == 0:                                             # ---- SuperPoint
             big = rng.random() < 0.08
             H, W = (480, int(rng.choice([640, 752]))) if big else (8 * int(rng.integers(6, 33)), 8 * int(rng.integers(6, 41)))
+            if not big and rng.random() < 0.4:          # any size >= 8 goes (floor pooling): not a multiple of 8 / 4 / 2
+                H, W = H + int(rng.integers(0, 8)), W + int(rng.integers(0, 8))
             B, K = int(rng.integers(1, 6)), int(rng.choice([1, 7, 64, 100, 333, 512, 1024, 4096]))
             w = wsp if rng.random() < 0.6 else wsp2
             c.set_weights(capi.KIND_SUPERPOINT, w)
@@ -75,7 +77,7 @@ def main(seconds=60.0, seed=0):
                 ok &= good
             tag = f"lg P={P} Mmax={Mmax} Nmax={Nmax} m={ms_} n={ns_}"
         elif kind == 3:                                           # ---- sparse stereo matching on extracted features
-            H, W = 8 * int(rng.integers(12, 40)), 8 * int(rng.integers(16, 60))
+            H, W = 8 * int(rng.integers(12, 40)) + int(rng.integers(0, 8)) * int(rng.random() < 0.4), 8 * int(rng.integers(16, 60)) + int(rng.integers(0, 8)) * int(rng.random() < 0.4)
             disp = int(rng.integers(0, 30))
             scene = synth.make_scene(rng, H, W + disp, margin=0)
             left = np.ascontiguousarray(np.clip(scene[:, :W] + rng.integers(0, 8, (H, W)), 0, 255).astype(np.uint8))
@@ -105,7 +107,7 @@ def main(seconds=60.0, seed=0):
             tag = f"search Nq={Nq} Nf={Nf} / distinctive Np={len(plens)}"
         else:                                                     # ---- stream mode vs extract + oracle matches
             big = rng.random() < 0.08
-            H, W = (480, 640) if big else (8 * int(rng.integers(10, 31)), 8 * int(rng.integers(10, 41)))
+            H, W = (480, 640) if big else (8 * int(rng.integers(10, 31)) + int(rng.integers(0, 8)) * int(rng.random() < 0.4), 8 * int(rng.integers(10, 41)) + int(rng.integers(0, 8)) * int(rng.random() < 0.4))
             B, K = int(rng.integers(2, 8)), int(rng.choice([32, 48, 100, 128, 256, 300, 512, 1024] if big else [1, 5, 32, 33, 48, 100, 101, 128, 256, 300, 512]))
             c.set_weights(capi.KIND_SUPERPOINT, wsp)
             frames, _ = synth.make_frames(B, H, W, seed=int(rng.integers(1 << 30)))
