@@ -426,8 +426,18 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     rccl = None
-    if world > 1:
+    # RFE_BENCH_FORCE_PG=1: build the process group and run every collective of the N-rank flow even at world size 1 -- the
+    # RCCL code path (init with device_id, all_gather_object, device all-reduce, the per-step gather) on a 1-GPU box
+    pg = world > 1 or os.environ.get("RFE_BENCH_FORCE_PG") == "1"
+    if pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        # RCCL prints a version banner through C stdio on stdout when the communicator comes up; stdout belongs to the ONE JSON
+        # line, so fd 1 points at stderr until the group exists and the C buffers are flushed
+        import ctypes
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -440,6 +450,10 @@ def main():
         dist.all_reduce(ones)
         rccl = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "allreduce_sum_of_ones": int(ones.item()),
                 "devices": ident, "distinct_devices": len({(d.get("pci_bus_id"), d.get("uuid"), d["device_index"]) for d in ident})}
+        torch.cuda.synchronize(dev)
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
         if rccl["allreduce_sum_of_ones"] != world:
             print(f"bench.py: all-reduce over the process group saw {rccl['allreduce_sum_of_ones']} ranks, expected {world}", file=sys.stderr)
             sys.exit(3)
@@ -474,7 +488,7 @@ def main():
     frames = torch.from_numpy(frames_np).to(dev)
     pack = sharding.ResultPack(B, KMAX, dev)    # every output of the step in one contiguous buffer; the gather moves its prefix
     n, kxy, score, desc, S, pairs, ms = pack.n, pack.kxy, pack.score, pack.desc, pack.S, pack.pairs, pack.ms
-    gather = sharding.RootGather(pack, world, rank, with_desc=args.gather_desc) if world > 1 else None
+    gather = sharding.RootGather(pack, world, rank, with_desc=args.gather_desc, always_collective=pg) if pg else None
 
     def step():
         if args.workload == "c2":
@@ -488,7 +502,7 @@ def main():
             gather()
 
     def fence():
-        if world > 1:
+        if pg:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -527,7 +541,7 @@ def main():
         ctx.profile_filter(None)
     prof = prof_full
     per_rank_ms = [dt / max(args.steps, 1) * 1e3]
-    if world > 1:
+    if pg:
         tall = torch.zeros(world, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         tall[rank] = dt
         dist.all_reduce(tall)                      # every rank's own clock around the same barrier-bracketed region
@@ -572,7 +586,7 @@ def main():
         wall = time.perf_counter() - t0
         per = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(args.sustained_steps)], np.float64)
         wmax = wall
-        if world > 1:
+        if pg:
             tw = torch.tensor([wall], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(tw, op=dist.ReduceOp.MAX)
             wmax = float(tw.item())
@@ -629,7 +643,7 @@ def main():
                                        f"({int((h_ != t_.cpu()).sum())} elements)")
 
     gathered_ok = None
-    if world > 1 and rank == 0:   # the gathered payload of the last step really holds every rank's results
+    if pg and rank == 0:   # the gathered payload of the last step really holds every rank's results
         gn = sharding.assemble(gather, shard.owned)[0]
         gathered_ok = bool(gn.numel() == world * shard.owned + 1 and torch.equal(gather.rank_view(0, "n").cpu(), n.cpu()) and int((gn > 0).sum()) == gn.numel())
 
@@ -690,9 +704,14 @@ def main():
             if ref is not None:
                 out["cpu_baseline_port"] = out["cpu_baseline"]
                 out["cpu_baseline"] = ref
-        print(json.dumps(out))
+        try:        # anything a native library still holds in C stdio goes out BEFORE the JSON line
+            import ctypes as _ct
+            _ct.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if pg:
         dist.barrier()
         dist.destroy_process_group()
 

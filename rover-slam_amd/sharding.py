@@ -79,12 +79,13 @@ class ResultPack:
 class RootGather:
     """ONE dist.gather per step into a receive buffer allocated once on rank 0."""
 
-    def __init__(self, pack: ResultPack, world: int, rank: int, with_desc=False):
+    def __init__(self, pack: ResultPack, world: int, rank: int, with_desc=False, always_collective=False):
         self.pack, self.world, self.rank, self.with_desc = pack, world, rank, with_desc
+        self.always_collective = always_collective     # world size 1: still go through dist.gather (RCCL path check on one GPU)
         self.nbytes = pack.total_bytes if with_desc else pack.compact_bytes
         # gloo has no device-memory gather: the functional check of the N-rank flow on a 1-GPU box stages through
         # (pinned) host memory; RCCL ("nccl") gathers device to device
-        self.via_host = (pack.buf.device.type == "cuda" and world > 1 and dist.is_initialized() and dist.get_backend() != "nccl")
+        self.via_host = (pack.buf.device.type == "cuda" and (world > 1 or always_collective) and dist.is_initialized() and dist.get_backend() != "nccl")
         rdev = torch.device("cpu") if self.via_host else pack.buf.device
         self.stage = torch.empty(self.nbytes, dtype=torch.uint8).pin_memory() if self.via_host else None
         self.recv = torch.empty((world, self.nbytes), dtype=torch.uint8, device=rdev) if rank == 0 else None
@@ -92,7 +93,7 @@ class RootGather:
 
     def __call__(self):
         src = self.pack.payload(self.with_desc)
-        if self.world == 1:
+        if self.world == 1 and not self.always_collective:
             if self.recv is not None:
                 self.recv[0].copy_(src)
             return self.recv

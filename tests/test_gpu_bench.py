@@ -43,3 +43,13 @@ def test_bench_gpus2_over_gloo_on_one_gpu():
     assert d["gather"]["collectives_per_step"] == 1 and d["gather"]["last_step_payload_verified"] is True
     assert len(d["per_rank_ms_per_step"]["all"]) == 2
     assert abs(d["value"] - 2 * 32 * 1e3 / d["ms_per_step"]) / d["value"] < 1e-3      # whole-job frames over the max-over-ranks time
+
+
+def test_bench_rccl_code_path_at_world_size_one():
+    """RCCL needs one GPU per rank, so the N-rank run belongs to the driver's 8-GPU box; what CAN run here is the same code path
+    at world size 1 (RFE_BENCH_FORCE_PG=1): process group on the "nccl" backend bound to the device, object all-gather, device
+    all-reduce, barrier-bracketed timing and the per-step dist.gather of the packed results into the preallocated buffer."""
+    d = _bench("--steps", "2", "--warmup", "1", "--sustained-steps", "4", "--no-cpu-baseline", "--no-pcie", env={"RFE_BENCH_FORCE_PG": "1"})
+    assert d["n_gpus"] == 1 and d["rccl"]["backend"] == "nccl" and d["rccl"]["world_size"] == 1 and d["rccl"]["allreduce_sum_of_ones"] == 1
+    assert d["gather"]["collectives_per_step"] == 1 and d["gather"]["last_step_payload_verified"] is True
+    assert abs(d["value"] - 32 * 1e3 / d["ms_per_step"]) / d["value"] < 1e-3
