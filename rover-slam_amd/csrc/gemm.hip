@@ -143,10 +143,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
             ra[it] = make_float4(ln_elem(ra[it].x, it, rg.x, rbeta.x), ln_elem(ra[it].y, it, rg.y, rbeta.y),
                                  ln_elem(ra[it].z, it, rg.z, rbeta.z), ln_elem(ra[it].w, it, rg.w, rbeta.w));
     };
+#ifdef RFE_TUNING
+    const int abl = g.abl;
+#else
+    constexpr int abl = 0;
+#endif
     if (PF) load_tile(0);
     if (LNI) ln_tile();   // first tile: nothing to hide it under
     for (int k0 = 0; k0 < g.K; k0 += BK) {
         if (!PF) load_tile(k0);
+        if (!(abl & 2) || k0 == 0) {
         __syncthreads();   // previous tile fully consumed
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
@@ -166,7 +172,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) { float* d = db + it * 32 * LDT; d[0] = rb[it].x; d[1] = rb[it].y; d[2] = rb[it].z; d[3] = rb[it].w; }
         __syncthreads();
-        if (PF && k0 + BK < g.K) load_tile(k0 + BK);
+        }
+        if (PF && k0 + BK < g.K && !(abl & 1)) load_tile(k0 + BK);
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
             float a[MB], b[NB];
@@ -219,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
                 for (int rr = 0; rr < 4; ++rr) {
                     const int r = rq * 4 + rr;
                     const int m = m0 + (wm * MB + mb) * 32 + rr + 8 * rq + 4 * h;
-                    if (m >= M) continue;
+                    if (m >= M || ((abl & 4) && m != 0)) continue;
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
                         const int n = n0 + (wn * NB + nb) * 32 + i;
@@ -280,6 +287,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 
 int launch_gemm_nt(hipStream_t s, const GemmArgs& g_in) {
     GemmArgs g = g_in;
+#ifdef RFE_TUNING
+    g.abl = tune_int("RFE_DBG_GEMM_ABL", 0);
+#endif
     const int batch = g.batch > 0 ? g.batch : 1;
     auto tiles = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * batch; };
     const bool res = g.R != nullptr, lna = g.stats_in != nullptr;
