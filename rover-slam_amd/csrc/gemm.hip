@@ -38,12 +38,19 @@ __device__ __forceinline__ float gelu_short(float t) {
 // alpha like the oracle.  (Round 1's LDS-transposed whole-row epilogue, which also applied the LightGlue rotary to q | k, is gone:
 // the rotary moved into the attention kernel's loads -- same arithmetic, same time overall, one epilogue fewer here.)
 // PFT: register prefetch of the next K tile under the MFMAs (always on for the 64-row latency tiles).
-template <int MB, int NB, bool RES, bool PFT = false, bool LNA = false>
+// KP (k-permuted, opt-in through GemmArgs::kperm): LDS tiles [rows][32] WITHOUT padding, the eight 16-byte slots of a row XOR-swizzled
+// by (row & 7): staging writes one ds_write_b128 per loaded float4 (the padded layout needs four scalar writes), a fragment read is
+// one ds_read_b128 per four k-steps (lane half h reads k = 16 h + 4 g .. + 3 of its row; eight consecutive lanes = eight rows hit the
+// eight different slots -> all 32 banks).  MFMA step (g, c) therefore multiplies k = 4 g + c and k = 16 + 4 g + c: every product
+// of the K tile is summed, in a different order than k ascending -- LightGlue only (SuperPoint's 1x1 heads stay bit-exact on the
+// padded path).  LDS instructions per K tile and wave: 36 instead of 144.
+template <int MB, int NB, bool RES, bool PFT = false, bool LNA = false, bool KP = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     constexpr int BM = MB * 64, BN = NB * 64;
-    __shared__ float lds_ab[(BM + BN) * LDT];   // A tile | B tile
+    constexpr int LDR = KP ? BK : LDT;          // LDS row stride in words
+    __shared__ __attribute__((aligned(16))) float lds_ab[(BM + BN) * LDR];   // A tile | B tile
     float* const As = lds_ab;
-    float* const Bs = lds_ab + BM * LDT;
+    float* const Bs = lds_ab + BM * LDR;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -108,10 +115,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
             ln_mean[it] = mean; ln_rstd[it] = 1.0f / sqrtf(var + 1e-5f);
         }
     }
-    float* const da = As + lrow * LDT + lkq * 4;
-    float* const db = Bs + lrow * LDT + lkq * 4;
-    const float* const ap = As + (wm * MB * 32 + i) * LDT + h;
-    const float* const bp = Bs + (wn * NB * 32 + i) * LDT + h;
+    float* const da = KP ? As + lrow * LDR + ((lkq ^ (lrow & 7)) << 2) : As + lrow * LDR + lkq * 4;   // rows lrow + 32 it: same (row & 7)
+    float* const db = KP ? Bs + lrow * LDR + ((lkq ^ (lrow & 7)) << 2) : Bs + lrow * LDR + lkq * 4;
+    const float* const ap = KP ? As + (wm * MB * 32 + i) * LDR : As + (wm * MB * 32 + i) * LDR + h;
+    const float* const bp = KP ? Bs + (wn * NB * 32 + i) * LDR : Bs + (wn * NB * 32 + i) * LDR + h;
 
     // Small (64-row) tiles serve latency-bound problems (one pair: M = 2048, one workgroup per CU), where every K step
     // would otherwise expose a full global-memory round trip: there the next tile's loads are issued before the MFMA
@@ -167,39 +174,86 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
                 }
                 v = make_float4(e[0], e[1], e[2], e[3]);
             }
-            float* d = da + it * 32 * LDT; d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            float* d = da + it * 32 * LDR;
+            if (KP) *reinterpret_cast<f32x4*>(d) = f32x4{v.x, v.y, v.z, v.w};
+            else { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
         }
 #pragma unroll
-        for (int it = 0; it < B_IT; ++it) { float* d = db + it * 32 * LDT; d[0] = rb[it].x; d[1] = rb[it].y; d[2] = rb[it].z; d[3] = rb[it].w; }
+        for (int it = 0; it < B_IT; ++it) {
+            float* d = db + it * 32 * LDR;
+            if (KP) *reinterpret_cast<f32x4*>(d) = f32x4{rb[it].x, rb[it].y, rb[it].z, rb[it].w};
+            else { d[0] = rb[it].x; d[1] = rb[it].y; d[2] = rb[it].z; d[3] = rb[it].w; }
+        }
         __syncthreads();
         }
         if (PF && k0 + BK < g.K && !(abl & 1)) load_tile(k0 + BK);
+        // LNI: the tile prefetched before this loop has landed by now (>= 64 MFMAs = 4096 cycles after its loads were issued):
+        // its LayerNorm + GELU -- VALU work, 2 of the 16 elements of this thread per k-step -- runs in the shadow of the
+        // MFMAs of the remaining k-steps instead of on the staging path in front of the barrier
+#define RFE_LN_SHADOW(S_)                                                                             \
+        if (LNI && (S_) >= BK / 4) {                                                                  \
+            constexpr int per = (A_IT * 4) / (BK / 4);                                                \
+            _Pragma("unroll") for (int u = 0; u < per; ++u) {                                         \
+                const int e = ((S_) - BK / 4) * per + u, it = e >> 2, q = e & 3;                      \
+                float* comp = q == 0 ? &ra[it].x : q == 1 ? &ra[it].y : q == 2 ? &ra[it].z : &ra[it].w; \
+                const float gq = q == 0 ? rg.x : q == 1 ? rg.y : q == 2 ? rg.z : rg.w;                \
+                const float bq = q == 0 ? rbeta.x : q == 1 ? rbeta.y : q == 2 ? rbeta.z : rbeta.w;    \
+                *comp = ln_elem(*comp, it, gq, bq);                                                   \
+            }                                                                                         \
+        }
+        if (KP) {
+            // fragments of group g+1 are requested while group g multiplies: the A fragments into a second register set, each B
+            // fragment back into its own registers as soon as its last MFMA of this group has been issued (+8 VGPRs, no LDS
+            // round trip exposed at the group boundaries)
+            const int iswz = i & 7;
+            f32x4 a4[MB], b4[NB];
+            {
+                const int slot = ((h << 2) ^ iswz) << 2;
 #pragma unroll
-        for (int s = 0; s < BK / 2; ++s) {
-            float a[MB], b[NB];
+                for (int mb = 0; mb < MB; ++mb) a4[mb] = *reinterpret_cast<const f32x4*>(ap + mb * 32 * LDR + slot);
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) a[mb] = ap[mb * 32 * LDT + 2 * s];
+                for (int nb = 0; nb < NB; ++nb) b4[nb] = *reinterpret_cast<const f32x4*>(bp + nb * 32 * LDR + slot);
+            }
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) b[nb] = bp[nb * 32 * LDT + 2 * s];
+            for (int gq4 = 0; gq4 < 4; ++gq4) {
+                const int nslot = (((h << 2) + gq4 + 1) ^ iswz) << 2;
+                f32x4 an[MB];
+                if (gq4 < 3) {
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
+                    for (int mb = 0; mb < MB; ++mb) an[mb] = *reinterpret_cast<const f32x4*>(ap + mb * 32 * LDR + nslot);
+                    __builtin_amdgcn_sched_barrier(0);   // keep the requests up here (the scheduler would sink them to their first use)
+                }
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
-            if (LNI && s >= BK / 4) {
-                // the tile prefetched before this loop has landed by now (>= 64 MFMAs = 4096 cycles after its loads were issued):
-                // its LayerNorm + GELU -- VALU work, 2 of the 16 elements of this thread per k-step -- runs in the shadow of the
-                // MFMAs of the remaining k-steps instead of on the staging path in front of the barrier
-                constexpr int per = (A_IT * 4) / (BK / 4);
+                for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
-                for (int u = 0; u < per; ++u) {
-                    const int e = (s - BK / 4) * per + u, it = e >> 2, q = e & 3;
-                    float* comp = q == 0 ? &ra[it].x : q == 1 ? &ra[it].y : q == 2 ? &ra[it].z : &ra[it].w;
-                    const float gq = q == 0 ? rg.x : q == 1 ? rg.y : q == 2 ? rg.z : rg.w;
-                    const float bq = q == 0 ? rbeta.x : q == 1 ? rbeta.y : q == 2 ? rbeta.z : rbeta.w;
-                    *comp = ln_elem(*comp, it, gq, bq);
+                    for (int cq = 0; cq < 4; ++cq)
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb)
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[mb][cq], b4[nb][cq], acc[mb][nb], 0, 0, 0);
+                    if (gq4 < 3) { b4[nb] = *reinterpret_cast<const f32x4*>(bp + nb * 32 * LDR + nslot); __builtin_amdgcn_sched_barrier(0); }
+                    RFE_LN_SHADOW(gq4 * 4 + nb)
+                }
+                if (gq4 < 3) {
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) a4[mb] = an[mb];
                 }
             }
+        } else {
+#pragma unroll
+            for (int s = 0; s < BK / 2; ++s) {
+                float a[MB], b[NB];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) a[mb] = ap[mb * 32 * LDR + 2 * s];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) b[nb] = bp[nb * 32 * LDR + 2 * s];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
+                RFE_LN_SHADOW(s)
+            }
         }
+#undef RFE_LN_SHADOW
     }
 
     {   // bias (+alpha, +ReLU, +residual) epilogue: 128-B coalesced accesses straight from the D layout
@@ -295,9 +349,15 @@ int launch_gemm_nt(hipStream_t s, const GemmArgs& g_in) {
     const bool res = g.R != nullptr, lna = g.stats_in != nullptr;
     static const bool lni = tune_int("RFE_LN_INTERLEAVE", 1) != 0;   // tuning switch
 
+    static const bool kp_on = tune_int("RFE_GEMM_KP", 1) != 0;   // tuning switch: 0 = padded layout / k-ascending order everywhere
+    const bool kp = kp_on && g.kperm != 0;
     static const bool pft = tune_int("RFE_GEMM_PF", 1) != 0;   // register prefetch of the next K tile also on the 128-row tiles (+1 % on ffn1 / ffn2, profiles/r02_pmc.md); RFE_GEMM_PF=0 (tuning build) disables
 #define RFE_GEMM_GO(MB_, NB_, GRID)                                                                  \
     do {                                                                                             \
+        if (kp && MB_ == 2 && pft && !lna) {                                                         \
+            if (res) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, true, MB_ == 2, false, MB_ == 2>), GRID, dim3(256), 0, s, g); \
+            else hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, false, MB_ == 2, false, MB_ == 2>), GRID, dim3(256), 0, s, g);         \
+        } else                                                                                       \
         if (lna && lni && MB_ == 2) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, true, MB_ == 2, true>), GRID, dim3(256), 0, s, g);   /* LN + GELU on A under the MFMAs */ \
         else if (lna) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, true, false, true>), GRID, dim3(256), 0, s, g);   /* LN + GELU on A at staging */ \
         else if (pft && MB_ == 2 && res) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, true, MB_ == 2>), GRID, dim3(256), 0, s, g);    \

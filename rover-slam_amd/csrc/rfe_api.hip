@@ -450,6 +450,13 @@ GemmArgs gemm_plain(const float* A, int lda, const float* Bw, int ldb, const flo
     return g;
 }
 
+// LightGlue Linears: tolerance-checked, free to use the k-permuted GEMM path (GemmArgs::kperm)
+GemmArgs gemm_lg(const float* A, int lda, const float* Bw, int ldb, const float* bias, float* C, int ldc, int M, int N, int K) {
+    GemmArgs g = gemm_plain(A, lda, Bw, ldb, bias, C, ldc, M, N, K);
+    g.kperm = 1;
+    return g;
+}
+
 int sp_check(rfe_ctx* c, int H, int W, int B, int Kmax) {
     if (!c) return RFE_ERR_INVALID;
     if (!c->has_sp) return fail(c, RFE_ERR_NO_WEIGHTS, "SuperPoint weights not loaded (rfe_load_weights / rfe_set_weights)");
@@ -625,13 +632,13 @@ void lg_ffn(rfe_ctx* c, LgBuffers& b, float* x, const float* second, int rows, c
     static const bool ln_fuse = tune_int("RFE_LN_FUSE", 1) != 0;
     int P = 0;
     { ProfScope p(c, "lg_ffn1");   // A = [x | second]: second is the message, or the attention context when Wo is folded into W1
-      GemmArgs a = gemm_plain(x, 256, w1, 512, b1, b.h, 512, rows, 512, 512);
+      GemmArgs a = gemm_lg(x, 256, w1, 512, b1, b.h, 512, rows, 512, 512);
       a.A2 = second; a.lda2 = 256; a.K1 = 256;
       if (ln_fuse) a.stats_out = b.lnstat;
       P = launch_gemm_nt(s, a); }
     if (P == 0) { ProfScope p(c, "lg_ln_gelu"); launch_lg_ln_gelu(s, b.h, g, be, rows); }   // small problems (and RFE_LN_FUSE=0): stand-alone pass
     { ProfScope p(c, "lg_ffn2");
-      GemmArgs a = gemm_plain(b.h, 512, w2, 512, b2, x, 256, rows, 256, 512);
+      GemmArgs a = gemm_lg(b.h, 512, w2, 512, b2, x, 256, rows, 256, 512);
       a.R = x; a.ldr = 256;
       if (P > 0) { a.stats_in = b.lnstat; a.stats_p = P; a.ln_g = g; a.ln_b = be; }
       launch_gemm_nt(s, a); }
@@ -642,13 +649,13 @@ void lg_self_block(rfe_ctx* c, LgBuffers& b, const LgLayerDev& Lw, float* x, con
     hipStream_t s = c->stream;
     const int rows = nseq * L;
     // q,k,v = Wqkv x + b (plain epilogue); the rotary of q and k is applied by the attention kernel as it loads them
-    { ProfScope p(c, "lg_qkv"); launch_gemm_nt(s, gemm_plain(x, 256, Lw.wqkv, 256, Lw.bqkv, b.qkv, 768, rows, 768, 256)); }
+    { ProfScope p(c, "lg_qkv"); launch_gemm_nt(s, gemm_lg(x, 256, Lw.wqkv, 256, Lw.bqkv, b.qkv, 768, rows, 768, 256)); }
     { ProfScope p(c, "lg_attention");
       launch_lg_attention(s, b.qkv, b.qkv + 256, b.qkv + 512, 768, b.ctx, nseq, L, L, lens, lens, nullptr, lg_part(b, nseq, L), csn); }
     if (c->opt_lg_fold) {
         lg_ffn(c, b, x, b.ctx, rows, Lw.w1f, Lw.b1f, Lw.lng, Lw.lnb, Lw.w2, Lw.b2);
     } else {
-        { ProfScope p(c, "lg_proj"); launch_gemm_nt(s, gemm_plain(b.ctx, 256, Lw.wo, 256, Lw.bo, b.msg, 256, rows, 256, 256)); }
+        { ProfScope p(c, "lg_proj"); launch_gemm_nt(s, gemm_lg(b.ctx, 256, Lw.wo, 256, Lw.bo, b.msg, 256, rows, 256, 256)); }
         lg_ffn(c, b, x, b.msg, rows, Lw.w1, Lw.b1, Lw.lng, Lw.lnb, Lw.w2, Lw.b2);
     }
 }
@@ -666,22 +673,22 @@ int lg_forward(rfe_ctx* c, LgBuffers& b, int P, int L, float thr, int cap, int32
         const LgLayerDev& Lw = W.L[l];
         if (l > 0 || !first_self_done) lg_self_block(c, b, Lw, b.x, b.csn, b.lens, nseq, L);
         // ---- cross block
-        { ProfScope p(c, "lg_cross_qkv"); launch_gemm_nt(s, gemm_plain(b.x, 256, Lw.cwqkv, 256, Lw.cbqkv, b.qkv, 512, rows, 512, 256)); }
+        { ProfScope p(c, "lg_cross_qkv"); launch_gemm_nt(s, gemm_lg(b.x, 256, Lw.cwqkv, 256, Lw.cbqkv, b.qkv, 512, rows, 512, 256)); }
         { ProfScope p(c, "lg_attention"); launch_lg_attention(s, b.qkv, b.qkv, b.qkv + 256, 512, b.ctx, nseq, L, L, b.lens, b.lens, b.kvmap, lg_part(b, nseq, L)); }
         if (c->opt_lg_fold) {
             lg_ffn(c, b, b.x, b.ctx, rows, Lw.cw1f, Lw.cb1f, Lw.clng, Lw.clnb, Lw.cw2, Lw.cb2);
         } else {
-            { ProfScope p(c, "lg_proj"); launch_gemm_nt(s, gemm_plain(b.ctx, 256, Lw.cwo, 256, Lw.cbo, b.msg, 256, rows, 256, 256)); }
+            { ProfScope p(c, "lg_proj"); launch_gemm_nt(s, gemm_lg(b.ctx, 256, Lw.cwo, 256, Lw.cbo, b.msg, 256, rows, 256, 256)); }
             lg_ffn(c, b, b.x, b.msg, rows, Lw.cw1, Lw.cb1, Lw.clng, Lw.clnb, Lw.cw2, Lw.cb2);
         }
     }
     // ---- assignment
     { ProfScope p(c, "lg_proj");
-      GemmArgs a = gemm_plain(b.x, 256, W.wp, 256, W.bp, b.md, 256, rows, 256, 256);
+      GemmArgs a = gemm_lg(b.x, 256, W.wp, 256, W.bp, b.md, 256, rows, 256, 256);
       a.alpha = 0.25f;  // / 256^(1/4)
       launch_gemm_nt(s, a); }
     { ProfScope p(c, "lg_sim");
-      GemmArgs g = gemm_plain(b.md, 256, b.md + (size_t)P * L * 256, 256, nullptr, b.sim, L, L, L, 256);
+      GemmArgs g = gemm_lg(b.md, 256, b.md + (size_t)P * L * 256, 256, nullptr, b.sim, L, L, L, 256);
       g.batch = P; g.sA = (long long)L * 256; g.sB = (long long)L * 256; g.sC = (long long)L * L;
       g.m_valid = b.lens;
       launch_gemm_nt(s, g); }

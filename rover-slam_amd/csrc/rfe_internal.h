@@ -82,6 +82,9 @@ struct GemmArgs {
     // launch_gemm_nt --, the consumer normalises its A operand while staging it: gelu(((a - mean) * rstd) * ln_g[k] + ln_b[k])
     float* stats_out;
     const float* stats_in; int stats_p; const float* ln_g; const float* ln_b;
+    // kperm != 0: the caller does not need the k-ascending reduction order (LightGlue: tolerance-checked, not bit-exact).  The 128-row
+    // tiles then use the 16-byte-swizzled LDS layout with 128-bit fragment reads, which consume k in the order (s, 16 + s) per K tile.
+    int kperm;
 #ifdef RFE_TUNING
     int abl;   // timing ablations (wrong results): 1 = global loads of the first K tile only, 2 = LDS stores / barriers of the first K tile only, 4 = no epilogue stores
 #endif
