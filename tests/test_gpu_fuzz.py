@@ -1,6 +1,7 @@
 """GPU: a short run of the randomised shape sweep (tools/fuzz_parity.py): random image sizes, batches, keypoint budgets,
 ragged LightGlue batches and stream-mode shapes against the oracle.  SuperPoint bit-exact, match lists identical
-(flips are tolerated only for matches within 2e-4 of the 0.1 filter or of an argmax tie), scores within 5e-4."""
+(flips are tolerated only where the stated score tolerance allows them: within tol of the 0.1 filter, or two best
+row / column probabilities closer than 2 tol -- tools/fuzz_parity.py:borderline), scores within 5e-4."""
 import importlib.util
 import os
 
