@@ -396,6 +396,116 @@ __global__ __launch_bounds__(256, 4) void conv3x3_small_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// Composite-tile variant of conv3x3_mfma_kernel for batches of feature maps that the 8 x 32 tile does not divide (the 60 x 80 grid
+// of 640 x 480 frames: 7.5 x 2.5 tiles, 22 % of the MFMAs wasted).  The frames are laid out on a VIRTUAL canvas -- two frames side by
+// side (2W columns), the pairs stacked (ceil(B/2) * H rows) -- and the canvas is cut into 8 x 32 tiles, so a tile may consist of up to
+// 2 x 2 pieces that come from different frames (rows 56-59 of one frame pair + rows 0-3 of the next, columns 64-79 of the left frame +
+// columns 0-15 of the right one).  Every piece is staged with its own zero-padded halo: the LDS tile is 12 x 36 instead of 10 x 34
+// and a lane's A offsets just start two rows / columns further in when its pixel lies in the second piece.  160 x 1020 canvas for 33
+// frames: 640 tiles, 96.7 % of the MFMA rows are real pixels.  Same per-pixel reduction order as every other variant (bit-exact).
+constexpr int CIH = TH + 4, CIW = TW + 4, CPLANE = CIH * CIW;
+template <int CIN, bool RELU, int TAG, int CK>
+__global__ __launch_bounds__(256, 2) void conv3x3_comp_kernel(
+    const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
+    float* __restrict__ out, int B, int H, int W, int COUT, int gx, int gy, int ntiles) {
+    constexpr int KCH = CK * 9;
+    __shared__ __attribute__((aligned(16))) float lds[CK * CPLANE + KCH * NT];
+    float* lds_in = lds;
+    float* lds_w = lds + CK * CPLANE;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, h = lane >> 5;
+    const ConvBlock blk = conv_decode(COUT / NT, gx, gy, ntiles);
+    if (!blk.valid) return;
+    const int ct = blk.ct, co0 = ct * NT;
+    const int x0 = blk.bx * TW, y0 = blk.by * TH;              // canvas coordinates
+    const int pair0 = y0 / H, yin = y0 % H, half0 = x0 / W, xin = x0 % W;
+    const int rb = (H - yin) < TH ? (H - yin) : TH;            // output rows [0, rb) = piece 0, [rb, 8) = piece 1 (next frame pair)
+    const int cb = (W - xin) < TW ? (W - xin) : TW;            // output columns [0, cb) = piece 0, [cb, 32) = piece 1 (right frame)
+    auto frame_of = [&](int pr, int pc) { const int hf = half0 + pc; const int f = 2 * (pair0 + pr) + hf; return (hf <= 1 && f < B) ? f : -1; };
+    if (frame_of(0, 0) < 0 && frame_of(0, 1) < 0 && frame_of(1, 0) < 0 && frame_of(1, 1) < 0) return;   // tile holds no real pixel
+
+    f32x16 acc[2][2];
+    {
+        const float b0 = bias[co0 + col], b1 = bias[co0 + 32 + col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][0][r] = b0; acc[1][0][r] = b0; acc[0][1][r] = b1; acc[1][1][r] = b1; }
+    }
+    int aoff[9];
+    {
+        const int r0 = 2 * wave;                                // rb is even (H even): rows 2w and 2w+1 lie in the same piece
+        const int base = (r0 + (r0 >= rb ? 2 : 0)) * CIW + col + (col >= cb ? 2 : 0);
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            const int k0 = 2 * s, k1 = 2 * s + 1;
+            const int o0 = (k0 / 9) * CPLANE + ((k0 % 9) / 3) * CIW + (k0 % 9) % 3;
+            const int o1 = (k1 / 9) * CPLANE + ((k1 % 9) / 3) * CIW + (k1 % 9) % 3;
+            aoff[s] = (h ? o1 : o0) + base;
+        }
+    }
+    const int boff = h * NT + col;
+    const float* wp_ct = wp + (size_t)ct * (CIN / CK) * KCH * NT;
+
+    constexpr int S_IT = (CIH * CIW * (CK / 4) + 255) / 256;
+    int s_goff[S_IT], s_loff[S_IT];   // global element offset (-1: zero padding), LDS word offset (-1: unused slot)
+#pragma unroll
+    for (int it = 0; it < S_IT; ++it) {
+        const int idx = tid + it * 256;
+        const int cq = idx % (CK / 4), pix = idx / (CK / 4);
+        const int lr = pix / CIW, lc = pix % CIW;
+        const int pr = lr >= rb + 2, hr = lr - (pr ? rb + 2 : 0), nr = pr ? TH - rb : rb;   // haloed row hr of a piece with nr rows
+        const int pc = lc >= cb + 2, hc = lc - (pc ? cb + 2 : 0), nc = pc ? TW - cb : cb;
+        const bool slot = idx < CIH * CIW * (CK / 4) && nr > 0 && nc > 0 && hr < nr + 2 && hc < nc + 2;
+        const int y = (pr ? 0 : yin) + hr - 1, x = (pc ? 0 : xin) + hc - 1;
+        const int f = frame_of(pr, pc);
+        s_loff[it] = slot ? (cq * 4) * CPLANE + lr * CIW + lc : -1;
+        s_goff[it] = (slot && f >= 0 && y >= 0 && y < H && x >= 0 && x < W) ? ((f * H + y) * W + x) * CIN + cq * 4 : -1;
+    }
+    static_assert((CIN / CK) % 2 == 0, "paired chunk fetch");
+    float4 v_odd[S_IT];
+    for (int ch = 0; ch < CIN / CK; ++ch) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < S_IT; ++it) {
+            if (s_loff[it] < 0) continue;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((ch & 1) == 0) {
+                v_odd[it] = v;
+                if (s_goff[it] >= 0) {
+                    v = *reinterpret_cast<const float4*>(in + s_goff[it] + ch * CK);
+                    v_odd[it] = *reinterpret_cast<const float4*>(in + s_goff[it] + (ch + 1) * CK);
+                }
+            } else {
+                v = v_odd[it];
+            }
+            float* d = lds_in + s_loff[it];
+            d[0] = v.x; d[CPLANE] = v.y; d[2 * CPLANE] = v.z; d[3 * CPLANE] = v.w;
+        }
+        conv_stage_weights<CK>(lds_w, wp_ct + (size_t)ch * KCH * NT, tid);
+        __syncthreads();
+        conv_chunk_mma<CK, CPLANE, CIW>(lds_in, lds_w, aoff, boff, acc);
+    }
+    // epilogue: D layout as in conv_store, every pixel mapped back to (frame, y, x)
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const int r = 2 * wave + mb, pr = r >= rb;
+        const int y = pr ? r - rb : yin + r;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int c = (q & 3) + 8 * (q >> 2) + 4 * h, pc = c >= cb;
+            const int x = pc ? c - cb : xin + c;
+            const int f = frame_of(pr, pc);
+            if (f < 0) continue;
+            float v0 = acc[mb][0][q], v1 = acc[mb][1][q];
+            if (RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+            float* o = out + (((size_t)f * H + y) * W + x) * COUT + co0 + col;
+            o[0] = v0; o[32] = v1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // conv1a + conv1b fused: the 64-channel input tile of conv1b is never read from HBM; every staged
 // 8-channel chunk is recomputed in LDS from the u8 image tile (NormalizeImage * 1/255, conv1a 1->64,
 // bias, ReLU -- same fmaf chain as conv1a_u8_kernel / the oracle, so still bit-exact), then conv1b +
@@ -512,6 +622,18 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
     // workgroups (round 2): conv4 unchanged, heads 0.85 -> 1.05 ms.
     // -> conv4a/4b take the wide tile, convPa/Da the 12x16 tile.  RFE_CONV_TALL: 0 = 8x32 everywhere, 1 = 12x16 everywhere, 2 = wide for conv4 only
     static const int tall = tune_int("RFE_CONV_TALL", -1);
+    static const int comp = tune_int("RFE_CONV_COMP", 1);   // composite tiles over the two-frames-wide canvas (0: round-2a tilings)
+    if (comp && !no_wide && ck8 && !pool && relu && cin == 128 && (tag == L_4A || tag == L_4B || tag == L_PA || tag == L_DA) && B >= 2 &&
+        H % 2 == 0 && W >= TW && H >= TH && (H % TH != 0 || W % TW != 0)) {
+        const int cx = (2 * W + TW - 1) / TW, cy = (((B + 1) / 2) * H + TH - 1) / TH;
+        const dim3 gc(conv_grid(cx, cy, 1, cout / NT));
+        switch (tag) {
+            case L_4A: hipLaunchKernelGGL((conv3x3_comp_kernel<128, true, L_4A, 8>), gc, dim3(256), 0, s, in, wp, bias, out, B, H, W, cout, cx, cy, cx * cy); return;
+            case L_4B: hipLaunchKernelGGL((conv3x3_comp_kernel<128, true, L_4B, 8>), gc, dim3(256), 0, s, in, wp, bias, out, B, H, W, cout, cx, cy, cx * cy); return;
+            case L_PA: hipLaunchKernelGGL((conv3x3_comp_kernel<128, true, L_PA, 8>), gc, dim3(256), 0, s, in, wp, bias, out, B, H, W, cout, cx, cy, cx * cy); return;
+            default: hipLaunchKernelGGL((conv3x3_comp_kernel<128, true, L_DA, 8>), gc, dim3(256), 0, s, in, wp, bias, out, B, H, W, cout, cx, cy, cx * cy); return;
+        }
+    }
     if (!no_wide && ck8 && !pool && relu && cin == 128 && (tag == L_4A || tag == L_4B || tag == L_PA || tag == L_DA)) {
         const bool heads = tag == L_PA || tag == L_DA;
         if ((tall == 1 || (tall == -1 && heads)) && W % 16 == 0 && H % 12 == 0) {

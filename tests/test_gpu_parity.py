@@ -98,7 +98,8 @@ def test_superpoint_maps_bitexact(ctx, oracle, H, W):
         d.free()
 
 
-@pytest.mark.parametrize("H,W,kmax", [(120, 160, 4096), (120, 160, 100), (64, 96, 33), (240, 320, 512), (125, 163, 4096), (93, 201, 64)])
+@pytest.mark.parametrize("H,W,kmax", [(120, 160, 4096), (120, 160, 100), (64, 96, 33), (240, 320, 512), (125, 163, 4096), (93, 201, 64),
+                                      (480, 640, 700), (256, 400, 300), (488, 304, 128)])   # 60x80 / 32x50 / 61x38 grids: composite conv tiles
 def test_extract_bitexact_vs_oracle(ctx, oracle, H, W, kmax):
     frames, _ = synth.make_frames(3, H, W, seed=kmax)
     n, kxy, score, desc = ctx.extract(frames, kmax=kmax)
