@@ -225,91 +225,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// Wide-tile variant for feature maps whose width is a multiple of 80 (the 60 x 80 grid of 640 x 480
-// frames: conv4a/4b/Pa/Da).  The 8 x 32 tile above wastes 22 % of its MFMAs there (60 = 7.5 x 8,
-// 80 = 2.5 x 32).  Here a workgroup is 5 waves covering 4 rows x 80 columns exactly: an M-block is
-// 2 rows x 16 columns, wave w owns columns 16w..16w+15 of rows 0-1 (block 0) and 2-3 (block 1).
-// Same reduction order (bit-exact), no pooling (none of these layers pools).
-// Generalised: M-blocks of 2 rows x 16 columns, NW waves of two vertically stacked blocks each, laid out column-major
-// over a TROWS x TCOLS tile.  <5, 4, 80> is the wide tile above (10 waves on 4 SIMDs at 2 workgroups/CU: 3,3,2,2 ->
-// measured only +6 %); <3, 12, 16> tiles 60 x 80 exactly with 3-wave workgroups (4 per CU = 3 waves on every SIMD).
-// WSTRIDE: LDS row stride of the staged planes in words, 0 = TCOLS + 2.  An A-fragment read touches 16 consecutive words of
-// row R (lanes 0-15) and of row R + 1 (lanes 16-31): the two runs fall on disjoint banks only when the stride is 16 mod 32
-// (48 for the 16-wide tile, 112 for the 80-wide one); stride 18 / 82 makes lanes 30-31 collide with lanes 0-1 on every read.
-// Measured (profiles/r02_ab_notes.md): the conflict-free strides cost a workgroup per CU of occupancy (39.9 KB LDS) and lose
-// more than the conflicts do (heads 0.87 -> 0.92 ms), so the product uses the unpadded stride.
-template <int CIN, bool RELU, int TAG, int CK, int NW, int TROWS, int TCOLS, int WSTRIDE = 0>
-__global__ __launch_bounds__(NW * 64, NW == 3 ? 4 : 2) void conv3x3_blk16_kernel(
-    const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
-    float* __restrict__ out, int H, int W, int COUT, int gx, int gy, int ntiles) {
-    constexpr int KCH = CK * 9, NTHR = NW * 64;
-    constexpr int WIH_ = TROWS + 2, WIW_ = TCOLS + 2, WTWS_ = WSTRIDE ? WSTRIDE : WIW_, WPLANE_ = WIH_ * WTWS_, WCOLS = TCOLS / 16;
-    static_assert(WTWS_ >= WIW_, "row stride must hold the haloed row");
-    static_assert(NW * 4 * 16 == TROWS * TCOLS, "NW waves x (4 rows x 16 columns) must cover the tile");
-    __shared__ __attribute__((aligned(16))) float lds[CK * WPLANE_ + KCH * NT];
-    float* lds_in = lds;
-    float* lds_w = lds + CK * WPLANE_;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int col = lane & 31, h = lane >> 5;
-    const ConvBlock blk = conv_decode(COUT / NT, gx, gy, ntiles);
-    if (!blk.valid) return;
-    const int b = blk.b, ct = blk.ct;
-    const int x0 = blk.bx * TCOLS, y0 = blk.by * TROWS;
-    const int co0 = ct * NT;
-    const int wr0 = (wave / WCOLS) * 4, wc0 = (wave % WCOLS) * 16;   // this wave's 4 x 16 pixel patch inside the tile
-
-    f32x16 acc[2][2];
-    {
-        const float b0 = bias[co0 + col], b1 = bias[co0 + 32 + col];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[0][0][r] = b0; acc[1][0][r] = b0; acc[0][1][r] = b1; acc[1][1][r] = b1; }
-    }
-    int aoff[9];
-#pragma unroll
-    for (int s = 0; s < 9; ++s) {
-        const int k0 = 2 * s, k1 = 2 * s + 1;
-        const int o0 = (k0 / 9) * WPLANE_ + ((k0 % 9) / 3) * WTWS_ + (k0 % 9) % 3;
-        const int o1 = (k1 / 9) * WPLANE_ + ((k1 % 9) / 3) * WTWS_ + (k1 % 9) % 3;
-        aoff[s] = (h ? o1 : o0) + (wr0 + (col >> 4)) * WTWS_ + wc0 + (col & 15);
-    }
-    const int boff = h * NT + col;
-    const float* in_b = in + (size_t)b * H * W * CIN;
-    const float* wp_ct = wp + (size_t)ct * (CIN / CK) * KCH * NT;
-
-    for (int ch = 0; ch < CIN / CK; ++ch) {
-        __syncthreads();
-        for (int idx = tid; idx < WIH_ * WIW_ * (CK / 4); idx += NTHR) {
-            const int cq = idx % (CK / 4), pix = idx / (CK / 4);
-            const int py = pix / WIW_, px = pix % WIW_;
-            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-                v = *reinterpret_cast<const float4*>(in_b + ((size_t)gy * W + gx) * CIN + ch * CK + cq * 4);
-            float* d = lds_in + (cq * 4) * WPLANE_ + py * WTWS_ + px;
-            d[0] = v.x; d[WPLANE_] = v.y; d[2 * WPLANE_] = v.z; d[3 * WPLANE_] = v.w;
-        }
-        conv_stage_weights<CK, NTHR>(lds_w, wp_ct + (size_t)ch * KCH * NT, tid);
-        __syncthreads();
-        conv_chunk_mma<CK, WPLANE_, 2 * WTWS_>(lds_in, lds_w, aoff, boff, acc);
-    }
-    // D row m = (r&3)+8*(r>>2)+4h of block mb -> pixel (y0 + wr0 + 2*mb + (m>>4), x0 + wc0 + (m&15))
-    float* out_b = out + (size_t)b * H * W * COUT;
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int y = y0 + wr0 + 2 * mb + (m >> 4), x = x0 + wc0 + (m & 15);
-            if (y >= H || x >= W) continue;
-            float v0 = acc[mb][0][r], v1 = acc[mb][1][r];
-            if (RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-            float* o = out_b + ((size_t)y * W + x) * COUT + co0 + col;
-            o[0] = v0; o[32] = v1;
-        }
-}
-
-// ------------------------------------------------------------------------------------------
 // Small-tile variant for latency-bound launches (one or two frames: the 60 x 80 layers give the tiles above only
 // 30-60 workgroups for 256 CUs, conv4a at batch 1 ran at 8 TFLOP/s).  Workgroup = 4 waves covering 4 rows x 32 columns
 // x 32 output channels: wave w owns row w (one M-block) and ONE accumulator, so the grid is 4x larger (180-360
@@ -616,14 +531,11 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
         else hipLaunchKernelGGL((conv3x3_small_kernel<64, false, 8>), gs, dim3(256), 0, s, in, wp, bias, out, H, W, cout, sx, sy, sx * sy * B);
         return;
     }
-    static const bool no_wide = tune_env("RFE_CONV_NO_WIDE") != nullptr;   // tuning / test switch
-    // 60 x 80 grid, measured (TFLOP/s, batch 33): 8x32 tile 94 (conv4) / 103 (heads); wide 4x80 tile 97 / 94 (the 256-channel
-    // heads re-stage the larger input tile four times); 12x16 tile of 3-wave workgroups 83 / 108; 20x16 tile of 5-wave
-    // workgroups (round 2): conv4 unchanged, heads 0.85 -> 1.05 ms.
-    // -> conv4a/4b take the wide tile, convPa/Da the 12x16 tile.  RFE_CONV_TALL: 0 = 8x32 everywhere, 1 = 12x16 everywhere, 2 = wide for conv4 only
-    static const int tall = tune_int("RFE_CONV_TALL", -1);
+    // 60 x 80 grid (conv4a/4b, convPa/Da), TFLOP/s at batch 33: plain 8x32 tiles 94 / 103 (22 % of the MFMA rows are padding); round-2a
+    // tilings that divide the grid exactly with M-blocks of 2 rows x 16 columns (4x80 tile of 5 waves, 12x16 tile of 3 waves) 99 / 110;
+    // composite 8x32 tiles over the two-frames-wide canvas 125 / 127 -> adopted, the 2x16-block kernels are gone (profiles/r02_ab_notes.md)
     static const int comp = tune_int("RFE_CONV_COMP", 1);   // composite tiles over the two-frames-wide canvas (0: round-2a tilings)
-    if (comp && !no_wide && ck8 && !pool && relu && cin == 128 && (tag == L_4A || tag == L_4B || tag == L_PA || tag == L_DA) && B >= 2 &&
+    if (comp && ck8 && !pool && relu && cin == 128 && (tag == L_4A || tag == L_4B || tag == L_PA || tag == L_DA) && B >= 2 &&
         H % 2 == 0 && W >= TW && H >= TH && (H % TH != 0 || W % TW != 0)) {
         const int cx = (2 * W + TW - 1) / TW, cy = (((B + 1) / 2) * H + TH - 1) / TH;
         const dim3 gc(conv_grid(cx, cy, 1, cout / NT));
@@ -632,26 +544,6 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
             case L_4B: hipLaunchKernelGGL((conv3x3_comp_kernel<128, true, L_4B, 8>), gc, dim3(256), 0, s, in, wp, bias, out, B, H, W, cout, cx, cy, cx * cy); return;
             case L_PA: hipLaunchKernelGGL((conv3x3_comp_kernel<128, true, L_PA, 8>), gc, dim3(256), 0, s, in, wp, bias, out, B, H, W, cout, cx, cy, cx * cy); return;
             default: hipLaunchKernelGGL((conv3x3_comp_kernel<128, true, L_DA, 8>), gc, dim3(256), 0, s, in, wp, bias, out, B, H, W, cout, cx, cy, cx * cy); return;
-        }
-    }
-    if (!no_wide && ck8 && !pool && relu && cin == 128 && (tag == L_4A || tag == L_4B || tag == L_PA || tag == L_DA)) {
-        const bool heads = tag == L_PA || tag == L_DA;
-        if ((tall == 1 || (tall == -1 && heads)) && W % 16 == 0 && H % 12 == 0) {
-            const int tx = W / 16, ty = H / 12;
-            const dim3 gt(conv_grid(tx, ty, B, cout / NT));
-            switch (tag) {
-                case L_4A: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4A, 8, 3, 12, 16>), gt, dim3(192), 0, s, in, wp, bias, out, H, W, cout, tx, ty, tx * ty * B); return;
-                case L_4B: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4B, 8, 3, 12, 16>), gt, dim3(192), 0, s, in, wp, bias, out, H, W, cout, tx, ty, tx * ty * B); return;
-                case L_PA: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_PA, 8, 3, 12, 16>), gt, dim3(192), 0, s, in, wp, bias, out, H, W, cout, tx, ty, tx * ty * B); return;
-                default: hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_DA, 8, 3, 12, 16>), gt, dim3(192), 0, s, in, wp, bias, out, H, W, cout, tx, ty, tx * ty * B); return;
-            }
-        }
-        if ((tall == 2 || tall == -1) && W % 80 == 0 && !heads) {
-            const int wx = W / 80, wy = (H + 3) / 4;
-            const dim3 gw(conv_grid(wx, wy, B, cout / NT));
-            if (tag == L_4A) hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4A, 8, 5, 4, 80>), gw, dim3(320), 0, s, in, wp, bias, out, H, W, cout, wx, wy, wx * wy * B);
-            else hipLaunchKernelGGL((conv3x3_blk16_kernel<128, true, L_4B, 8, 5, 4, 80>), gw, dim3(320), 0, s, in, wp, bias, out, H, W, cout, wx, wy, wx * wy * B);
-            return;
         }
     }
     switch (tag) {
