@@ -536,7 +536,8 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
     // composite 8x32 tiles over the two-frames-wide canvas 125 / 127 -> adopted, the 2x16-block kernels are gone (profiles/r02_ab_notes.md)
     static const int comp = tune_int("RFE_CONV_COMP", 1);   // composite tiles over the two-frames-wide canvas (0: round-2a tilings)
     if (comp && ck8 && !pool && relu && cin == 128 && (tag == L_4A || tag == L_4B || tag == L_PA || tag == L_DA) && B >= 2 &&
-        H % 2 == 0 && W >= TW && H >= TH && (H % TH != 0 || W % TW != 0)) {
+        H % 2 == 0 && W >= TW && H >= TH && (H % TH != 0 || W % TW != 0) &&
+        (long long)B * H * W * cin < (1ll << 31)) {   // 32-bit element offsets over the whole batch inside the kernel
         const int cx = (2 * W + TW - 1) / TW, cy = (((B + 1) / 2) * H + TH - 1) / TH;
         const dim3 gc(conv_grid(cx, cy, 1, cout / NT));
         switch (tag) {
