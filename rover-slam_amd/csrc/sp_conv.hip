@@ -229,15 +229,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
 // 30-60 workgroups for 256 CUs, conv4a at batch 1 ran at 8 TFLOP/s).  Workgroup = 4 waves covering 4 rows x 32 columns
 // x 32 output channels: wave w owns row w (one M-block) and ONE accumulator, so the grid is 4x larger (180-360
 // workgroups on 60 x 80) and each wave's serial MFMA chain is 4x shorter.  Reads the same packed weights (half of each
-// 64-wide row).  Same reduction order (bit-exact); no pooling.
+// 64-wide row).  Same reduction order (bit-exact).  POOL: the 2x2 windows span two waves (rows w, w+1), so the ReLU'd tile is
+// exchanged through LDS (4 x 32 px x 32 channels, the staging buffers are free by then) and pooled from there.
 constexpr int STH = 4, SIH = STH + 2, SPLANE = SIH * TWS, SNT = 32;
 
-template <int CIN, bool RELU, int CK>
+template <int CIN, bool RELU, int CK, bool POOL = false>
 __global__ __launch_bounds__(256, 4) void conv3x3_small_kernel(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ out, int H, int W, int COUT, int gx, int gy, int ntiles) {
     constexpr int KCH = CK * 9;
-    __shared__ __attribute__((aligned(16))) float lds[CK * SPLANE + KCH * SNT];
+    constexpr int LDS_WORDS = (CK * SPLANE + KCH * SNT) > (POOL ? STH * TW * SNT : 0) ? (CK * SPLANE + KCH * SNT) : STH * TW * SNT;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_WORDS];
     float* lds_in = lds;
     float* lds_w = lds + CK * SPLANE;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -295,6 +297,29 @@ __global__ __launch_bounds__(256, 4) void conv3x3_small_kernel(
 #pragma unroll
             for (int s = 0; s < 9; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[aoff[s]], bp[2 * s * SNT], acc, 0, 0, 0);
         }
+    }
+    if (POOL) {
+        __syncthreads();                                   // every wave is done with the staging buffers
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int xl = (r & 3) + 8 * (r >> 2) + 4 * h;
+            float v = acc[r];
+            if (RELU) v = fmaxf(v, 0.f);
+            lds[(wave * TW + xl) * SNT + col] = v;         // [row][column][channel]
+        }
+        __syncthreads();
+        const int Ho = H >> 1, Wo = W >> 1;
+        float* out_b = out + (size_t)b * Ho * Wo * COUT;
+        const int chn = tid & 31;
+#pragma unroll
+        for (int it = 0; it < (STH / 2) * (TW / 2) / 8; ++it) {
+            const int pp = (tid >> 5) + 8 * it, pr = pp / (TW / 2), pc = pp % (TW / 2);
+            const int yo = (y0 >> 1) + pr, xo = (x0 >> 1) + pc;
+            if (yo >= Ho || xo >= Wo) continue;
+            const float* e = lds + ((2 * pr) * TW + 2 * pc) * SNT + chn;
+            out_b[((size_t)yo * Wo + xo) * COUT + co0 + chn] = fmaxf(fmaxf(e[0], e[SNT]), fmaxf(e[TW * SNT], e[TW * SNT + SNT]));
+        }
+        return;
     }
     const int y = y0 + wave;
     if (y < H) {
@@ -522,9 +547,14 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
     const bool ck8 = conv_ck() == 8;
     // latency regime: too few 8 x 32 x 64 tiles to occupy the chip -> 4 x 32 x 32 tiles (4x the workgroups)
     static const int small_thr = tune_int("RFE_CONV_SMALL", 512);   // 0 disables
-    if (ck8 && !pool && (long long)gx * gy * B * (cout / NT) < small_thr && (cin == 64 || cin == 128)) {
+    if (ck8 && (!pool || relu) && (long long)gx * gy * B * (cout / NT) < small_thr && (cin == 64 || cin == 128)) {
         const int sx = (W + TW - 1) / TW, sy = (H + STH - 1) / STH;
         const dim3 gs(conv_grid(sx, sy, B, cout / SNT));
+        if (pool) {   // (every pooling layer of SuperPoint has a ReLU)
+            if (cin == 128) hipLaunchKernelGGL((conv3x3_small_kernel<128, true, 8, true>), gs, dim3(256), 0, s, in, wp, bias, out, H, W, cout, sx, sy, sx * sy * B);
+            else hipLaunchKernelGGL((conv3x3_small_kernel<64, true, 8, true>), gs, dim3(256), 0, s, in, wp, bias, out, H, W, cout, sx, sy, sx * sy * B);
+            return;
+        }
         if (cin == 128 && relu) hipLaunchKernelGGL((conv3x3_small_kernel<128, true, 8>), gs, dim3(256), 0, s, in, wp, bias, out, H, W, cout, sx, sy, sx * sy * B);
         else if (cin == 128) hipLaunchKernelGGL((conv3x3_small_kernel<128, false, 8>), gs, dim3(256), 0, s, in, wp, bias, out, H, W, cout, sx, sy, sx * sy * B);
         else if (relu) hipLaunchKernelGGL((conv3x3_small_kernel<64, true, 8>), gs, dim3(256), 0, s, in, wp, bias, out, H, W, cout, sx, sy, sx * sy * B);
