@@ -35,9 +35,9 @@ int main() {
     hipMemcpy(bias, hv.data(), 768 * 4, hipMemcpyHostToDevice); hipMemcpy(cs, hv.data(), (size_t)M * 32 * 4, hipMemcpyHostToDevice);
     hipMemcpy(sn, hv.data(), (size_t)M * 32 * 4, hipMemcpyHostToDevice);
     { GemmArgs g = plain(x, 256, w, 256, bias, ctx, 256, M, 256, 256); for (int i = 0; i < 3000; ++i) launch_gemm_nt(0, g); hipDeviceSynchronize(); }   // clock / power warm-up (~0.25 s)
-    { GemmArgs g = plain(x, 256, w, 512, bias, h, 512, M, 512, 512); g.A2 = ctx; g.lda2 = 256; g.K1 = 256; timeit("ffn1 (split A)", g); }
+    { GemmArgs g = plain(x, 256, w, 512, bias, h, 512, M, 512, 512); g.A2 = ctx; g.lda2 = 256; g.K1 = 256; timeit("ffn1 (split A)", g); g.kperm = 1; timeit("ffn1 (split A), k-permuted", g); }
     { GemmArgs g = plain(h, 512, w, 512, bias, x, 256, M, 256, 512); timeit("ffn2 no residual", g); g.R = x; g.ldr = 256; timeit("ffn2 + residual (in place)", g); }
-    { GemmArgs g = plain(x, 256, w, 256, bias, qkv, 768, M, 768, 256); timeit("qkv no rope", g); g.rope_cs = cs; g.rope_sn = sn; g.rope_ncols = 512; timeit("qkv + rope", g); }
+    { GemmArgs g = plain(x, 256, w, 256, bias, qkv, 768, M, 768, 256); timeit("qkv", g); g.kperm = 1; timeit("qkv, k-permuted LDS path", g); }
     { GemmArgs g = plain(x, 256, w, 256, bias, qkv, 512, M, 512, 256); timeit("cross qkv", g); }
     { GemmArgs g = plain(x, 256, w, 256, bias, ctx, 256, M, 256, 256); timeit("proj 256x256", g); }
     return 0;
