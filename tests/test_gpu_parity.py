@@ -231,6 +231,21 @@ def test_extract_fullsize_topk_vs_golden(ctx, golden_dir):
         assert np.abs(score[0] - g["score"][perm]).max() < 5e-6 and np.abs(desc[0] - g["desc"][perm]).max() < 2e-6
 
 
+@pytest.mark.parametrize("H,W", [(8, 8), (9, 17), (16, 8), (24, 40), (15, 15), (8, 200), (200, 8), (33, 31), (94, 310)])
+def test_extract_tiny_and_thin_images(ctx, oracle, H, W):
+    """The smallest inputs the entry points accept (one feature cell) and strips a single tile wide or tall, batch 1 and 3."""
+    w = Wt.make_superpoint(seed=7)
+    for B in (1, 3):
+        fr, _ = synth.make_frames(B, max(H, 48), max(W, 48), seed=H * 100 + W)
+        fr = np.ascontiguousarray(fr[:, :H, :W])
+        n, kxy, score, desc = ctx.extract(fr, kmax=64)
+        for i in range(B):
+            r = oracle.superpoint(w, fr[i], kmax=64)
+            k = r["n"]
+            assert n[i] == k
+            assert np.array_equal(kxy[i, :k], r["kxy"][:k]) and np.array_equal(score[i, :k], r["score"][:k]) and np.array_equal(desc[i, :k], r["desc"][:k])
+
+
 def test_extract_kitti_size_vs_oracle_and_golden(ctx, oracle, golden_dir):
     """KITTI's 1241 x 376 (not a multiple of 8; the reference graph has dynamic axes): bit-exact against the oracle, and against the
     independent HF fixture sp_f (top-k of 7790 candidates) / sp_g (101 x 151, all candidates)."""
