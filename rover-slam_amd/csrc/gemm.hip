@@ -351,7 +351,7 @@ int launch_gemm_nt(hipStream_t s, const GemmArgs& g_in) {
 
     static const bool kp_on = tune_int("RFE_GEMM_KP", 1) != 0;   // tuning switch: 0 = padded layout / k-ascending order everywhere
     const bool kp = kp_on && g.kperm != 0;
-    static const bool pft = tune_int("RFE_GEMM_PF", 1) != 0;   // register prefetch of the next K tile also on the 128-row tiles (+1 % on ffn1 / ffn2, profiles/r02_pmc.md); RFE_GEMM_PF=0 (tuning build) disables
+    static const bool pft = tune_int("RFE_GEMM_PF", 1) != 0;   // register prefetch of the next K tile also on the 128-row tiles (+1 % on ffn1 / ffn2, profiles/r02_ab_notes.md); RFE_GEMM_PF=0 (tuning build) disables
 #define RFE_GEMM_GO(MB_, NB_, GRID)                                                                  \
     do {                                                                                             \
         if (kp && MB_ == 2 && pft && !lna) {                                                         \

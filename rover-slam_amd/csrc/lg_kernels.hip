@@ -44,9 +44,9 @@ constexpr size_t AT_SPLIT_MAX_ROWS = 8192;    // only problems this small are la
 // same three fp32 operations round 1's projection epilogue used (bit-identical results).  The qkv projection keeps the plain
 // coalesced epilogue (101 -> 122 TFLOP/s); the K rows are rotated once per staging workgroup (8 query blocks per (sequence,
 // head): redundant VALU work worth ~1 % of the MFMA time, one extra 16-byte load per staged K float4; the table is 256 B per
-// row and L2 resident).  Net effect on the step: none within noise (profiles/r02_pmc.md) -- kept because it removes the
+// row and L2 resident).  Net effect on the step: none within noise (profiles/r02_ab_notes.md) -- kept because it removes the
 // LDS-transposed epilogue from the GEMM.  Variants that did not pay (double-buffered LDS, register prefetch of the next tile,
-// 64 queries per wave, 256-query workgroups, k rotated by the projection and q here) are recorded in profiles/r01_pmc.md / r02_pmc.md.
+// 64 queries per wave, 256-query workgroups, k rotated by the projection and q here) are recorded in profiles/r01_pmc.md / r02_ab_notes.md.
 // PFK (split variant only): the next K/V tile is fetched into registers right after the current one is published, i.e. under the
 // MFMAs.  The split variant runs one workgroup per CU, so nothing else hides the global round trip of every tile (the throughput
 // variant has 4 co-resident workgroups and measured slower with the prefetch: 146 VGPRs -> 3 workgroups, profiles/r02_ab_notes.md).

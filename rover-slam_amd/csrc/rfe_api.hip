@@ -969,7 +969,7 @@ extern "C" int rfe_stereo_frame_dev(rfe_ctx* c, const uint8_t* imgL, const uint8
     // both views as ONE batch of 2 (the reference runs them on two threads, src/Frame.cc:142-147).  Measured alternative: the
     // right view + stereo match on a second lane (own streams / workspace) next to left view + LightGlue -- 3.52 ms per stereo
     // frame against 3.26 ms for this form: two batch-1 extractions are no faster than one batch of 2, and the co-running
-    // kernels slow the latency-bound LightGlue chain (profiles/r02_pmc.md)
+    // kernels slow the latency-bound LightGlue chain (profiles/r02_ab_notes.md)
     RFE_HIP(c, hipMemcpy2DAsync(d_img, (size_t)W, imgL, (size_t)stride, (size_t)W, (size_t)H, hipMemcpyDeviceToDevice, s));
     RFE_HIP(c, hipMemcpy2DAsync(d_img + (size_t)H * W, (size_t)W, imgR, (size_t)stride, (size_t)W, (size_t)H, hipMemcpyDeviceToDevice, s));
     if ((rc = sp_forward(c, d_img, H, W, W, 2, Kmax, thr, n, kxy, score, desc))) return rc;
