@@ -414,6 +414,10 @@ def main():
         sys.exit(2)
     if args.check_launch:
         sys.exit(check_launch(args, rank, world))
+    if args.workload != "c4" and world > 1:
+        print(f"bench.py: --workload {args.workload} is a single-GPU latency configuration; only the metric's workload (c4) shards over ranks",
+              file=sys.stderr)
+        sys.exit(2)
 
     import torch
     import torch.distributed as dist
