@@ -246,6 +246,18 @@ def test_extract_tiny_and_thin_images(ctx, oracle, H, W):
             assert np.array_equal(kxy[i, :k], r["kxy"][:k]) and np.array_equal(score[i, :k], r["score"][:k]) and np.array_equal(desc[i, :k], r["desc"][:k])
 
 
+def test_extract_batch13_composite_conv_tiles(ctx, oracle):
+    """13 frames of 480 x 640 in one call: all four 60 x 80 layers take the composite 8 x 32 tiles over the two-frames-wide canvas
+    (7 frame pairs, the last one half empty; tiles assembled from pieces of up to four frames).  Every frame bit-exact."""
+    frames, _ = synth.make_frames(13, 480, 640, seed=1313)
+    n, kxy, score, desc = ctx.extract(frames, kmax=256)
+    w = Wt.make_superpoint(seed=7)
+    for i in range(13):
+        r = oracle.superpoint(w, frames[i], kmax=256)
+        assert n[i] == r["n"] == 256
+        assert np.array_equal(kxy[i], r["kxy"]) and np.array_equal(score[i], r["score"]) and np.array_equal(desc[i], r["desc"]), f"frame {i}"
+
+
 def test_extract_kitti_size_vs_oracle_and_golden(ctx, oracle, golden_dir):
     """KITTI's 1241 x 376 (not a multiple of 8; the reference graph has dynamic axes): bit-exact against the oracle, and against the
     independent HF fixture sp_f (top-k of 7790 candidates) / sp_g (101 x 151, all candidates)."""
