@@ -226,6 +226,13 @@ int rfe_k_lightglue_taps(rfe_ctx* ctx, const float* k0n, const float* k1n, const
                          const float* d1, int M, int N, float* x0_dev, float* x1_dev,
                          float* scores_dev /*[M,N]*/);
 
+/* One-shot tap for the NEXT LightGlue forward of this ctx, whichever entry point runs it (rfe_match[_dev] with P pairs,
+ * rfe_extract_match_stream_dev, rfe_stereo_frame_dev) and therefore whichever tiling it selects: after the last layer the final
+ * token states of pair `pair` are copied to x0_dev / x1_dev ([L,256] each, L = max(Mmax,Nmax) rounded up to 4; rows past the
+ * pair's keypoint counts are padding) and its log-assignment matrix to scores_dev ([L,L], row stride L; only the m x n block is
+ * written).  Any pointer may be NULL; pair < 0 disarms.  A pair index >= P of the next forward is ignored. */
+int rfe_k_set_lightglue_tap(rfe_ctx* ctx, int pair, float* x0_dev, float* x1_dev, float* scores_dev);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,7 +20,7 @@ EXPORTS = [
     "rfe_extract_match_stream_dev", "rfe_stereo_match", "rfe_stereo_match_dev", "rfe_stereo_frame_dev", "rfe_l2_distance_matrix", "rfe_binarize_descriptors",
     "rfe_search_candidates", "rfe_distinctive_descriptors",
     "rfe_profile_enable", "rfe_profile_filter", "rfe_profile_reset", "rfe_profile_read",
-    "rfe_k_conv3x3", "rfe_k_linear", "rfe_k_scoremap", "rfe_k_lightglue_taps",
+    "rfe_k_conv3x3", "rfe_k_linear", "rfe_k_scoremap", "rfe_k_lightglue_taps", "rfe_k_set_lightglue_tap",
 ]
 
 if not os.path.exists(LIB_PATH):
@@ -79,6 +79,7 @@ lib.rfe_k_conv3x3.argtypes = [C.c_void_p, _fp, C.c_int, C.c_int, C.c_int, C.c_in
 lib.rfe_k_linear.argtypes = [C.c_void_p, _fp, C.c_int, C.c_int, _fp, _fp, C.c_int, C.c_int, _fp]
 lib.rfe_k_scoremap.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]
 lib.rfe_k_lightglue_taps.argtypes = [C.c_void_p, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]
+lib.rfe_k_set_lightglue_tap.argtypes = [C.c_void_p, C.c_int, _fp, _fp, _fp]
 
 
 class RfeError(RuntimeError):

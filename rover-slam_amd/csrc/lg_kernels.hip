@@ -416,16 +416,18 @@ __global__ __launch_bounds__(256) void lg_rowarg_kernel(const float* __restrict_
                                                         const float* __restrict__ z1, const float* __restrict__ rowlse,
                                                         const float* __restrict__ collse, int L, const int* __restrict__ m,
                                                         const int* __restrict__ n, int32_t* __restrict__ a0,
-                                                        float* __restrict__ mx0, float* __restrict__ scores_opt) {
+                                                        float* __restrict__ mx0, float* __restrict__ scores_opt, int scores_pair) {
     const int p = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= m[p]) return;
     const int nn = n[p];
     const float* r = sim + ((size_t)p * L + i) * L;
     const float lr = rowlse[(size_t)p * L + i], l0 = z0[(size_t)p * L + i];
     float best = -INFINITY; int bi = 0x7fffffff;
+    // score dump (test taps): every pair into [P,L,L] (scores_pair < 0) or one pair into [L,L]
+    float* const dump = !scores_opt ? nullptr : scores_pair < 0 ? scores_opt + ((size_t)p * L + i) * L : p == scores_pair ? scores_opt + (size_t)i * L : nullptr;
     for (int jj = lane; jj < nn; jj += 64) {
         const float sc = lg_score(r[jj], lr, collse[(size_t)p * L + jj], l0, z1[(size_t)p * L + jj]);
-        if (scores_opt) scores_opt[((size_t)p * L + i) * L + jj] = sc;
+        if (dump) dump[jj] = sc;
         if (sc > best) { best = sc; bi = jj; }
     }
 #pragma unroll
@@ -527,13 +529,13 @@ __global__ __launch_bounds__(256) void lg_mutual_kernel(const int32_t* __restric
 
 void launch_lg_assign(hipStream_t s, const float* sim, const float* z0, const float* z1, int P, int L, int cap,
                       const int* m, const int* n, float thr, float* scores_opt, float* rowlse, float* collse,
-                      int32_t* a0, float* mx0, int32_t* a1, int32_t* S, int32_t* pairs, float* ms) {
+                      int32_t* a0, float* mx0, int32_t* a1, int32_t* S, int32_t* pairs, float* ms, int scores_pair) {
     hipLaunchKernelGGL(lg_rowlse_kernel, dim3((L + 3) / 4, P), dim3(256), 0, s, sim, L, m, n, rowlse);
     if ((long long)P * ((L + 31) / 32) < 128)   // a few pairs: narrower stripes, 4x the threads per workgroup
         hipLaunchKernelGGL((lg_col_kernel<16, 64>), dim3((L + 15) / 16, P), dim3(1024), 0, s, sim, z0, z1, rowlse, L, m, n, collse, a1);
     else
         hipLaunchKernelGGL((lg_col_kernel<32, 8>), dim3((L + 31) / 32, P), dim3(256), 0, s, sim, z0, z1, rowlse, L, m, n, collse, a1);
-    hipLaunchKernelGGL(lg_rowarg_kernel, dim3((L + 3) / 4, P), dim3(256), 0, s, sim, z0, z1, rowlse, collse, L, m, n, a0, mx0, scores_opt);
+    hipLaunchKernelGGL(lg_rowarg_kernel, dim3((L + 3) / 4, P), dim3(256), 0, s, sim, z0, z1, rowlse, collse, L, m, n, a0, mx0, scores_opt, scores_pair);
     hipLaunchKernelGGL(lg_mutual_kernel, dim3(P), dim3(256), 0, s, a0, mx0, a1, L, cap, m, n, thr, S, pairs, ms);
 }
 

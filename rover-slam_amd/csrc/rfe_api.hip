@@ -692,10 +692,20 @@ int lg_forward(rfe_ctx* c, LgBuffers& b, int P, int L, float thr, int cap, int32
       g.batch = P; g.sA = (long long)L * 256; g.sB = (long long)L * 256; g.sC = (long long)L * L;
       g.m_valid = b.lens;
       launch_gemm_nt(s, g); }
+    // one-shot test tap (rfe_k_set_lightglue_tap): final token states [L,256] per side and the log-assignment matrix [L,L]
+    // of ONE pair of this forward, whatever the entry point and tiling (batched, stream, stereo frame)
+    const bool tap = c->tap.armed && c->tap.pair < P;
+    c->tap.armed = false;
+    int scores_pair = -1;
+    if (tap && c->tap.scores && !scores_opt) { scores_opt = c->tap.scores; scores_pair = c->tap.pair; }
     { ProfScope p(c, "lg_assign");
       launch_lg_matchability(s, b.x, W.wm, W.bm, rows, b.z);
       launch_lg_assign(s, b.sim, b.z, b.z + (size_t)P * L, P, L, cap, b.lens, b.lens + P, thr, scores_opt, b.rowlse,
-                       b.collse, b.a0, b.mx0, b.a1, S, pairs, ms); }
+                       b.collse, b.a0, b.mx0, b.a1, S, pairs, ms, scores_pair); }
+    if (tap) {
+        if (c->tap.x0) RFE_HIP(c, hipMemcpyAsync(c->tap.x0, b.x + (size_t)c->tap.pair * L * 256, (size_t)L * 1024, hipMemcpyDeviceToDevice, s));
+        if (c->tap.x1) RFE_HIP(c, hipMemcpyAsync(c->tap.x1, b.x + (size_t)(P + c->tap.pair) * L * 256, (size_t)L * 1024, hipMemcpyDeviceToDevice, s));
+    }
     RFE_HIP(c, hipGetLastError());
     return RFE_OK;
 }
@@ -1205,6 +1215,13 @@ extern "C" int rfe_k_scoremap(rfe_ctx* c, const uint8_t* img, int H, int W, int 
     if (nms) RFE_HIP(c, hipMemcpyAsync(nms, b.nmap, hw * 4, hipMemcpyDeviceToDevice, c->stream));
     if (descmap) RFE_HIP(c, hipMemcpyAsync(descmap, b.dmap, hw / 64 * 256 * 4, hipMemcpyDeviceToDevice, c->stream));
     RFE_HIP(c, hipStreamSynchronize(c->stream));
+    return RFE_OK;
+}
+
+extern "C" int rfe_k_set_lightglue_tap(rfe_ctx* c, int pair, float* x0, float* x1, float* scores) {
+    if (!c) return RFE_ERR_INVALID;
+    if (pair < 0) { c->tap.armed = false; return RFE_OK; }
+    c->tap.armed = true; c->tap.pair = pair; c->tap.x0 = x0; c->tap.x1 = x1; c->tap.scores = scores;
     return RFE_OK;
 }
 

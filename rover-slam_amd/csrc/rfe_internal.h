@@ -13,7 +13,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace rfe {
 
-// Tuning / ablation switches read from the environment exist only in a -DRFE_TUNING build (make TUNING=1 ->
+// Tuning / ablation switches read from the environment exist only in a -DRFE_TUNING build (`make tuning` ->
 // librover_fe_tuning.so, used by tools/ for A/B measurements).  The shipped library never consults the environment:
 // its numerics and kernel choices depend on its arguments and on rfe_set_option alone.
 #ifdef RFE_TUNING
@@ -111,6 +111,9 @@ struct rfe_ctx {
     void* ws_tmp = nullptr; size_t ws_tmp_bytes = 0; // test hooks
     void* ws_st = nullptr; size_t ws_st_bytes = 0;   // stereo stream state: staged views, previous left view's features
     int st_H = 0, st_W = 0, st_K = 0; bool st_have_prev = false;
+    // one-shot test tap (rfe_k_set_lightglue_tap): the next LightGlue forward of this ctx, whatever entry point runs it,
+    // copies the final token states / log-assignment matrix of one pair to these device buffers
+    struct { bool armed = false; int pair = 0; float *x0 = nullptr, *x1 = nullptr, *scores = nullptr; } tap;
     // profiling
     bool prof = false;
     std::string prof_filter;          // non-empty: only this stage records events
@@ -176,7 +179,7 @@ void launch_lg_ln_gelu(hipStream_t s, float* h, const float* g, const float* b, 
 void launch_lg_assign(hipStream_t s, const float* sim, const float* z0, const float* z1, int P, int L,
                       int cap, const int* m, const int* n, float thr, float* scores_opt, float* rowlse,
                       float* collse, int32_t* a0, float* mx0, int32_t* a1, int32_t* S, int32_t* pairs,
-                      float* ms);
+                      float* ms, int scores_pair = -1 /*>= 0: scores_opt is [L,L] and receives that pair only*/);
 void launch_lg_matchability(hipStream_t s, const float* x, const float* w, const float* b, int64_t rows, float* z);
 void launch_copy_f32(hipStream_t s, const float* src, float* dst, int64_t n);
 void launch_normalize_kpts(hipStream_t s, const int32_t* kxy, int64_t n, int rows, int cols, float* out);

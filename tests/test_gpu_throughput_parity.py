@@ -1,0 +1,136 @@
+"""GPU parity of the THROUGHPUT tiling against the oracle.
+
+The kernels the benchmark times -- 128x256 k-permuted GEMM tiles, the LayerNorm + GELU fusion around ffn.0 / ffn.3, the one-workgroup
+attention, the per-frame layer-0 self block of the stream mode -- are only selected from 32 768 token rows upwards
+(launch_gemm_nt, gemm.hip), i.e. P >= 16 pairs at K = 1024.  These tests run such batches against oracle.lightglue PER PAIR on inputs
+with hundreds of matches, and read the final token states / the log-assignment matrix of one pair of the batched / stream call
+through the one-shot tap (rfe_k_set_lightglue_tap).  Semantics held: src/Matchers/lightglue_onnx.cpp:437-453 (the match list)."""
+import numpy as np
+import pytest
+
+from rover_slam_amd import weights as Wt, synth
+from tolerances import LG_SCORE_TOL, LG_STATE_TOL, LG_LOGSCORE_RTOL, lists_agree_borderline
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from rover_slam_amd import capi
+    c = capi.Context(0)
+    c.set_weights(capi.KIND_SUPERPOINT, Wt.make_superpoint(seed=7))
+    c.set_weights(capi.KIND_LIGHTGLUE, Wt.make_lightglue(seed=11))
+    yield c
+    c.close()
+
+
+def _constructed_batch(P, K, seed, lens0, lens1):
+    """set 1 = permuted copy of a random unit-vector set 0 with 1 % descriptor noise and 0.02 keypoint noise (the construction of
+    tools/lg_tolerance_study.py): several hundred true matches per pair."""
+    rng = np.random.default_rng(seed)
+    k0 = np.zeros((P, K, 2), np.float32); k1 = np.zeros((P, K, 2), np.float32)
+    d0 = np.zeros((P, K, 256), np.float32); d1 = np.zeros((P, K, 256), np.float32)
+    for p in range(P):
+        a = rng.standard_normal((K, 256)).astype(np.float32); a /= np.linalg.norm(a, axis=1, keepdims=True)
+        kk = rng.uniform(-0.9, 0.9, (K, 2)).astype(np.float32)
+        perm = rng.permutation(K)
+        m, n = lens0[p], lens1[p]
+        d0[p, :m] = a[:m]; k0[p, :m] = kk[:m]
+        bb = a[perm][:n] + 0.01 * rng.standard_normal((n, 256)).astype(np.float32)
+        d1[p, :n] = bb / np.linalg.norm(bb, axis=1, keepdims=True)
+        k1[p, :n] = (kk[perm][:n] + 0.02 * rng.standard_normal((n, 2))).astype(np.float32)
+    return k0, k1, d0, d1
+
+
+@pytest.mark.parametrize("fold", [1, 0])
+def test_lightglue_batch16_k1024_vs_oracle(ctx, oracle, fold):
+    """P = 16 pairs at K = 1024 in ONE call = 32 768 token rows: qkv / cross-qkv / ffn.0 / ffn.3 take the 128x256 k-permuted tiles with
+    the fused LayerNorm + GELU, the attention one workgroup per query block -- the exact instantiations of the bench step.  Every pair
+    against the oracle: match list (borderline rule), match scores, > 400 matches; pair 9's final token states and log-assignment
+    matrix through the tap."""
+    from rover_slam_amd import capi
+    P, K, tap_pair = 16, 1024, 9
+    lens0 = [1024] * P; lens1 = [1024] * P
+    lens0[3], lens1[5], lens0[12], lens1[12] = 700, 900, 611, 1001          # a few ragged pairs inside the full-size batch
+    k0, k1, d0, d1 = _constructed_batch(P, K, 77, lens0, lens1)
+    dx0, dx1, dsc = ctx.alloc(K * 1024), ctx.alloc(K * 1024), ctx.alloc(K * K * 4)
+    ctx.set_option(capi.OPT_LG_FOLD_WO, fold)
+    try:
+        ctx._chk(capi.lib.rfe_k_set_lightglue_tap(ctx.h, tap_pair, dx0.ptr, dx1.ptr, dsc.ptr))
+        S, pairs, ms = ctx.match(k0, k1, d0, d1, lens0, lens1)
+    finally:
+        ctx.set_option(capi.OPT_LG_FOLD_WO, 1)
+    x0, x1, sc = dx0.download((K, 256), np.float32), dx1.download((K, 256), np.float32), dsc.download((K, K), np.float32)
+    w = Wt.make_lightglue(seed=11)
+    worst, total = 0.0, 0
+    for p in range(P):
+        m, n = lens0[p], lens1[p]
+        r = oracle.lightglue(w, k0[p, :m], k1[p, :n], d0[p, :m], d1[p, :n], debug=True)
+        ok, dev, one_sided = lists_agree_borderline(pairs[p, :S[p]], ms[p, :S[p]], r["pairs"], r["ms"], r["scores"], K)
+        assert ok and dev < LG_SCORE_TOL, (p, ok, dev, one_sided)
+        assert S[p] > 400 and r["S"] > 400, (p, S[p], r["S"])
+        worst, total = max(worst, dev), total + int(S[p])
+        if p == tap_pair:
+            assert np.abs(x0[:m] - r["x0"]).max() < LG_STATE_TOL and np.abs(x1[:n] - r["x1"]).max() < LG_STATE_TOL
+            assert np.abs(sc[:m, :n] - r["scores"]).max() < LG_LOGSCORE_RTOL * np.abs(r["scores"]).max()
+    print(f"batch16 fold={fold}: {total} matches over {P} pairs, max |score dev| {worst:.2e}")
+    for b in (dx0, dx1, dsc):
+        b.free()
+
+
+def test_lightglue_batch16_tap_equals_single_pair_tap(ctx):
+    """The tap itself: pair 2 of a P = 16 batch (throughput tiles) against the same pair alone through rfe_k_lightglue_taps
+    (64-row latency tiles, split-key attention): token states within the stated tolerance of each other."""
+    from rover_slam_amd import capi
+    P, K = 16, 1024
+    k0, k1, d0, d1 = _constructed_batch(P, K, 5, [1024] * P, [1024] * P)
+    dx0, dx1 = ctx.alloc(K * 1024), ctx.alloc(K * 1024)
+    ctx._chk(capi.lib.rfe_k_set_lightglue_tap(ctx.h, 2, dx0.ptr, dx1.ptr, None))
+    ctx.match(k0, k1, d0, d1, [K] * P, [K] * P)
+    xb0, xb1 = dx0.download((K, 256), np.float32), dx1.download((K, 256), np.float32)
+    bufs = [ctx.alloc(a.nbytes).upload(a) for a in (k0[2], k1[2], d0[2], d1[2])]
+    ctx._chk(capi.lib.rfe_k_lightglue_taps(ctx.h, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr, K, K, dx0.ptr, dx1.ptr, None))
+    xs0, xs1 = dx0.download((K, 256), np.float32), dx1.download((K, 256), np.float32)
+    assert np.abs(xb0 - xs0).max() < LG_STATE_TOL and np.abs(xb1 - xs1).max() < LG_STATE_TOL
+    # a tap is one-shot: the next call leaves the buffers alone
+    dx0.upload(np.zeros((K, 256), np.float32))
+    ctx.match(k0[:1], k1[:1], d0[:1], d1[:1], [K], [K])
+    assert not dx0.download((K, 256), np.float32).any()
+    for b in bufs + [dx0, dx1]:
+        b.free()
+
+
+def test_stream_b33_filter0_vs_oracle(ctx, oracle):
+    """configs[3]'s per-GPU shard through rfe_extract_match_stream_dev (B = 33 frames 640x480, Kmax = 1024: per-frame layer-0 self
+    block, throughput tiles) with filter_thr = 0.0, so EVERY mutual pair is emitted -- hundreds per pair instead of the handful
+    that pass 0.1 with random weights.  Five pairs against the oracle (borderline rule, scores), pair 16's final token states and
+    log-assignment matrix through the tap."""
+    from rover_slam_amd import capi
+    B, H, W, K, tap_pair = 33, 480, 640, 1024, 16
+    frames, _ = synth.make_frames(B, H, W, seed=20240314)
+    dimg = ctx.alloc(frames.nbytes).upload(frames)
+    dn, dk, ds, dd = ctx.alloc(B * 4), ctx.alloc(B * K * 8), ctx.alloc(B * K * 4), ctx.alloc(B * K * 1024)
+    dS, dp, dm = ctx.alloc((B - 1) * 4), ctx.alloc((B - 1) * K * 8), ctx.alloc((B - 1) * K * 4)
+    dx0, dx1, dsc = ctx.alloc(K * 1024), ctx.alloc(K * 1024), ctx.alloc(K * K * 4)
+    ctx._chk(capi.lib.rfe_k_set_lightglue_tap(ctx.h, tap_pair, dx0.ptr, dx1.ptr, dsc.ptr))
+    ctx._chk(capi.lib.rfe_extract_match_stream_dev(ctx.h, dimg.ptr, H, W, W, B, K, 0.0005, 0.0, dn.ptr, dk.ptr, ds.ptr, dd.ptr,
+                                                   dS.ptr, dp.ptr, dm.ptr))
+    ctx.synchronize()
+    n, kxy, desc = dn.download((B,), np.int32), dk.download((B, K, 2), np.int32), dd.download((B, K, 256), np.float32)
+    S, pairs, ms = dS.download((B - 1,), np.int32), dp.download((B - 1, K, 2), np.int32), dm.download((B - 1, K), np.float32)
+    x0, x1, sc = dx0.download((K, 256), np.float32), dx1.download((K, 256), np.float32), dsc.download((K, K), np.float32)
+    wlg = Wt.make_lightglue(seed=11)
+    total = 0
+    for i in (0, 7, tap_pair, 24, 31):
+        kn = [oracle.normalize_keypoints(kxy[j, :n[j]].astype(np.float32), H, W) for j in (i, i + 1)]   # extraction is bit-exact (other tests)
+        r = oracle.lightglue(wlg, kn[0], kn[1], desc[i, :n[i]], desc[i + 1, :n[i + 1]], filter_thr=0.0, debug=True)
+        ok, dev, one_sided = lists_agree_borderline(pairs[i, :S[i]], ms[i, :S[i]], r["pairs"], r["ms"], r["scores"], K, filter_thr=0.0)
+        assert ok and dev < LG_SCORE_TOL, (i, ok, dev, one_sided)
+        assert S[i] > 100, (i, S[i])          # mutual nearest neighbours of two 1024-keypoint sets: hundreds
+        total += int(S[i])
+        if i == tap_pair:
+            assert np.abs(x0[:n[i]] - r["x0"]).max() < LG_STATE_TOL and np.abs(x1[:n[i + 1]] - r["x1"]).max() < LG_STATE_TOL
+            assert np.abs(sc[:n[i], :n[i + 1]] - r["scores"]).max() < LG_LOGSCORE_RTOL * np.abs(r["scores"]).max()
+    print(f"stream B=33 filter 0: {total} matches over 5 pairs")
+    for d in (dimg, dn, dk, ds, dd, dS, dp, dm, dx0, dx1, dsc):
+        d.free()

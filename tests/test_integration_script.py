@@ -54,6 +54,14 @@ def _fake_checkout(tmp_path):
         f = co / p
         f.parent.mkdir(parents=True, exist_ok=True)
         f.write_text('#include "Matchers/SPmatcher.h"\n')
+    for p in AI.SHADOWED_HEADERS:                       # stand-ins for the reference headers: same guards, a marker macro
+        f = co / p
+        f.parent.mkdir(parents=True, exist_ok=True)
+        guard = {"SPextractor.h": "SPEXTRACTOR_H", "SPmatcher.h": "ORBMATCHER_H"}.get(f.name)
+        body = "#define FAKE_REFERENCE_HEADER 1\nnamespace ORB_SLAM3 { class SPextractor; class SPmatcher; }\n"
+        f.write_text(f"#ifndef {guard}\n#define {guard}\n{body}#endif\n" if guard else "#pragma once\n" + body)
+    # a header of the checkout's own include/ that pulls the two facades in with QUOTED includes, like include/Tracking.h:39,41
+    (co / "include" / "Tracking.h").write_text('#pragma once\n#include "Matchers/SPmatcher.h"\n#include "Extractors/SPextractor.h"\n')
     (co / "CMakeLists.txt").write_text(FAKE_CMAKE)
     return co
 
@@ -85,6 +93,18 @@ def test_apply_on_synthetic_checkout(tmp_path):
     assert "src/System.cc" in out and "include/Settings.h)" in out and "add_executable(mono" in out
     assert (co / "CMakeLists.txt.pre_rfe").read_text() == FAKE_CMAKE
     assert AI.main([str(co)]) == 0 and (co / "CMakeLists.txt").read_text() == out   # idempotent
+    for p in AI.SHADOWED_HEADERS:                                         # the six headers are forwarders now, originals kept
+        assert AI.is_forwarder(str(co / p)) and "FAKE_REFERENCE_HEADER" in (co / (p + ".pre_rfe")).read_text()
+    # a forwarder that was put back (e.g. `git checkout include/`) is a failed check, and a re-run repairs it
+    shutil.copy(co / (AI.SHADOWED_HEADERS[0] + ".pre_rfe"), co / AI.SHADOWED_HEADERS[0])
+    assert any("still is the reference header" in x for x in AI.check_tree(str(co), ROOT, applied=True))
+    assert AI.main([str(co)]) == 0 and AI.check_tree(str(co), ROOT, applied=True) == []
+    # --revert: everything back
+    assert AI.main([str(co), "--revert"]) == 0
+    assert (co / "CMakeLists.txt").read_text() == FAKE_CMAKE and not (co / "CMakeLists.txt.pre_rfe").exists()
+    for p in AI.SHADOWED_HEADERS:
+        assert "FAKE_REFERENCE_HEADER" in (co / p).read_text() and not (co / (p + ".pre_rfe")).exists()
+    assert AI.main([str(co)]) == 0
     # a file that is not Rover-SLAM's is refused, untouched
     (co / "CMakeLists.txt").write_text("project(x)\nadd_library(x a.cc)\n")
     assert AI.main([str(co)]) == 3 and (co / "CMakeLists.txt").read_text() == "project(x)\nadd_library(x a.cc)\n"
@@ -99,9 +119,32 @@ def test_apply_on_copy_of_reference(tmp_path):
         shutil.copytree(os.path.join(REF, d), co / d)
     assert AI.main([str(co)]) == 0
     _check_result((co / "CMakeLists.txt").read_text())
+    for p in AI.SHADOWED_HEADERS:                      # the real headers: renamed byte for byte, forwarders in their place
+        assert AI.is_forwarder(str(co / p))
+        assert (co / (p + ".pre_rfe")).read_bytes() == open(os.path.join(REF, p), "rb").read()
     before = open(os.path.join(REF, "CMakeLists.txt")).read().splitlines()
     after = (co / "CMakeLists.txt").read_text().splitlines()
     assert abs(len(after) - len(before)) < 20                            # a handful of lines change, nothing else
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="no g++")
+def test_quoted_include_from_checkout_header_sees_the_dropin(tmp_path):
+    """Tracking.h / LocalMapping.h / LoopClosing.h include "Matchers/SPmatcher.h" / "Extractors/SPextractor.h"
+    with QUOTES, and a quoted include searches the including file's directory before any -I path -- so -I<this repo>/include
+    first does NOT shadow the reference headers for them.  A translation unit that includes a header located in the checkout's
+    include/ must see the drop-in classes after apply_integration (forwarders), and demonstrably did not before."""
+    co = _fake_checkout(tmp_path)
+    tu = tmp_path / "tu.cc"
+    tu.write_text('#include "Tracking.h"\n'
+                  "#ifdef FAKE_REFERENCE_HEADER\n#error the reference header won over the drop-in\n#endif\n"
+                  "static_assert(sizeof(ORB_SLAM3::SPextractor) > 0 && sizeof(ORB_SLAM3::SPmatcher) > 0, \"drop-in classes are complete types\");\n"
+                  "int main() { return rfe_version() == nullptr; }\n")
+    cmd = ["g++", "-std=c++14", "-fsyntax-only", "-DRFE_NO_OPENCV", "-I" + os.path.join(ROOT, "include"), "-I" + str(co / "include"), str(tu)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode != 0 and "the reference header won" in r.stderr          # the defect, before the forwarders exist
+    assert AI.main([str(co)]) == 0
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
 
 
 def _function_bodies(src, head_regex):

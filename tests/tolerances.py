@@ -30,3 +30,31 @@ def lists_agree(pairs_a, ms_a, pairs_b, ms_b, filter_thr=0.1, slack=5e-4):
     ok = all(abs(s - filter_thr) <= slack for _, s in only)
     dev = max((abs(da[k] - db[k]) for k in da.keys() & db.keys()), default=0.0)
     return ok, dev
+
+
+def _top2_gap(logscores):
+    """difference of the two largest match probabilities of a row / column of the log-assignment matrix"""
+    import numpy as np
+    t = np.sort(logscores)[-2:]
+    return float(np.exp(t[-1]) - np.exp(t[0])) if len(t) == 2 else float("inf")
+
+
+def borderline(sc, i, j, keypoints, filter_thr=0.1):
+    """A match that only one side reports is legitimate when fp32 noise can produce it: match probabilities agree to
+    tol = LG_SCORE_TOL_SMALL (<= 256 keypoints) / LG_SCORE_TOL, so the filter can flip within tol of its threshold and a
+    row / column argmax can flip when the two best probabilities are closer than 2 tol (each moves by up to tol).
+    sc: the reference's log-assignment matrix [M,N]."""
+    import numpy as np
+    tol = LG_SCORE_TOL_SMALL if keypoints <= 256 else LG_SCORE_TOL
+    return abs(float(np.exp(sc[i, j])) - filter_thr) < tol or _top2_gap(sc[i]) < 2 * tol or _top2_gap(sc[:, j]) < 2 * tol
+
+
+def lists_agree_borderline(pairs_a, ms_a, pairs_b, ms_b, scores_ref, keypoints, filter_thr=0.1):
+    """Match lists equal up to borderline flips (see `borderline`).  Returns (ok, max |score difference| over the common
+    matches, number of one-sided matches)."""
+    da = {(int(i), int(j)): float(s) for (i, j), s in zip(pairs_a, ms_a)}
+    db = {(int(i), int(j)): float(s) for (i, j), s in zip(pairs_b, ms_b)}
+    only = da.keys() ^ db.keys()
+    ok = all(borderline(scores_ref, i, j, keypoints, filter_thr) for (i, j) in only)
+    dev = max((abs(da[k] - db[k]) for k in da.keys() & db.keys()), default=0.0)
+    return ok, dev, len(only)

@@ -12,20 +12,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle as O
 from rover_slam_amd import capi, synth, weights as Wt
-
-
-def top2_gap(logscores):
-    """difference of the two largest match probabilities of a row / column of the log-assignment matrix"""
-    t = np.sort(logscores)[-2:]
-    return float(np.exp(t[-1]) - np.exp(t[0])) if len(t) == 2 else float("inf")
-
-
-def borderline(sc, i, j, keypoints):
-    """A match that only one side reports is legitimate when fp32 noise can produce it: match probabilities agree to
-    tol = LG_SCORE_TOL_SMALL (<= 256 keypoints) / LG_SCORE_TOL (tests/tolerances.py), so the 0.1 filter can flip within tol and a
-    row / column argmax can flip when the two best probabilities are closer than 2 tol (each moves by up to tol)."""
-    tol = 1e-4 if keypoints <= 256 else 5e-4
-    return abs(float(np.exp(sc[i, j])) - 0.1) < tol or top2_gap(sc[i]) < 2 * tol or top2_gap(sc[:, j]) < 2 * tol
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from tolerances import borderline  # noqa: E402  (the one statement of the borderline rule)
 
 
 def main(seconds=60.0, seed=0):
