@@ -168,8 +168,10 @@ int rfe_stereo_match_dev(rfe_ctx* ctx, const uint8_t* imgL, const uint8_t* imgR,
  * threads (src/Frame.cc:106-171, :142-147) and calls ComputeStereoMatches (:165, :1159-1446); Tracking then matches the
  * frame against the previous one with LightGlue (SPmatcher::MatchingPoints_onnx, Frame overload, src/Matchers/SPmatcher.cc:457-542,
  * called from :1050-1080).  Here: both views through SuperPoint as one batch of 2, the sparse stereo match on the device-
- * resident features (keypoint counts never visit the host), and one LightGlue match of the PREVIOUS left view (set 0,
- * kept inside the ctx) against this left view (set 1) with the true image size.  Asynchronous on the ctx stream.
+ * resident features (keypoint counts never visit the host), and one LightGlue match of THIS left view (set 0) against the
+ * PREVIOUS left view (set 1, kept inside the ctx) with the true image size -- the argument order of
+ * SearchBySP(mCurrentFrame, mLastFrame) (src/Tracking.cc:3465; SPmatcher.cc:1050-1054), so pairs[k] = (index in the current
+ * frame, index in the previous frame) like vnMatches1[IdxCF] = IdxLF.  Asynchronous on the ctx stream.
  * imgL/imgR: device u8 [H,W], row pitch `stride`.  reset != 0 (or a change of H, W, Kmax) starts a new sequence: S = 0.
  * Outputs (device): n [2] (left, right), kxy [2,Kmax,2], score [2,Kmax], desc [2,Kmax,256] as rfe_extract_u8_dev;
  * uRight / depth [Kmax] as rfe_stereo_match (entries >= n[0] are -1); S [1], pairs [Kmax,2], ms [Kmax] as rfe_match_dev. */

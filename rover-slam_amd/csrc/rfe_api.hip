@@ -987,8 +987,10 @@ extern "C" int rfe_stereo_frame_dev(rfe_ctx* c, const uint8_t* imgL, const uint8
     { ProfScope ps(c, "stereo_match");
       launch_stereo_match_counts(s, d_img, d_img + (size_t)H * W, H, W, W, kxy, kxy + (size_t)Kmax * 2, Kmax, n, desc,
                                  desc + (size_t)Kmax * 256, mb, mbf, uRight, depth, sadv); }
-    // temporal match: previous left view (set 0) against this left view (set 1), true image size like the Frame overload
-    // of MatchingPoints_onnx (src/Matchers/SPmatcher.cc:457-542, :463-464)
+    // temporal match exactly as Tracking issues it: SearchBySP(mCurrentFrame, mLastFrame) (src/Tracking.cc:3465) ->
+    // MatchingPoints_onnx(CurrentFrame, LastFrame, vnMatches1) (src/Matchers/SPmatcher.cc:1050-1054): THIS left view is set 0,
+    // the previous left view set 1, so pairs are (current index, previous index) like vnMatches1[IdxCF] = IdxLF; true image
+    // size like the Frame overload (:457-542, :463-464)
     { ProfScope ps(c, "lg_misc"); launch_normalize_kpts(s, kxy, Kmax, H, W, kn_cur); }
     if (c->st_have_prev) {
         const int L = ((Kmax + 3) / 4) * 4;
@@ -996,7 +998,7 @@ extern "C" int rfe_stereo_frame_dev(rfe_ctx* c, const uint8_t* imgL, const uint8
         LgBuffers b;
         lg_carve(c->ws_lg, 1, L, b);
         { ProfScope ps(c, "lg_misc");
-          if ((rc = lg_stage(c, b, kn_prev, kn_cur, desc_prev, desc, n_prev, n, 1, Kmax, Kmax, L))) return rc; }
+          if ((rc = lg_stage(c, b, kn_cur, kn_prev, desc, desc_prev, n, n_prev, 1, Kmax, Kmax, L))) return rc; }
         if ((rc = lg_forward(c, b, 1, L, filter_thr, Kmax, S, pairs, ms, nullptr))) return rc;
     } else {
         hipLaunchKernelGGL(st_zero_count_kernel, dim3(1), dim3(1), 0, s, S);

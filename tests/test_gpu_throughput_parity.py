@@ -102,12 +102,16 @@ def test_lightglue_batch16_tap_equals_single_pair_tap(ctx):
 
 def test_stream_b33_filter0_vs_oracle(ctx, oracle):
     """configs[3]'s per-GPU shard through rfe_extract_match_stream_dev (B = 33 frames 640x480, Kmax = 1024: per-frame layer-0 self
-    block, throughput tiles) with filter_thr = 0.0, so EVERY mutual pair is emitted -- hundreds per pair instead of the handful
-    that pass 0.1 with random weights.  Five pairs against the oracle (borderline rule, scores), pair 16's final token states and
-    log-assignment matrix through the tap."""
+    block, throughput tiles) with filter_thr = 0.0, so EVERY mutual pair is emitted (with random weights only a handful pass 0.1).
+    Frames 9, 17 and 25 repeat their predecessor: those pairs give 200+ mutual matches, the others of the bench stream the 50-100
+    mutual nearest neighbours random weights leave.  Six pairs against the oracle (borderline rule, scores); pair 16
+    (a repeated frame) also with its final token states and log-assignment matrix through the tap."""
     from rover_slam_amd import capi
     B, H, W, K, tap_pair = 33, 480, 640, 1024, 16
     frames, _ = synth.make_frames(B, H, W, seed=20240314)
+    dup = (8, 16, 24)
+    for i in dup:
+        frames[i + 1] = frames[i]
     dimg = ctx.alloc(frames.nbytes).upload(frames)
     dn, dk, ds, dd = ctx.alloc(B * 4), ctx.alloc(B * K * 8), ctx.alloc(B * K * 4), ctx.alloc(B * K * 1024)
     dS, dp, dm = ctx.alloc((B - 1) * 4), ctx.alloc((B - 1) * K * 8), ctx.alloc((B - 1) * K * 4)
@@ -120,17 +124,17 @@ def test_stream_b33_filter0_vs_oracle(ctx, oracle):
     S, pairs, ms = dS.download((B - 1,), np.int32), dp.download((B - 1, K, 2), np.int32), dm.download((B - 1, K), np.float32)
     x0, x1, sc = dx0.download((K, 256), np.float32), dx1.download((K, 256), np.float32), dsc.download((K, K), np.float32)
     wlg = Wt.make_lightglue(seed=11)
-    total = 0
-    for i in (0, 7, tap_pair, 24, 31):
+    total, worst = 0, 0.0
+    for i in (0, 7, 8, tap_pair, 24, 31):
         kn = [oracle.normalize_keypoints(kxy[j, :n[j]].astype(np.float32), H, W) for j in (i, i + 1)]   # extraction is bit-exact (other tests)
         r = oracle.lightglue(wlg, kn[0], kn[1], desc[i, :n[i]], desc[i + 1, :n[i + 1]], filter_thr=0.0, debug=True)
         ok, dev, one_sided = lists_agree_borderline(pairs[i, :S[i]], ms[i, :S[i]], r["pairs"], r["ms"], r["scores"], K, filter_thr=0.0)
         assert ok and dev < LG_SCORE_TOL, (i, ok, dev, one_sided)
-        assert S[i] > 100, (i, S[i])          # mutual nearest neighbours of two 1024-keypoint sets: hundreds
-        total += int(S[i])
+        assert S[i] > (150 if i in dup else 20), (i, S[i])     # measured: 216 / 59 (random weights)
+        total, worst = total + int(S[i]), max(worst, dev)
         if i == tap_pair:
             assert np.abs(x0[:n[i]] - r["x0"]).max() < LG_STATE_TOL and np.abs(x1[:n[i + 1]] - r["x1"]).max() < LG_STATE_TOL
             assert np.abs(sc[:n[i], :n[i + 1]] - r["scores"]).max() < LG_LOGSCORE_RTOL * np.abs(r["scores"]).max()
-    print(f"stream B=33 filter 0: {total} matches over 5 pairs")
+    print(f"stream B=33 filter 0: {total} matches over 6 pairs, max |score dev| {worst:.2e}, S = {S.tolist()}")
     for d in (dimg, dn, dk, ds, dd, dS, dp, dm, dx0, dx1, dsc):
         d.free()

@@ -218,8 +218,9 @@ def test_stereo_frame_stream_vs_oracle(oracle, H, W, kmax):
         if prev is None:
             assert got["S"] == 0
         else:
-            lg = oracle.lightglue(wlg, oracle.normalize_keypoints(prev["kxy"][:prev["n"]].astype(np.float32), H, W),
-                                  oracle.normalize_keypoints(rl["kxy"][:nl].astype(np.float32), H, W), prev["desc"][:prev["n"]], rl["desc"][:nl])
+            # set 0 = the CURRENT left view, set 1 = the previous one: SearchBySP(mCurrentFrame, mLastFrame), Tracking.cc:3465
+            lg = oracle.lightglue(wlg, oracle.normalize_keypoints(rl["kxy"][:nl].astype(np.float32), H, W),
+                                  oracle.normalize_keypoints(prev["kxy"][:prev["n"]].astype(np.float32), H, W), rl["desc"][:nl], prev["desc"][:prev["n"]])
             assert got["S"] == lg["S"] and np.array_equal(got["pairs"][:lg["S"]], lg["pairs"])
             assert np.abs(got["ms"][:lg["S"]] - lg["ms"]).max() < LG_SCORE_TOL      # the stated fp32 tolerance (tests/tolerances.py)
         prev = rl
