@@ -180,7 +180,7 @@ int rfe_stereo_frame_dev(rfe_ctx* ctx, const uint8_t* imgL_dev, const uint8_t* i
                          float* score_dev, float* desc_dev, float* uRight_dev, float* depth_dev, int32_t* S_dev,
                          int32_t* pairs_dev, float* ms_dev);
 
-/* ---- descriptor helpers for the callers' classic searches, host pointers ----
+/* ---- descriptor helpers for the callers' classic searches, host pointers (device forms below) ----
  * rfe_l2_distance_matrix: out[i*N + j] = SPmatcher::DescriptorDistance_sp(a_i, b_j)
  *   (src/Matchers/SPmatcher.cc:2184-2189) for all pairs of a [M,256] x b [N,256]; the candidate lists of
  *   SearchByProjection / Fuse (SPmatcher.cc:1170-1354, 49-357) stay with the caller.
@@ -202,6 +202,22 @@ int rfe_binarize_descriptors(rfe_ctx* ctx, const float* desc, int rows, uint8_t*
 int rfe_search_candidates(rfe_ctx* ctx, const float* q, int Nq, const float* f, int Nf, const int32_t* offsets,
                           const int32_t* cand, const uint8_t* skip, int32_t* best_idx, float* best_dist, float* second_dist);
 int rfe_distinctive_descriptors(rfe_ctx* ctx, const float* desc, const int32_t* offsets, int Np, int32_t* best, float* median);
+
+/* Device-resident forms of the four helpers above (descriptors normally never leave HBM: they come out of rfe_extract_u8_dev /
+ * rfe_stereo_frame_dev, and the host forms re-upload 1 KB per descriptor per call): every pointer is a DEVICE pointer, the call is
+ * asynchronous on the ctx stream, the host forms are thin staging wrappers around these.  What the host forms validate and these
+ * cannot without a synchronisation is the caller's contract instead: offsets[0] = 0, offsets non-decreasing;
+ * rfe_search_candidates_dev ignores candidate indices outside [0, Nf) (SPmatcher.cc:1218-1262 semantics otherwise unchanged);
+ * rfe_distinctive_descriptors_dev (MapPoint.cc:438-530) takes `total` >= offsets[Np] (descriptor count) and `maxn` >= the largest
+ * observation count of any point (<= 8192) from the caller, and reports a point with more observations than maxn rounded up to
+ * a power of two as best = -2. */
+int rfe_l2_distance_matrix_dev(rfe_ctx* ctx, const float* a_dev, int M, const float* b_dev, int N, float* out_dev);
+int rfe_binarize_descriptors_dev(rfe_ctx* ctx, const float* desc_dev, int rows, uint8_t* out_dev);
+int rfe_search_candidates_dev(rfe_ctx* ctx, const float* q_dev, int Nq, const float* f_dev, int Nf, const int32_t* offsets_dev,
+                              const int32_t* cand_dev, const uint8_t* skip_dev, int32_t* best_idx_dev, float* best_dist_dev,
+                              float* second_dist_dev);
+int rfe_distinctive_descriptors_dev(rfe_ctx* ctx, const float* desc_dev, const int32_t* offsets_dev, int Np, int total, int maxn,
+                                    int32_t* best_dev, float* median_dev);
 
 /* ---- per-stage timing (hipEvent on the ctx stream), for bench.py's roofline object ----
  * Enable, run, then read back: names is a ';'-separated list of stage names, ms / calls the

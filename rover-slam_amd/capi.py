@@ -19,6 +19,7 @@ EXPORTS = [
     "rfe_memcpy_d2h", "rfe_extract_u8", "rfe_extract_u8_dev", "rfe_extract_u8_bin", "rfe_extract_u8_bin_dev", "rfe_match", "rfe_match_dev", "rfe_match_fused",
     "rfe_extract_match_stream_dev", "rfe_stereo_match", "rfe_stereo_match_dev", "rfe_stereo_frame_dev", "rfe_l2_distance_matrix", "rfe_binarize_descriptors",
     "rfe_search_candidates", "rfe_distinctive_descriptors",
+    "rfe_l2_distance_matrix_dev", "rfe_binarize_descriptors_dev", "rfe_search_candidates_dev", "rfe_distinctive_descriptors_dev",
     "rfe_profile_enable", "rfe_profile_filter", "rfe_profile_reset", "rfe_profile_read",
     "rfe_k_conv3x3", "rfe_k_linear", "rfe_k_scoremap", "rfe_k_lightglue_taps", "rfe_k_set_lightglue_tap",
 ]
@@ -71,6 +72,10 @@ lib.rfe_l2_distance_matrix.argtypes = [C.c_void_p, _fp, C.c_int, _fp, C.c_int, _
 lib.rfe_binarize_descriptors.argtypes = [C.c_void_p, _fp, C.c_int, _u8p]
 lib.rfe_search_candidates.argtypes = [C.c_void_p, _fp, C.c_int, _fp, C.c_int, _ip, _ip, _u8p, _ip, _fp, _fp]
 lib.rfe_distinctive_descriptors.argtypes = [C.c_void_p, _fp, _ip, C.c_int, _ip, _fp]
+lib.rfe_l2_distance_matrix_dev.argtypes = [C.c_void_p, _fp, C.c_int, _fp, C.c_int, _fp]
+lib.rfe_binarize_descriptors_dev.argtypes = [C.c_void_p, _fp, C.c_int, _u8p]
+lib.rfe_search_candidates_dev.argtypes = [C.c_void_p, _fp, C.c_int, _fp, C.c_int, _ip, _ip, _u8p, _ip, _fp, _fp]
+lib.rfe_distinctive_descriptors_dev.argtypes = [C.c_void_p, _fp, _ip, C.c_int, C.c_int, C.c_int, _ip, _fp]
 lib.rfe_profile_enable.argtypes = [C.c_void_p, C.c_int]
 lib.rfe_profile_filter.argtypes = [C.c_void_p, C.c_char_p]
 lib.rfe_profile_reset.argtypes = [C.c_void_p]

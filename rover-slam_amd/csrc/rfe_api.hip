@@ -1010,7 +1010,21 @@ extern "C" int rfe_stereo_frame_dev(rfe_ctx* c, const uint8_t* imgL, const uint8
     return RFE_OK;
 }
 
-// all-pairs DescriptorDistance_sp and descriptor binarisation, host pointers
+// =====================================================================================
+// descriptor helpers of the callers' classic searches.  The "_dev" forms take device pointers and are
+// asynchronous on the ctx stream (descriptors usually ARE device resident: they come out of rfe_extract_u8_dev /
+// rfe_stereo_frame_dev); the host-pointer forms validate, stage through ws_io and call them.
+// =====================================================================================
+extern "C" int rfe_l2_distance_matrix_dev(rfe_ctx* c, const float* a, int M, const float* b, int N, float* out) {
+    if (!c) return RFE_ERR_INVALID;
+    if (M < 0 || N < 0 || (M > 0 && N > 0 && (!a || !b || !out))) return fail(c, RFE_ERR_INVALID, "l2_distance_matrix: bad argument");
+    if (M == 0 || N == 0) return RFE_OK;
+    RFE_HIP(c, hipSetDevice(c->device));
+    { ProfScope ps(c, "l2_matrix"); launch_l2_matrix(c->stream, a, M, b, N, out); }
+    RFE_HIP(c, hipGetLastError());
+    return RFE_OK;
+}
+
 extern "C" int rfe_l2_distance_matrix(rfe_ctx* c, const float* a, int M, const float* b, int N, float* out) {
     if (!c) return RFE_ERR_INVALID;
     if (M < 0 || N < 0 || (M > 0 && N > 0 && (!a || !b || !out))) return fail(c, RFE_ERR_INVALID, "l2_distance_matrix: bad argument");
@@ -1022,10 +1036,20 @@ extern "C" int rfe_l2_distance_matrix(rfe_ctx* c, const float* a, int M, const f
     float* da = (float*)c->ws_io; float* db = (float*)((char*)c->ws_io + ba); float* dout = (float*)((char*)c->ws_io + ba + bb);
     RFE_HIP(c, hipMemcpyAsync(da, a, (size_t)M * 1024, hipMemcpyHostToDevice, c->stream));
     RFE_HIP(c, hipMemcpyAsync(db, b, (size_t)N * 1024, hipMemcpyHostToDevice, c->stream));
-    launch_l2_matrix(c->stream, da, M, db, N, dout);
-    RFE_HIP(c, hipGetLastError());
+    if ((rc = rfe_l2_distance_matrix_dev(c, da, M, db, N, dout))) return rc;
     RFE_HIP(c, hipMemcpyAsync(out, dout, (size_t)M * N * 4, hipMemcpyDeviceToHost, c->stream));
     RFE_HIP(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    return RFE_OK;
+}
+
+extern "C" int rfe_binarize_descriptors_dev(rfe_ctx* c, const float* desc, int rows, uint8_t* out) {
+    if (!c) return RFE_ERR_INVALID;
+    if (rows < 0 || (rows > 0 && (!desc || !out))) return fail(c, RFE_ERR_INVALID, "binarize_descriptors: bad argument");
+    if (rows == 0) return RFE_OK;
+    RFE_HIP(c, hipSetDevice(c->device));
+    launch_binarize(c->stream, desc, rows, out);
+    RFE_HIP(c, hipGetLastError());
     return RFE_OK;
 }
 
@@ -1039,14 +1063,30 @@ extern "C" int rfe_binarize_descriptors(rfe_ctx* c, const float* desc, int rows,
     if (rc) return rc;
     float* dd = (float*)c->ws_io; uint8_t* dout = (uint8_t*)c->ws_io + bd;
     RFE_HIP(c, hipMemcpyAsync(dd, desc, (size_t)rows * 1024, hipMemcpyHostToDevice, c->stream));
-    launch_binarize(c->stream, dd, rows, dout);
-    RFE_HIP(c, hipGetLastError());
+    if ((rc = rfe_binarize_descriptors_dev(c, dd, rows, dout))) return rc;
     RFE_HIP(c, hipMemcpyAsync(out, dout, (size_t)rows * 256, hipMemcpyDeviceToHost, c->stream));
     RFE_HIP(c, hipStreamSynchronize(c->stream));
     return RFE_OK;
 }
 
-// Classic-search descriptor arithmetic, host pointers.
+// best / second-best scan of SPmatcher::SearchByProjection1 (src/Matchers/SPmatcher.cc:1218-1248) over device-resident CSR
+// candidate lists.  The lists cannot be validated from the host without a synchronisation: the kernel ignores candidate
+// indices outside [0, Nf); offsets must be non-decreasing with offsets[0] = 0 (the caller's contract, as for the host form).
+extern "C" int rfe_search_candidates_dev(rfe_ctx* c, const float* q, int Nq, const float* f, int Nf, const int32_t* offsets,
+                                         const int32_t* cand, const uint8_t* skip, int32_t* best_idx, float* best_dist,
+                                         float* second_dist) {
+    if (!c) return RFE_ERR_INVALID;
+    if (Nq < 0 || Nf < 0) return fail(c, RFE_ERR_INVALID, "search_candidates: negative count");
+    if (Nq == 0) return RFE_OK;
+    if (!q || !offsets || !best_idx || !best_dist || !second_dist || (Nf > 0 && (!f || !cand)))
+        return fail(c, RFE_ERR_INVALID, "search_candidates: null pointer");
+    RFE_HIP(c, hipSetDevice(c->device));
+    { ProfScope ps(c, "search_candidates");
+      launch_search_candidates(c->stream, q, Nq, f, Nf, offsets, cand, skip, best_idx, best_dist, second_dist); }
+    RFE_HIP(c, hipGetLastError());
+    return RFE_OK;
+}
+
 extern "C" int rfe_search_candidates(rfe_ctx* c, const float* q, int Nq, const float* f, int Nf, const int32_t* offsets,
                                      const int32_t* cand, const uint8_t* skip, int32_t* best_idx, float* best_dist,
                                      float* second_dist) {
@@ -1076,16 +1116,32 @@ extern "C" int rfe_search_candidates(rfe_ctx* c, const float* q, int Nq, const f
     RFE_HIP(c, hipMemcpyAsync(doff, offsets, (size_t)(Nq + 1) * 4, hipMemcpyHostToDevice, s));
     if (nnz > 0) RFE_HIP(c, hipMemcpyAsync(dc, cand, (size_t)nnz * 4, hipMemcpyHostToDevice, s));
     if (skip && Nf > 0) RFE_HIP(c, hipMemcpyAsync(dsk, skip, (size_t)Nf, hipMemcpyHostToDevice, s));
-    {
-        ProfScope ps(c, "search_candidates");
-        launch_search_candidates(s, dq, Nq, df, doff, dc, skip ? dsk : nullptr, dbi, dbd, dsd);
-    }
-    RFE_HIP(c, hipGetLastError());
+    if ((rc = rfe_search_candidates_dev(c, dq, Nq, df, Nf, doff, dc, skip ? dsk : nullptr, dbi, dbd, dsd))) return rc;
     RFE_HIP(c, hipMemcpyAsync(best_idx, dbi, (size_t)Nq * 4, hipMemcpyDeviceToHost, s));
     RFE_HIP(c, hipMemcpyAsync(best_dist, dbd, (size_t)Nq * 4, hipMemcpyDeviceToHost, s));
     RFE_HIP(c, hipMemcpyAsync(second_dist, dsd, (size_t)Nq * 4, hipMemcpyDeviceToHost, s));
     RFE_HIP(c, hipStreamSynchronize(s));
     prof_collect(c);
+    return RFE_OK;
+}
+
+// MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:438-530) for Np map points whose observed descriptors and CSR
+// offsets live on the device.  `total` >= offsets[Np] (the number of descriptors, grid size) and `maxn` >= the largest
+// observation count (LDS row, <= 8192) come from the caller, who built the lists; a point with more observations than maxn
+// rounded up to a power of two is reported as best = -2 instead of computed.
+extern "C" int rfe_distinctive_descriptors_dev(rfe_ctx* c, const float* desc, const int32_t* offsets, int Np, int total, int maxn,
+                                               int32_t* best, float* median) {
+    if (!c) return RFE_ERR_INVALID;
+    if (Np < 0 || total < 0 || maxn < 0) return fail(c, RFE_ERR_INVALID, "distinctive_descriptors: negative count");
+    if (Np == 0) return RFE_OK;
+    if (!offsets || !best || !median || (total > 0 && !desc)) return fail(c, RFE_ERR_INVALID, "distinctive_descriptors: null pointer");
+    if (maxn > 8192) return fail(c, RFE_ERR_INVALID, "distinctive_descriptors: more than 8192 observations of one map point");
+    RFE_HIP(c, hipSetDevice(c->device));
+    int rc = ensure_ws(c, &c->ws_tmp, &c->ws_tmp_bytes, al((size_t)std::max(total, 1) * 4));   // per-descriptor medians
+    if (rc) return rc;
+    { ProfScope ps(c, "distinctive");
+      launch_distinctive(c->stream, desc, offsets, total, Np, std::max(maxn, 1), (float*)c->ws_tmp, best, median); }
+    RFE_HIP(c, hipGetLastError());
     return RFE_OK;
 }
 
@@ -1106,30 +1162,18 @@ extern "C" int rfe_distinctive_descriptors(rfe_ctx* c, const float* desc, const 
     const int total = offsets[Np];
     if (total > 0 && !desc) return fail(c, RFE_ERR_INVALID, "distinctive_descriptors: null descriptors");
     RFE_HIP(c, hipSetDevice(c->device));
-    std::vector<int32_t> point((size_t)std::max(total, 1));
-    for (int p = 0; p < Np; ++p)
-        for (int g = offsets[p]; g < offsets[p + 1]; ++g) point[g] = p;
-    const size_t bd = al((size_t)std::max(total, 1) * 1024), bo = al((size_t)(Np + 1) * 4), bp = al((size_t)std::max(total, 1) * 4),
-                 br = al((size_t)Np * 4);
-    int rc = ensure_ws(c, &c->ws_io, &c->ws_io_bytes, bd + bo + 2 * bp + 2 * br);
+    const size_t bd = al((size_t)std::max(total, 1) * 1024), bo = al((size_t)(Np + 1) * 4), br = al((size_t)Np * 4);
+    int rc = ensure_ws(c, &c->ws_io, &c->ws_io_bytes, bd + bo + 2 * br);
     if (rc) return rc;
     char* w = (char*)c->ws_io;
-    float* dd = (float*)w; w += bd; int32_t* doff = (int32_t*)w; w += bo; int32_t* dpt = (int32_t*)w; w += bp;
-    float* dmed = (float*)w; w += bp; int32_t* dbest = (int32_t*)w; w += br; float* dmedian = (float*)w;
+    float* dd = (float*)w; w += bd; int32_t* doff = (int32_t*)w; w += bo; int32_t* dbest = (int32_t*)w; w += br; float* dmedian = (float*)w;
     hipStream_t s = c->stream;
-    if (total > 0) {
-        RFE_HIP(c, hipMemcpyAsync(dd, desc, (size_t)total * 1024, hipMemcpyHostToDevice, s));
-        RFE_HIP(c, hipMemcpyAsync(dpt, point.data(), (size_t)total * 4, hipMemcpyHostToDevice, s));
-    }
+    if (total > 0) RFE_HIP(c, hipMemcpyAsync(dd, desc, (size_t)total * 1024, hipMemcpyHostToDevice, s));
     RFE_HIP(c, hipMemcpyAsync(doff, offsets, (size_t)(Np + 1) * 4, hipMemcpyHostToDevice, s));
-    {
-        ProfScope ps(c, "distinctive");
-        launch_distinctive(s, dd, doff, dpt, total, Np, maxn, dmed, dbest, dmedian);
-    }
-    RFE_HIP(c, hipGetLastError());
+    if ((rc = rfe_distinctive_descriptors_dev(c, dd, doff, Np, total, maxn, dbest, dmedian))) return rc;
     RFE_HIP(c, hipMemcpyAsync(best, dbest, (size_t)Np * 4, hipMemcpyDeviceToHost, s));
     RFE_HIP(c, hipMemcpyAsync(median, dmedian, (size_t)Np * 4, hipMemcpyDeviceToHost, s));
-    RFE_HIP(c, hipStreamSynchronize(s));   // also keeps `point` alive until its copy is done
+    RFE_HIP(c, hipStreamSynchronize(s));
     prof_collect(c);
     return RFE_OK;
 }

@@ -195,9 +195,9 @@ void launch_stereo_match_counts(hipStream_t s, const uint8_t* imgL, const uint8_
 
 void launch_l2_matrix(hipStream_t s, const float* a, int M, const float* b, int N, float* out);
 void launch_binarize(hipStream_t s, const float* d, int64_t rows, uint8_t* out);
-void launch_search_candidates(hipStream_t s, const float* q, int Nq, const float* f, const int32_t* offsets, const int32_t* cand,
+void launch_search_candidates(hipStream_t s, const float* q, int Nq, const float* f, int Nf, const int32_t* offsets, const int32_t* cand,
                               const uint8_t* skip, int32_t* best_idx, float* best_dist, float* second_dist);
-void launch_distinctive(hipStream_t s, const float* desc, const int32_t* offsets, const int32_t* point, int total, int Np, int maxn,
-                        float* med, int32_t* best, float* median);
+void launch_distinctive(hipStream_t s, const float* desc, const int32_t* offsets, int total /*>= offsets[Np]*/, int Np, int maxn,
+                        float* med /*[total] scratch*/, int32_t* best, float* median);
 
 }  // namespace rfe

@@ -23,7 +23,7 @@ __device__ __forceinline__ float desc_dist_wave(const float4 a, const float4 b) 
     return (float)sqrt(p);
 }
 
-__global__ __launch_bounds__(256) void search_candidates_kernel(const float* __restrict__ q, int Nq, const float* __restrict__ f,
+__global__ __launch_bounds__(256) void search_candidates_kernel(const float* __restrict__ q, int Nq, const float* __restrict__ f, int Nf,
                                                                 const int32_t* __restrict__ offsets, const int32_t* __restrict__ cand,
                                                                 const uint8_t* __restrict__ skip, int32_t* __restrict__ best_idx,
                                                                 float* __restrict__ best_dist, float* __restrict__ second_dist) {
@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256) void search_candidates_kernel(const float* __r
     const int e = offsets[i + 1];
     for (int c = offsets[i]; c < e; ++c) {
         const int idx = cand[c];
+        if ((unsigned)idx >= (unsigned)Nf) continue;   // device-resident lists cannot be validated by the host: stay inside f
         if (skip && skip[idx]) continue;
         const float dist = desc_dist_wave(a, reinterpret_cast<const float4*>(f + (size_t)idx * 256)[lane]);
         if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx = idx; }
@@ -43,25 +44,33 @@ __global__ __launch_bounds__(256) void search_candidates_kernel(const float* __r
     if (lane == 0) { best_idx[i] = bestIdx; best_dist[i] = bestDist; second_dist[i] = bestDist2; }
 }
 
-void launch_search_candidates(hipStream_t s, const float* q, int Nq, const float* f, const int32_t* offsets, const int32_t* cand,
+void launch_search_candidates(hipStream_t s, const float* q, int Nq, const float* f, int Nf, const int32_t* offsets, const int32_t* cand,
                               const uint8_t* skip, int32_t* best_idx, float* best_dist, float* second_dist) {
     if (Nq <= 0) return;
-    hipLaunchKernelGGL(search_candidates_kernel, dim3((Nq + 3) / 4), dim3(256), 0, s, q, Nq, f, offsets, cand, skip, best_idx,
+    hipLaunchKernelGGL(search_candidates_kernel, dim3((Nq + 3) / 4), dim3(256), 0, s, q, Nq, f, Nf, offsets, cand, skip, best_idx,
                        best_dist, second_dist);
 }
 
-// one wave (= one workgroup) per observed descriptor g; point[g] = its map point
+// one wave (= one workgroup) per observed descriptor g.  Its map point p (offsets[p] <= g < offsets[p+1]) is found by a binary
+// search over the device-resident offsets (empty points share an offset: the LAST p with offsets[p] <= g is the owner), so no
+// host-built descriptor -> point table is needed.  Points with more than P2 observations (the LDS row) are left to the pick kernel.
 __global__ __launch_bounds__(64) void distinctive_rows_kernel(const float* __restrict__ desc, const int32_t* __restrict__ offsets,
-                                                              const int32_t* __restrict__ point, int P2, float* __restrict__ med) {
+                                                              int Np, int P2, float* __restrict__ med) {
     extern __shared__ float row[];
     const int lane = threadIdx.x;
     const int g = blockIdx.x;
-    const int p = point[g];
+    if (g >= offsets[Np]) return;          // the grid is sized for the caller's `total`, an upper bound
+    int lo = 0, hi = Np;                   // invariant: offsets[lo] <= g < offsets[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (offsets[mid] <= g) lo = mid; else hi = mid;
+    }
+    const int p = lo;
     const int o = offsets[p], n = offsets[p + 1] - o;
+    if (n > P2) { if (lane == 0) med[g] = __builtin_inff(); return; }
     const float4 a = reinterpret_cast<const float4*>(desc + (size_t)g * 256)[lane];
     int p2 = 1;
     while (p2 < n) p2 <<= 1;
-    (void)P2;
     for (int j = 0; j < n; ++j) {
         const float d = (o + j == g) ? 0.f : desc_dist_wave(a, reinterpret_cast<const float4*>(desc + (size_t)(o + j) * 256)[lane]);
         if (lane == 0) row[j] = d;
@@ -83,12 +92,13 @@ __global__ __launch_bounds__(64) void distinctive_rows_kernel(const float* __res
     if (lane == 0) med[g] = row[(int)(0.5 * (n - 1))];
 }
 
-__global__ void distinctive_pick_kernel(const float* __restrict__ med, const int32_t* __restrict__ offsets, int Np,
+__global__ void distinctive_pick_kernel(const float* __restrict__ med, const int32_t* __restrict__ offsets, int Np, int maxn,
                                         int32_t* __restrict__ best, float* __restrict__ median) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= Np) return;
     const int o = offsets[p], n = offsets[p + 1] - o;
     if (n <= 0) { best[p] = -1; median[p] = 0.f; return; }
+    if (n > maxn) { best[p] = -2; median[p] = 0.f; return; }   // more observations than the caller's bound: reported, not computed
     float bm = 2147483647.0f; int bi = 0;
     for (int i = 0; i < n; ++i) {
         const float m = med[o + i];
@@ -97,15 +107,14 @@ __global__ void distinctive_pick_kernel(const float* __restrict__ med, const int
     best[p] = bi; median[p] = bm;
 }
 
-void launch_distinctive(hipStream_t s, const float* desc, const int32_t* offsets, const int32_t* point, int total, int Np, int maxn,
+void launch_distinctive(hipStream_t s, const float* desc, const int32_t* offsets, int total, int Np, int maxn,
                         float* med, int32_t* best, float* median) {
     if (Np <= 0) return;
-    if (total > 0) {
-        int P2 = 1;
-        while (P2 < maxn) P2 <<= 1;
-        hipLaunchKernelGGL(distinctive_rows_kernel, dim3(total), dim3(64), (size_t)P2 * 4, s, desc, offsets, point, P2, med);
-    }
-    hipLaunchKernelGGL(distinctive_pick_kernel, dim3((Np + 255) / 256), dim3(256), 0, s, med, offsets, Np, best, median);
+    int P2 = 1;
+    while (P2 < maxn) P2 <<= 1;
+    if (total > 0)
+        hipLaunchKernelGGL(distinctive_rows_kernel, dim3(total), dim3(64), (size_t)P2 * 4, s, desc, offsets, Np, P2, med);
+    hipLaunchKernelGGL(distinctive_pick_kernel, dim3((Np + 255) / 256), dim3(256), 0, s, med, offsets, Np, P2, best, median);
 }
 
 }  // namespace rfe

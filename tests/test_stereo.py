@@ -232,3 +232,78 @@ def test_stereo_frame_stream_vs_oracle(oracle, H, W, kmax):
     dimg.free()
     st.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_device_resident_search_helpers_match_oracle(oracle):
+    """rfe_search_candidates_dev / rfe_distinctive_descriptors_dev / rfe_l2_distance_matrix_dev /
+    rfe_binarize_descriptors_dev on buffers that never leave HBM -- the frame descriptors are the extractor's own device output
+    (rfe_extract_u8_dev), the CSR lists are uploaded once -- bit-exact against rfo_search_candidates /
+    rfo_distinctive_descriptors (SPmatcher.cc:1218-1262, MapPoint.cc:438-530), asynchronous on the ctx stream."""
+    from rover_slam_amd import capi
+    ctx = capi.Context(0)
+    ctx.set_weights(capi.KIND_SUPERPOINT, Wt.make_superpoint(seed=7))
+    H, W, K = 240, 320, 512
+    frames, _ = synth.make_frames(2, H, W, seed=12)
+    dev = lambda a: ctx.alloc(np.ascontiguousarray(a).nbytes).upload(a)
+    dimg = dev(frames)
+    dn, dk, ds, dd = ctx.alloc(2 * 4), ctx.alloc(2 * K * 8), ctx.alloc(2 * K * 4), ctx.alloc(2 * K * 1024)
+    ctx._chk(capi.lib.rfe_extract_u8_dev(ctx.h, dimg.ptr, H, W, W, 2, K, 0.0005, dn.ptr, dk.ptr, ds.ptr, dd.ptr))
+    n = dn.download((2,), np.int32)
+    desc = dd.download((2, K, 256), np.float32)
+    assert n.min() > 100
+    Nq, Nf = int(n[0]), int(n[1])
+    q_ptr, f_ptr = dd.ptr, dd.ptr + K * 1024                      # frame 0's descriptors query frame 1's, both still in HBM
+    # ---- search: candidate lists over frame 1's features (plus junk indices the device form must ignore)
+    rng = np.random.default_rng(3)
+    lens = rng.integers(0, 30, Nq)
+    off = np.zeros(Nq + 1, np.int32); off[1:] = np.cumsum(lens)
+    cand = rng.integers(0, Nf, off[-1]).astype(np.int32)
+    skip = (rng.random(Nf) < 0.2).astype(np.uint8)
+    junk = cand.copy()
+    bad = rng.random(junk.shape[0]) < 0.05
+    junk[bad] = np.where(rng.random(int(bad.sum())) < 0.5, -1 - rng.integers(0, 9, int(bad.sum())), Nf + rng.integers(0, 9, int(bad.sum())))
+    doff, dskip = dev(off), dev(skip)
+    dbi, dbd, dsd = ctx.alloc(Nq * 4), ctx.alloc(Nq * 4), ctx.alloc(Nq * 4)
+    for cd, sk in ((cand, skip), (cand, None), (junk, skip)):
+        dc = dev(cd)
+        ctx._chk(capi.lib.rfe_search_candidates_dev(ctx.h, q_ptr, Nq, f_ptr, Nf, doff.ptr, dc.ptr, dskip.ptr if sk is not None else None,
+                                                    dbi.ptr, dbd.ptr, dsd.ptr))
+        ctx.synchronize()
+        # reference: the oracle on the valid candidates only (out-of-range indices are ignored by contract)
+        keep = (cd >= 0) & (cd < Nf)
+        off_v = np.zeros(Nq + 1, np.int32); off_v[1:] = np.cumsum([int(keep[off[i]:off[i + 1]].sum()) for i in range(Nq)])
+        rbi, rbd, rsd = oracle.search_candidates(desc[0, :Nq], desc[1, :Nf], off_v, cd[keep], sk)
+        assert np.array_equal(dbi.download((Nq,), np.int32), rbi)
+        assert np.array_equal(dbd.download((Nq,), np.float32), rbd) and np.array_equal(dsd.download((Nq,), np.float32), rsd)
+        dc.free()
+    # ---- all-pairs distances and binarisation of device-resident descriptors
+    dout = ctx.alloc(Nq * Nf * 4)
+    ctx._chk(capi.lib.rfe_l2_distance_matrix_dev(ctx.h, q_ptr, Nq, f_ptr, Nf, dout.ptr))
+    host = np.empty((Nq, Nf), np.float32)
+    ctx.synchronize()
+    got = dout.download((Nq, Nf), np.float32)
+    ctx._chk(capi.lib.rfe_l2_distance_matrix(ctx.h, desc[0, :Nq].ctypes.data, Nq, np.ascontiguousarray(desc[1, :Nf]).ctypes.data, Nf, host.ctypes.data))
+    assert np.array_equal(got, host)
+    dbits = ctx.alloc(Nq * 256)
+    ctx._chk(capi.lib.rfe_binarize_descriptors_dev(ctx.h, q_ptr, Nq, dbits.ptr))
+    ctx.synchronize()
+    assert np.array_equal(dbits.download((Nq, 256), np.uint8), (desc[0, :Nq] > 0).astype(np.uint8))
+    # ---- distinctive descriptors: map points observing runs of frame 0's descriptors
+    lens2 = np.concatenate([[1, 2, 0, 3, 64, 65], rng.integers(1, 12, 40)]).astype(np.int32)
+    lens2 = lens2[np.cumsum(lens2) <= Nq]
+    off2 = np.zeros(len(lens2) + 1, np.int32); off2[1:] = np.cumsum(lens2)
+    Np, total = len(lens2), int(off2[-1])
+    doff2, dbest, dmed = dev(off2), ctx.alloc(Np * 4), ctx.alloc(Np * 4)
+    ctx._chk(capi.lib.rfe_distinctive_descriptors_dev(ctx.h, q_ptr, doff2.ptr, Np, total + 7, int(lens2.max()), dbest.ptr, dmed.ptr))   # total is an upper bound
+    ctx.synchronize()
+    rbest, rmed = oracle.distinctive_descriptors(desc[0, :total], off2)
+    assert np.array_equal(dbest.download((Np,), np.int32), rbest) and np.array_equal(dmed.download((Np,), np.float32), rmed)
+    # a bound smaller than the largest point: that point is reported (-2), the others are still right
+    ctx._chk(capi.lib.rfe_distinctive_descriptors_dev(ctx.h, q_ptr, doff2.ptr, Np, total, 16, dbest.ptr, dmed.ptr))
+    ctx.synchronize()
+    b16 = dbest.download((Np,), np.int32)
+    assert (b16[lens2 > 16] == -2).all() and np.array_equal(b16[lens2 <= 16], rbest[lens2 <= 16])
+    for b in (dimg, dn, dk, ds, dd, doff, dskip, dbi, dbd, dsd, dout, dbits, doff2, dbest, dmed):
+        b.free()
+    ctx.close()

@@ -19,6 +19,9 @@ LG_SCORE_TOL_SMALL = 1e-4   # <= 256 keypoints per side
 LG_STATE_TOL = 1e-4         # final token states x0 / x1
 LG_LOGSCORE_RTOL = 1e-5     # log-domain assignment matrix relative to its largest magnitude (|values| up to ~450, one fp32
                             # ulp there is 3e-5; measured 2.4e-3 absolute = 5.4e-6 relative)
+LG_LOGSCORE_ATOL = 1e-2     # the same matrix, absolute (used where the largest magnitude is small, e.g. two identical frames: the error of a
+                            # log-score is a sum of fp32 roundings of O(100) similarity logits and does not shrink with the largest entry; measured 3.8e-3);
+                            # every entry is ALSO compared as a probability, exp(score), within LG_SCORE_TOL
 
 
 def lists_agree(pairs_a, ms_a, pairs_b, ms_b, filter_thr=0.1, slack=5e-4):
