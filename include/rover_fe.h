@@ -244,6 +244,10 @@ int rfe_k_lightglue_taps(rfe_ctx* ctx, const float* k0n, const float* k1n, const
                          const float* d1, int M, int N, float* x0_dev, float* x1_dev,
                          float* scores_dev /*[M,N]*/);
 
+/* One FFN block of LightGlue with the loaded weights: out = x + ffn.3(gelu(LayerNorm(ffn.0([x | second])))) for `rows` token rows
+ * (x, second, out: device [rows,256]; out may not alias x), self (cross = 0) or cross block of `layer`.  Goes through the forward's
+ * own code, so the row count selects the tiling: >= 32768 rows = throughput tiles with the fused LayerNorm + GELU. */
+int rfe_k_lightglue_ffn(rfe_ctx* ctx, int layer, int cross, const float* x_dev, const float* second_dev, int rows, float* out_dev);
 /* One-shot tap for the NEXT LightGlue forward of this ctx, whichever entry point runs it (rfe_match[_dev] with P pairs,
  * rfe_extract_match_stream_dev, rfe_stereo_frame_dev) and therefore whichever tiling it selects: after the last layer the final
  * token states of pair `pair` are copied to x0_dev / x1_dev ([L,256] each, L = max(Mmax,Nmax) rounded up to 4; rows past the

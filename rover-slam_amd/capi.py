@@ -21,7 +21,7 @@ EXPORTS = [
     "rfe_search_candidates", "rfe_distinctive_descriptors",
     "rfe_l2_distance_matrix_dev", "rfe_binarize_descriptors_dev", "rfe_search_candidates_dev", "rfe_distinctive_descriptors_dev",
     "rfe_profile_enable", "rfe_profile_filter", "rfe_profile_reset", "rfe_profile_read",
-    "rfe_k_conv3x3", "rfe_k_linear", "rfe_k_scoremap", "rfe_k_lightglue_taps", "rfe_k_set_lightglue_tap",
+    "rfe_k_conv3x3", "rfe_k_linear", "rfe_k_scoremap", "rfe_k_lightglue_taps", "rfe_k_set_lightglue_tap", "rfe_k_lightglue_ffn",
 ]
 
 if not os.path.exists(LIB_PATH):
@@ -85,6 +85,7 @@ lib.rfe_k_linear.argtypes = [C.c_void_p, _fp, C.c_int, C.c_int, _fp, _fp, C.c_in
 lib.rfe_k_scoremap.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]
 lib.rfe_k_lightglue_taps.argtypes = [C.c_void_p, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]
 lib.rfe_k_set_lightglue_tap.argtypes = [C.c_void_p, C.c_int, _fp, _fp, _fp]
+lib.rfe_k_lightglue_ffn.argtypes = [C.c_void_p, C.c_int, C.c_int, _fp, _fp, C.c_int, _fp]
 
 
 class RfeError(RuntimeError):

@@ -100,18 +100,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
         int row = lrow + 32 * it; row = row < nlast ? row : nlast;
         boff[it] = row * g.ldb + lkq * 4;
     }
-    // LNA: LayerNorm statistics of this thread's A rows from the producer's partial sums (one pass: var = E[x^2] - mean^2)
+    // LNA: LayerNorm statistics of this thread's A rows from the producer's partials.  Each partial is (mean, M2 = sum of squared
+    // deviations from that mean) of NPART = K / stats_p columns; they are merged with the parallel-variance formula
+    //   mean = avg(mean_p),  M2 = sum(M2_p) + NPART * sum((mean_p - mean)^2),  var = M2 / K
+    // -- no E[x^2] - mean^2 anywhere, so rows with |mean| >> std (a large ffn.0 bias in real weights) keep their variance
     float ln_mean[A_IT], ln_rstd[A_IT];
     if (LNA) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             int row = lrow + 32 * it; row = row < mlast ? row : mlast;
             const float* sp = g.stats_in + ((size_t)(m0 + row) + (size_t)z * g.M) * g.stats_p * 2;
-            float s1 = 0.f, s2 = 0.f;
-            for (int p = 0; p < g.stats_p; ++p) { s1 += sp[2 * p]; s2 += sp[2 * p + 1]; }
-            const float inv = 1.0f / (float)g.K, mean = s1 * inv;
-            float var = s2 * inv - mean * mean;
-            var = var > 0.f ? var : 0.f;
+            float ms = 0.f, m2 = 0.f;
+            for (int p = 0; p < g.stats_p; ++p) { ms += sp[2 * p]; m2 += sp[2 * p + 1]; }
+            const float mean = ms / (float)g.stats_p;
+            float dev = 0.f;
+            for (int p = 0; p < g.stats_p; ++p) { const float d = sp[2 * p] - mean; dev = fmaf(d, d, dev); }
+            const float var = (m2 + dev * ((float)g.K / (float)g.stats_p)) / (float)g.K;
             ln_mean[it] = mean; ln_rstd[it] = 1.0f / sqrtf(var + 1e-5f);
         }
     }
@@ -294,38 +298,51 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
             }
     }
     if (g.stats_out) {
-        // Per-row (sum, sum of squares) of this wave's NB*32 stored columns.  A lane holds T = MB*16 rows (one value per row after
-        // the in-lane sum over its NB columns); the 32 lanes of a half-wave hold the same rows for 32 different columns.  Butterfly
-        // that halves the rows kept per lane at every step (T/2, ..., 1 exchanges instead of 5 T): lane i ends with row i's total.
+        // Per-row LayerNorm partials of this wave's NB*32 stored columns, as (mean, M2 = sum of squared deviations from that mean):
+        // a lane first reduces its own NB values of a row (two passes over registers), then the 32 lanes of a half-wave -- the same
+        // rows, 32 different columns -- are merged with the parallel-variance formula for equal counts c
+        //   mean = (mean_a + mean_b) / 2,   M2 = M2_a + M2_b + (mean_b - mean_a)^2 * c / 2
+        // in a butterfly that halves the rows kept per lane at every step (T/2, ..., 1 exchanges instead of 5 T): lane i ends
+        // with row i's partial.  Shifted data throughout: no sum of raw squares that would cancel for |mean| >> std.
+        // (launch_gemm_nt only passes stats_out when N is a whole number of column tiles: every column is a real column.)
         constexpr int T = MB * 16;
-        float s1[T], s2[T];
+        float sm[T], s2[T];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float a1 = 0.f, a2 = 0.f;
+                float v[NB], a1 = 0.f;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    const int n = n0 + (wn * NB + nb) * 32 + i;
-                    float v = acc[mb][nb][r] * g.alpha;
-                    if (g.relu) v = fmaxf(v, 0.f);
-                    if (n >= g.N) v = 0.f;
-                    a1 += v; a2 = fmaf(v, v, a2);
+                    v[nb] = acc[mb][nb][r] * g.alpha;
+                    if (g.relu) v[nb] = fmaxf(v[nb], 0.f);
+                    a1 += v[nb];
                 }
-                s1[mb * 16 + r] = a1; s2[mb * 16 + r] = a2;
+                const float mu = a1 * (1.0f / NB);
+                float a2 = 0.f;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) { const float d = v[nb] - mu; a2 = fmaf(d, d, a2); }
+                sm[mb * 16 + r] = mu; s2[mb * 16 + r] = a2;
             }
+        float cnt_half = 0.5f * NB;     // c / 2 of the groups being merged
 #pragma unroll
         for (int o = T / 2; o >= 1; o >>= 1) {
             const bool up = (i & o) != 0;
 #pragma unroll
             for (int j = 0; j < o; ++j) {
-                const float k1 = up ? s1[j + o] : s1[j], t1 = up ? s1[j] : s1[j + o];
+                const float km = up ? sm[j + o] : sm[j], tm = up ? sm[j] : sm[j + o];
                 const float k2 = up ? s2[j + o] : s2[j], t2 = up ? s2[j] : s2[j + o];
-                s1[j] = k1 + __shfl_xor(t1, o);
-                s2[j] = k2 + __shfl_xor(t2, o);
+                const float om = __shfl_xor(tm, o), o2 = __shfl_xor(t2, o);
+                const float d = om - km;
+                sm[j] = 0.5f * (km + om);
+                s2[j] = (k2 + o2) + d * d * cnt_half;
             }
+            cnt_half *= 2.0f;
         }
-        if (T < 32) { s1[0] += __shfl_xor(s1[0], 16); s2[0] += __shfl_xor(s2[0], 16); }   // 16 rows on 32 lanes: lane bit 4 still to fold
+        if (T < 32) {   // 16 rows on 32 lanes: lane bit 4 still to fold
+            const float om = __shfl_xor(sm[0], 16), o2 = __shfl_xor(s2[0], 16), d = om - sm[0];
+            s2[0] = (s2[0] + o2) + d * d * cnt_half; sm[0] = 0.5f * (sm[0] + om);
+        }
         // lane i (< T) of half h now holds local row t = i: mb = t / 16, r = t % 16 -> tile row (r & 3) + 8 (r >> 2) + 4 h
         if (i < T) {
             const int r = i & 15;
@@ -333,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
             if (m < M) {
                 const int P = (int)gridDim.x * 2;
                 float* sp = g.stats_out + (((size_t)m + (size_t)z * g.M) * P + blockIdx.x * 2 + wn) * 2;
-                sp[0] = s1[0]; sp[1] = s2[0];
+                sp[0] = sm[0]; sp[1] = s2[0];
             }
         }
     }
@@ -370,7 +387,7 @@ int launch_gemm_nt(hipStream_t s, const GemmArgs& g_in) {
     // workgroup per CU) the fused normalisation puts the erf on the critical path and measured slower than the stand-alone pass
     // (one pair: ffn.0 + ffn.3 + LN 0.74 -> 0.89 ms); the caller falls back to it when 0 comes back.
     const bool big = (g.N % 256 == 0 && tiles(128, 256) >= 256) || tiles(128, 128) >= 256 || g.M > 8192;
-    if (!big) g.stats_out = nullptr;
+    if (!big || g.N % 256) g.stats_out = nullptr;   // partials cover whole column tiles only
     int ntiles;
     if (g.N % 256 == 0 && tiles(128, 256) >= 256) { ntiles = g.N / 256; RFE_GEMM_GO(2, 4, dim3(g.N / 256, (g.M + 127) / 128, batch)); }
     else if (tiles(128, 128) >= 256 || g.M > 8192) { ntiles = (g.N + 127) / 128; RFE_GEMM_GO(2, 2, dim3((g.N + 127) / 128, (g.M + 127) / 128, batch)); }

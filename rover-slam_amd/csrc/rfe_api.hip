@@ -1264,6 +1264,27 @@ extern "C" int rfe_k_scoremap(rfe_ctx* c, const uint8_t* img, int H, int W, int 
     return RFE_OK;
 }
 
+// x + ffn([x | second]) of one LightGlue block with the loaded weights (unfolded W1: `second` is the attention message), through
+// the same lg_ffn the forward uses -- so `rows` selects the path: >= 32768 rows take the 128x256 tiles with the LayerNorm + GELU
+// fused across ffn.0 / ffn.3, a few thousand rows the 64-row tiles with the stand-alone lg_ln_gelu pass.
+extern "C" int rfe_k_lightglue_ffn(rfe_ctx* c, int layer, int cross, const float* x, const float* second, int rows, float* out) {
+    int rc = lg_check(c, 1, 4, 4);
+    if (rc) return rc;
+    if (layer < 0 || layer >= LG_LAYERS || rows <= 0 || !x || !second || !out) return fail(c, RFE_ERR_INVALID, "k_lightglue_ffn: bad argument");
+    RFE_HIP(c, hipSetDevice(c->device));
+    const int L = 1024, P = (rows + 2 * L - 1) / (2 * L);
+    if ((rc = ensure_ws(c, &c->ws_lg, &c->ws_lg_bytes, lg_ws_bytes(P, L)))) return rc;
+    LgBuffers b;
+    lg_carve(c->ws_lg, P, L, b);
+    const LgLayerDev& Lw = c->lg.L[layer];
+    RFE_HIP(c, hipMemcpyAsync(out, x, (size_t)rows * 1024, hipMemcpyDeviceToDevice, c->stream));
+    if (cross) lg_ffn(c, b, out, second, rows, Lw.cw1, Lw.cb1, Lw.clng, Lw.clnb, Lw.cw2, Lw.cb2);
+    else lg_ffn(c, b, out, second, rows, Lw.w1, Lw.b1, Lw.lng, Lw.lnb, Lw.w2, Lw.b2);
+    RFE_HIP(c, hipGetLastError());
+    RFE_HIP(c, hipStreamSynchronize(c->stream));
+    return RFE_OK;
+}
+
 extern "C" int rfe_k_set_lightglue_tap(rfe_ctx* c, int pair, float* x0, float* x1, float* scores) {
     if (!c) return RFE_ERR_INVALID;
     if (pair < 0) { c->tap.armed = false; return RFE_OK; }

@@ -78,7 +78,8 @@ struct GemmArgs {
     const int* m_valid;               // optional per-batch valid row count (rows >= m_valid skipped)
     int batch;
     // LayerNorm(N) + GELU fused across two GEMMs (LightGlue ffn.0 -> LN -> GELU -> ffn.3): the producer's epilogue writes per-row
-    // partial (sum, sum of squares) of what it stores -- one pair per (column tile, wave column): stats_out [M][P][2], P returned by
+    // partial (mean, sum of squared deviations from it) of what it stores -- one pair per (column tile, wave column) = per 128
+    // columns: stats_out [M][P][2], P returned by
     // launch_gemm_nt --, the consumer normalises its A operand while staging it: gelu(((a - mean) * rstd) * ln_g[k] + ln_b[k])
     float* stats_out;
     const float* stats_in; int stats_p; const float* ln_g; const float* ln_b;

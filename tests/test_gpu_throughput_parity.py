@@ -141,3 +141,45 @@ def test_stream_b33_filter0_vs_oracle(ctx, oracle):
     print(f"stream B=33 filter 0: {total} matches over 6 pairs, max |score dev| {worst:.2e}, S = {S.tolist()}")
     for d in (dimg, dn, dk, ds, dd, dS, dp, dm, dx0, dx1, dsc):
         d.free()
+
+
+def test_fused_layernorm_rows_with_large_mean(ctx):
+    """the LayerNorm statistics of the fused ffn.0 -> LN -> GELU -> ffn.3 path come from per-tile partials; a one-pass
+    E[x^2] - mean^2 would cancel when |mean| >> std, which seeded synthetic weights never produce but real ones may.  Here ffn.0's
+    bias is raised by 1000 (rows of mean ~1000, std ~1): the fused throughput path (32 768 rows), the stand-alone lg_ln_gelu
+    path (the same rows in chunks of 4096: 64-row tiles) and a float64 evaluation must agree."""
+    from rover_slam_amd import capi
+    from scipy.special import erf
+    w = Wt.make_lightglue(seed=11)
+    man, _ = Wt.lg_manifest()
+    t = {name: (off, shape) for name, off, shape in man}
+    off, shape = t["layers.0.self.b1"]
+    w2 = w.copy()
+    w2[off:off + 512] += np.float32(1000.0)
+    c2 = capi.Context(0)
+    c2.set_weights(capi.KIND_LIGHTGLUE, w2)
+    rows = 32768
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((rows, 256)).astype(np.float32)
+    s = rng.standard_normal((rows, 256)).astype(np.float32)
+    dx, dsec, dout = c2.alloc(x.nbytes).upload(x), c2.alloc(s.nbytes).upload(s), c2.alloc(x.nbytes)
+    c2._chk(capi.lib.rfe_k_lightglue_ffn(c2.h, 0, 0, dx.ptr, dsec.ptr, rows, dout.ptr))
+    fused = dout.download((rows, 256), np.float32)
+    chunk = 4096
+    alone = np.empty_like(fused)
+    for r0 in range(0, rows, chunk):
+        c2._chk(capi.lib.rfe_k_lightglue_ffn(c2.h, 0, 0, dx.ptr + r0 * 1024, dsec.ptr + r0 * 1024, chunk, dout.ptr))
+        alone[r0:r0 + chunk] = dout.download((chunk, 256), np.float32)
+    g = lambda name: w2[t[name][0]:t[name][0] + int(np.prod(t[name][1]))].reshape(t[name][1]).astype(np.float64)
+    sel = rng.choice(rows, 512, replace=False)
+    h = np.concatenate([x[sel], s[sel]], 1).astype(np.float64) @ g("layers.0.self.W1").T + g("layers.0.self.b1")
+    assert h.mean() > 900 and h.std(axis=1).mean() < 5
+    mu, var = h.mean(1, keepdims=True), h.var(1, keepdims=True)
+    hn = (h - mu) / np.sqrt(var + 1e-5) * g("layers.0.self.ln_g") + g("layers.0.self.ln_b")
+    ref = x[sel] + (0.5 * hn * (1 + erf(hn / np.sqrt(2.0)))) @ g("layers.0.self.W2").T + g("layers.0.self.b2")
+    d_f, d_a, d_fa = np.abs(fused[sel] - ref).max(), np.abs(alone[sel] - ref).max(), np.abs(fused - alone).max()
+    print(f"large-mean rows: fused vs f64 {d_f:.2e}, stand-alone vs f64 {d_a:.2e}, fused vs stand-alone {d_fa:.2e}")
+    assert d_f < 3e-3 and d_a < 3e-3 and d_fa < 3e-3, (d_f, d_a, d_fa)
+    for b in (dx, dsec, dout):
+        b.free()
+    c2.close()
