@@ -219,6 +219,40 @@ int rfe_search_candidates_dev(rfe_ctx* ctx, const float* q_dev, int Nq, const fl
 int rfe_distinctive_descriptors_dev(rfe_ctx* ctx, const float* desc_dev, const int32_t* offsets_dev, int Np, int total, int maxn,
                                     int32_t* best_dev, float* median_dev);
 
+/* ---- multi-device pool (BASELINE configs[3] for a C / C++ host) ----
+ * The reference runs on ONE device (device_id = 0, src/Extractors/superpoint_onnx.cc:19, src/Matchers/lightglue_onnx.cpp:24) and
+ * is a C++ program (src/Tracking.cc:645-651); a pool gives such a host the frame sharding of rover-slam_amd/sharding.py without
+ * Python: one ctx + one host worker thread per member device.  A stream of F frames has F - 1 consecutive pairs; they are split
+ * as evenly as possible (rfe_pool_shard), member r extracts its pairs' frames -- ONE overlap frame with its neighbour, no
+ * inter-device dependency -- and matches them; every member's results are then gathered into one root buffer on member 0's device
+ * in global frame / pair order and copied to the caller's HOST arrays (layouts as rfe_extract_match_stream_dev with B = F;
+ * score / desc may be NULL = not gathered).
+ * transport: RFE_POOL_RCCL = grouped ncclSend / ncclRecv into the root (librccl is dlopen'ed at pool creation; needs pairwise
+ * distinct devices), RFE_POOL_COPY = peer / device-to-device copies issued by the root (members may share a device),
+ * RFE_POOL_AUTO = RCCL when the pool has more than one member and the communicators are up, else COPY.
+ * `devices` may name one device several times (functional tests on a one-GPU box; weights are then shared, see rfe_weights_id).
+ * A pool is single-caller like a ctx.  rfe_pool_ctx exposes a member's ctx (options, profiling); do not run it while a pool call
+ * is in flight. */
+typedef struct rfe_pool rfe_pool;
+#define RFE_POOL_AUTO 0
+#define RFE_POOL_RCCL 1
+#define RFE_POOL_COPY 2
+int rfe_pool_create(const int* devices, int n, rfe_pool** out);
+void rfe_pool_destroy(rfe_pool* pool);
+const char* rfe_pool_last_error(rfe_pool* pool); /* pool may be NULL: last error of a failed rfe_pool_create */
+int rfe_pool_size(rfe_pool* pool);
+rfe_ctx* rfe_pool_ctx(rfe_pool* pool, int member);
+int rfe_pool_has_rccl(rfe_pool* pool);           /* 1 = RCCL communicators are up */
+int rfe_pool_set_weights(rfe_pool* pool, int kind, const float* blob, int64_t count);
+int rfe_pool_load_weights(rfe_pool* pool, const char* sp_path, const char* lg_path);
+int rfe_pool_set_option(rfe_pool* pool, int option, int value);
+/* the sharding rule itself (pure function, no device): member `member` of n extracts frames [first_frame, first_frame + frames)
+ * of an F-frame stream and owns `pairs` consecutive pairs starting at first_frame (frames = pairs + 1; 0 / 0 = idle member) */
+int rfe_pool_shard(int F, int n, int member, int* first_frame, int* frames, int* pairs);
+int rfe_pool_extract_match_stream(rfe_pool* pool, const uint8_t* img_host, int H, int W, int stride, int F, int Kmax, float thr,
+                                  float filter_thr, int transport, int32_t* n, int32_t* kxy, float* score, float* desc,
+                                  int32_t* S, int32_t* pairs, float* ms);
+
 /* ---- per-stage timing (hipEvent on the ctx stream), for bench.py's roofline object ----
  * Enable, run, then read back: names is a ';'-separated list of stage names, ms / calls the
  * accumulated time and launch count per stage since the last reset.

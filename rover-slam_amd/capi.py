@@ -20,6 +20,8 @@ EXPORTS = [
     "rfe_extract_match_stream_dev", "rfe_stereo_match", "rfe_stereo_match_dev", "rfe_stereo_frame_dev", "rfe_l2_distance_matrix", "rfe_binarize_descriptors",
     "rfe_search_candidates", "rfe_distinctive_descriptors",
     "rfe_l2_distance_matrix_dev", "rfe_binarize_descriptors_dev", "rfe_search_candidates_dev", "rfe_distinctive_descriptors_dev",
+    "rfe_pool_create", "rfe_pool_destroy", "rfe_pool_last_error", "rfe_pool_size", "rfe_pool_ctx", "rfe_pool_has_rccl", "rfe_pool_set_weights",
+    "rfe_pool_load_weights", "rfe_pool_set_option", "rfe_pool_shard", "rfe_pool_extract_match_stream",
     "rfe_profile_enable", "rfe_profile_filter", "rfe_profile_reset", "rfe_profile_read",
     "rfe_k_conv3x3", "rfe_k_linear", "rfe_k_scoremap", "rfe_k_lightglue_taps", "rfe_k_set_lightglue_tap", "rfe_k_lightglue_ffn",
 ]
@@ -86,6 +88,24 @@ lib.rfe_k_scoremap.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_
 lib.rfe_k_lightglue_taps.argtypes = [C.c_void_p, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]
 lib.rfe_k_set_lightglue_tap.argtypes = [C.c_void_p, C.c_int, _fp, _fp, _fp]
 lib.rfe_k_lightglue_ffn.argtypes = [C.c_void_p, C.c_int, C.c_int, _fp, _fp, C.c_int, _fp]
+
+
+POOL_AUTO, POOL_RCCL, POOL_COPY = 0, 1, 2
+lib.rfe_pool_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+lib.rfe_pool_destroy.argtypes = [C.c_void_p]
+lib.rfe_pool_destroy.restype = None
+lib.rfe_pool_last_error.argtypes = [C.c_void_p]
+lib.rfe_pool_last_error.restype = C.c_char_p
+lib.rfe_pool_size.argtypes = [C.c_void_p]
+lib.rfe_pool_ctx.argtypes = [C.c_void_p, C.c_int]
+lib.rfe_pool_ctx.restype = C.c_void_p
+lib.rfe_pool_has_rccl.argtypes = [C.c_void_p]
+lib.rfe_pool_set_weights.argtypes = [C.c_void_p, C.c_int, _fp, C.c_int64]
+lib.rfe_pool_load_weights.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+lib.rfe_pool_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
+lib.rfe_pool_shard.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+lib.rfe_pool_extract_match_stream.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
+                                              _ip, _ip, _fp, _fp, _ip, _ip, _fp]
 
 
 class RfeError(RuntimeError):
@@ -165,6 +185,75 @@ class StereoStream:
         for b in self.bufs.values():
             b.free()
         self.bufs = {}
+
+
+def pool_shard(F, n, member):
+    """rfe_pool_shard: (first_frame, frames, pairs) of `member` among n for an F-frame stream (pure function, no device)."""
+    a, b, c = C.c_int(), C.c_int(), C.c_int()
+    rc = lib.rfe_pool_shard(F, n, member, C.byref(a), C.byref(b), C.byref(c))
+    if rc < 0:
+        raise RfeError(f"rfe_pool_shard({F}, {n}, {member}) failed ({rc})")
+    return a.value, b.value, c.value
+
+
+class Pool:
+    """rfe_pool: one ctx + host thread per member device; a stream of F frames sharded with one overlap frame, results
+    gathered into member 0's device (RCCL or copies) and returned as host arrays in global order."""
+
+    def __init__(self, devices):
+        devs = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = lib.rfe_pool_create(devs, len(devices), C.byref(h))
+        if rc != 0:
+            raise RfeError(f"rfe_pool_create failed ({rc}): {lib.rfe_pool_last_error(None).decode()}")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib.rfe_pool_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise RfeError(f"librover_fe pool error {rc}: {lib.rfe_pool_last_error(self.h).decode()}")
+        return rc
+
+    @property
+    def size(self):
+        return lib.rfe_pool_size(self.h)
+
+    @property
+    def has_rccl(self):
+        return bool(lib.rfe_pool_has_rccl(self.h))
+
+    def set_weights(self, kind, blob):
+        blob = np.ascontiguousarray(blob, np.float32)
+        self._chk(lib.rfe_pool_set_weights(self.h, kind, blob.ctypes.data, blob.size))
+
+    def set_option(self, option, value):
+        self._chk(lib.rfe_pool_set_option(self.h, option, int(value)))
+
+    def extract_match_stream(self, frames_u8, kmax=1024, thr=0.0005, filter_thr=0.1, transport=POOL_AUTO, with_desc=True):
+        """frames_u8: host [F,H,W] uint8.  Returns dict n [F], kxy [F,K,2], score / desc (with_desc), S [F-1], pairs [F-1,K,2], ms [F-1,K]."""
+        img = np.ascontiguousarray(frames_u8, np.uint8)
+        F, H, W = img.shape
+        P = max(F - 1, 1)
+        out = {"n": np.zeros((F,), np.int32), "kxy": np.zeros((F, kmax, 2), np.int32), "S": np.zeros((P,), np.int32),
+               "pairs": np.zeros((P, kmax, 2), np.int32), "ms": np.zeros((P, kmax), np.float32)}
+        if with_desc:
+            out["score"] = np.zeros((F, kmax), np.float32)
+            out["desc"] = np.zeros((F, kmax, 256), np.float32)
+        self._chk(lib.rfe_pool_extract_match_stream(self.h, img.ctypes.data, H, W, W, F, kmax, thr, filter_thr, transport, out["n"].ctypes.data,
+                                                    out["kxy"].ctypes.data, out["score"].ctypes.data if with_desc else None,
+                                                    out["desc"].ctypes.data if with_desc else None, out["S"].ctypes.data,
+                                                    out["pairs"].ctypes.data, out["ms"].ctypes.data))
+        return out
 
 
 class Context:

@@ -1,0 +1,156 @@
+"""The multi-device pool of the C ABI (rfe_pool_*, rover-slam_amd/csrc/rfe_pool.hip): configs[3] for a C / C++ host.
+
+CPU: the sharding rule (rfe_pool_shard) against rover-slam_amd/sharding.py and its own invariants; creation fails loudly without a GPU.
+GPU: a pool of one through RCCL (self send / receive into the root buffer) equals the single-ctx stream call bit for bit; three
+members sharing the one device of the box through the COPY transport equal (a) single-ctx calls on each member's shard bit for bit
+(the stitching is right) and (b) the one-ctx call on the whole stream (SuperPoint bit-exact, match lists identical up to fp32
+borderline flips: smaller shards select other tilings).  RCCL between DIFFERENT devices needs an N-GPU node: unmeasured here.
+Reference contrast: one device, src/Extractors/superpoint_onnx.cc:19."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from rover_slam_amd import sharding, synth, weights as Wt
+
+
+def test_pool_shard_matches_python_sharding_and_covers_the_stream():
+    from rover_slam_amd import capi
+    for per, world in [(32, 1), (32, 8), (4, 3), (1, 5)]:
+        F = per * world + 1
+        for r in range(world):
+            sh = sharding.shard_frames(per, world, r)
+            assert capi.pool_shard(F, world, r) == (sh.start, sh.frames, sh.owned)
+    for F in range(1, 40):
+        for n in range(1, 9):
+            pairs_seen, nxt = 0, 0
+            for r in range(n):
+                first, frames, own = capi.pool_shard(F, n, r)
+                if own:
+                    assert first == nxt and frames == own + 1      # shards are consecutive, one overlap frame each
+                    nxt = first + own
+                else:
+                    assert frames == (1 if (F == 1 and r == 0) else 0)
+                pairs_seen += own
+            assert pairs_seen == F - 1 and (nxt == F - 1 or F == 1)
+            owns = [capi.pool_shard(F, n, r)[2] for r in range(n)]
+            assert max(owns) - min(owns) <= 1                      # as even as possible
+    a = C.c_int()
+    assert capi.lib.rfe_pool_shard(0, 1, 0, C.byref(a), None, None) < 0 and capi.lib.rfe_pool_shard(5, 2, 2, None, None, None) < 0
+
+
+def test_pool_fails_loudly_without_gpu_and_on_bad_arguments():
+    import torch
+    from rover_slam_amd import capi
+    h = C.c_void_p()
+    assert capi.lib.rfe_pool_create(None, 1, C.byref(h)) == -1 and h.value is None
+    assert capi.lib.rfe_pool_create((C.c_int * 1)(0), 0, C.byref(h)) == -1
+    assert capi.lib.rfe_pool_size(None) == 0 and capi.lib.rfe_pool_ctx(None, 0) is None
+    assert capi.lib.rfe_pool_extract_match_stream(None, None, 8, 8, 8, 1, 1, 0.0, 0.0, 0, None, None, None, None, None, None, None) < 0
+    if torch.cuda.device_count() == 0:
+        with pytest.raises(capi.RfeError) as e:
+            capi.Pool([0])
+        assert "no HIP device" in str(e.value)
+
+
+def _same_matches(a, b, lo=0, hi=None, b_lo=0):
+    """S equal and, pair by pair, the first S entries of pairs / ms equal (entries past S are unspecified)."""
+    hi = len(a["S"]) if hi is None else hi
+    for p in range(lo, hi):
+        q = p - lo + b_lo
+        s = int(a["S"][p])
+        if s != int(b["S"][q]) or not np.array_equal(a["pairs"][p, :s], b["pairs"][q, :s]) or not np.array_equal(a["ms"][p, :s], b["ms"][q, :s]):
+            return False
+    return True
+
+
+def _single_ctx_stream(ctx, frames, kmax):
+    from rover_slam_amd import capi
+    B, H, W = frames.shape
+    P = max(B - 1, 1)
+    spec = [("n", np.int32, (B,)), ("kxy", np.int32, (B, kmax, 2)), ("score", np.float32, (B, kmax)), ("desc", np.float32, (B, kmax, 256)),
+            ("S", np.int32, (P,)), ("pairs", np.int32, (P, kmax, 2)), ("ms", np.float32, (P, kmax))]
+    dimg = ctx.alloc(frames.nbytes).upload(frames)
+    bufs = {nm: ctx.alloc(int(np.prod(sh)) * np.dtype(dt).itemsize) for nm, dt, sh in spec}
+    ctx._chk(capi.lib.rfe_extract_match_stream_dev(ctx.h, dimg.ptr, H, W, W, B, kmax, 0.0005, 0.1, bufs["n"].ptr, bufs["kxy"].ptr, bufs["score"].ptr,
+                                                   bufs["desc"].ptr, bufs["S"].ptr, bufs["pairs"].ptr, bufs["ms"].ptr))
+    ctx.synchronize()
+    out = {nm: bufs[nm].download(sh, dt) for nm, dt, sh in spec}
+    for b in list(bufs.values()) + [dimg]:
+        b.free()
+    return out
+
+
+@pytest.fixture(scope="module")
+def wsets():
+    return Wt.make_superpoint(seed=7), Wt.make_lightglue(seed=11)
+
+
+@pytest.mark.gpu
+def test_pool_of_one_through_rccl_equals_single_ctx(wsets):
+    from rover_slam_amd import capi
+    frames, _ = synth.make_frames(5, 240, 320, seed=5)
+    kmax = 512
+    pool = capi.Pool([0])
+    try:
+        assert pool.size == 1
+        assert pool.has_rccl, "librccl could not be opened / ncclCommInitAll failed on the GPU box"
+        pool.set_weights(capi.KIND_SUPERPOINT, wsets[0]); pool.set_weights(capi.KIND_LIGHTGLUE, wsets[1])
+        got = pool.extract_match_stream(frames, kmax=kmax, transport=capi.POOL_RCCL)
+        again = pool.extract_match_stream(frames, kmax=kmax, transport=capi.POOL_COPY)
+    finally:
+        pool.close()
+    ctx = capi.Context(0)
+    ctx.set_weights(capi.KIND_SUPERPOINT, wsets[0]); ctx.set_weights(capi.KIND_LIGHTGLUE, wsets[1])
+    ref = _single_ctx_stream(ctx, frames, kmax)
+    ctx.close()
+    assert ref["n"].min() > 50 and ref["S"].sum() > 0
+    for k in ("n", "kxy", "score", "desc"):
+        assert np.array_equal(got[k], ref[k]), f"RCCL transport: {k} differs from the single-ctx call"
+        assert np.array_equal(again[k], ref[k]), f"COPY transport: {k} differs from the single-ctx call"
+    assert _same_matches(got, ref), "RCCL transport: matches differ from the single-ctx call"
+    assert _same_matches(again, ref), "COPY transport: matches differ from the single-ctx call"
+
+
+@pytest.mark.gpu
+def test_pool_three_members_on_one_device_copy_transport(wsets, oracle):
+    from rover_slam_amd import capi
+    from tolerances import lists_agree
+    F, kmax = 11, 256                                      # 10 pairs over 3 members: 4 + 3 + 3
+    frames, _ = synth.make_frames(F, 240, 320, seed=9)
+    pool = capi.Pool([0, 0, 0])
+    try:
+        assert pool.size == 3 and not pool.has_rccl          # members share a device: no communicator
+        pool.set_weights(capi.KIND_SUPERPOINT, wsets[0]); pool.set_weights(capi.KIND_LIGHTGLUE, wsets[1])
+        ids = {capi.lib.rfe_weights_id(capi.lib.rfe_pool_ctx(pool.h, r), capi.KIND_LIGHTGLUE) for r in range(3)}
+        assert len(ids) == 1 and 0 not in ids                # one shared device copy of the weights
+        with pytest.raises(capi.RfeError) as e:
+            pool.extract_match_stream(frames, kmax=kmax, transport=capi.POOL_RCCL)
+        assert "share a device" in str(e.value)
+        got = pool.extract_match_stream(frames, kmax=kmax)   # AUTO -> COPY
+        got2 = pool.extract_match_stream(frames, kmax=kmax, with_desc=False)
+    finally:
+        pool.close()
+    ctx = capi.Context(0)
+    ctx.set_weights(capi.KIND_SUPERPOINT, wsets[0]); ctx.set_weights(capi.KIND_LIGHTGLUE, wsets[1])
+    whole = _single_ctx_stream(ctx, frames, kmax)
+    # (a) each member's rows = a single-ctx call on its shard, bit for bit
+    for r in range(3):
+        first, nfr, own = capi.pool_shard(F, 3, r)
+        part = _single_ctx_stream(ctx, np.ascontiguousarray(frames[first:first + nfr]), kmax)
+        rows = nfr if r == 2 else own
+        for k in ("n", "kxy", "score", "desc"):
+            assert np.array_equal(got[k][first:first + rows], part[k][:rows]), (r, k)
+        assert _same_matches(got, part, first, first + own), r
+    ctx.close()
+    for k in ("n", "kxy"):
+        assert np.array_equal(got2[k], got[k])
+    assert _same_matches(got2, got)
+    # (b) against the one-ctx call on the whole stream: SuperPoint bit-exact, matches up to fp32 borderline flips
+    for k in ("n", "kxy", "score", "desc"):
+        assert np.array_equal(got[k], whole[k]), k
+    assert whole["S"].sum() > 0
+    for p in range(F - 1):
+        a, b = int(got["S"][p]), int(whole["S"][p])
+        ok, dev = lists_agree(got["pairs"][p, :a], got["ms"][p, :a], whole["pairs"][p, :b], whole["ms"][p, :b], slack=1e-4)
+        assert ok and dev < 1e-4, (p, a, b, dev)

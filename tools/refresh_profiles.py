@@ -35,7 +35,7 @@ def main(tag, rnd=None):
     d = json.loads(bench)
     open(os.path.join(P, f"{rnd}_bench.json"), "w").write(bench + "\n")
     ks = capture(rocpd_stats.main, os.path.join(O, "trace", "t_results.db")).replace(ROOT + "/", "")
-    att = [(m.group(1), int(m.group(2)), float(m.group(3))) for m in re.finditer(r"`(lg_attention_kernel<0, false, (?:true|false)>)` \| (\d+) \| [\d.]+ \| ([\d.]+)", ks)]
+    att = [(m.group(1), int(m.group(2)), float(m.group(3))) for m in re.finditer(r"`(lg_attention_kernel<0, false(?:, (?:true|false))+>)` \| (\d+) \| [\d.]+ \| ([\d.]+)", ks)]
     att_avg = sum(c * a for _, c, a in att) / max(sum(c for _, c, _ in att), 1)
     head = f"""# Round {int(rnd[1:])} — rocprofv3 --kernel-trace summary (final round-{int(rnd[1:])} kernels)
 
