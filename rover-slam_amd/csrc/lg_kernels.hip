@@ -440,7 +440,10 @@ __global__ __launch_bounds__(256) void lg_rowarg_kernel(const float* __restrict_
 
 // Column pass, fused: column log-sum-exp AND column argmax (first maximum) of the score matrix in one launch -- a workgroup owns a
 // stripe of CW columns x all rows (CW * 4 B per row; 128 KB at L = 1024, CW = 32) and walks it three times (max, sum of exp, argmax
-// of the scores), the second and third walk hitting L2.  Needs only rowlse; collse goes out for the row argmax that follows.
+// of the scores).  With many pairs in flight the stripes do NOT stay in L2 between the walks (FETCH_SIZE = 3x the buffer once the
+// counter's factor 2 is applied, calibrated in profiles/r03_fetch_calibration.md): that shape takes lg_col_lds_kernel below; this
+// kernel serves the few-pair / odd-L shapes, where the whole similarity buffer fits the L2s.  Needs only rowlse; collse goes out
+// for the row argmax that follows.
 // <32, 8>: throughput shape (L/32 workgroups per pair).  <16, 64>: one or a few pairs -- 1024 threads, 64 workgroups per 1024
 // columns, 16 rows per thread instead of 128 (single pair at K = 1024: 46 + 20 us for the two separate kernels -> one short launch).
 template <int CW, int RG>
@@ -477,6 +480,72 @@ __global__ __launch_bounds__(CW * RG) void lg_col_kernel(const float* __restrict
         const float l1 = z1[(size_t)p * L + jj];
         for (int i = rg; i < mm; i += RG) {
             const float sc = lg_score(base[(size_t)i * L + jj], rowlse[(size_t)p * L + i], lc, z0[(size_t)p * L + i], l1);
+            if (sc > best) { best = sc; bi = i; }
+        }
+    }
+    rb[rg][c] = best; ri[rg][c] = bi;
+    __syncthreads();
+    if (rg == 0 && jj < nn) {
+        for (int g = 1; g < RG; ++g) {
+            const float ob = rb[g][c]; const int oi = ri[g][c];
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        a1[(size_t)p * L + jj] = bi == 0x7fffffff ? 0 : bi;
+    }
+}
+
+// The same column pass with the stripe RESIDENT IN LDS (L <= 1024, L % 32 == 0: the throughput shape).  The three-walk kernel above
+// re-reads its 128 KB stripe from beyond L2 -- 1024 stripes are resident at once, 16 MB per XCD against 4 MB of L2, and rocprofv3
+// counts FETCH_SIZE = 1.5-3x the similarity buffer per launch (profiles/r02_pmc.md) -- so here a workgroup of 1024 threads copies its
+// 32 columns x m rows ONCE, by global_load_lds_dwordx4 (a wave instruction moves eight 128-byte row segments = 1 KB, which is also
+// 1 KB of the [row][32] LDS image: a linear copy, no VGPRs), and walks LDS three times.  One workgroup per CU (128 KB + 8 KB of LDS).
+// Reduction tree: 32 row groups per column (rows rg, rg + 32, ...), combined in ascending group order.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+__global__ __launch_bounds__(1024) void lg_col_lds_kernel(const float* __restrict__ sim, const float* __restrict__ z0,
+                                                          const float* __restrict__ z1, const float* __restrict__ rowlse, int L,
+                                                          const int* __restrict__ m, const int* __restrict__ n,
+                                                          float* __restrict__ collse, int32_t* __restrict__ a1) {
+    constexpr int CW = 32, RG = 32;
+    __shared__ __attribute__((aligned(16))) float stripe[1024 * CW];
+    __shared__ float rb[RG][CW + 1];
+    __shared__ int ri[RG][CW + 1];
+    const int p = blockIdx.y, tid = threadIdx.x, c = tid % CW, rg = tid / CW;
+    const int j0 = blockIdx.x * CW, jj = j0 + c;
+    const int mm = m[p], nn = n[p];
+    if (j0 >= nn) return;                       // the whole stripe lies past this pair's keypoints (workgroup-uniform)
+    const float* base = sim + (size_t)p * L * L + j0;
+    {
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const float* src = base + (size_t)(lane >> 3) * L + (lane & 7) * 4;
+        for (int q = wave; q * 8 < mm; q += 16)      // rows 8 q .. 8 q + 7 (rows up to L - 1 exist: L % 8 == 0)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)q * 8 * L), (lds_ptr_t)(stripe + q * 8 * CW), 16, 0, 0);
+    }
+    __syncthreads();                            // every wave's copies have landed (vmcnt(0) in front of the barrier)
+    const float* col = stripe + c;
+    float mx = -INFINITY;
+    for (int i = rg; i < mm; i += RG) mx = fmaxf(mx, col[i * CW]);
+    rb[rg][c] = mx;
+    __syncthreads();
+    float gm = rb[0][c];
+#pragma unroll 8
+    for (int g = 1; g < RG; ++g) gm = fmaxf(gm, rb[g][c]);
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = rg; i < mm; i += RG) sum += expf(col[i * CW] - gm);
+    rb[rg][c] = sum;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll 8
+    for (int g = 0; g < RG; ++g) t += rb[g][c];       // every thread of a column: the same sum in the same order
+    const float lc = gm + logf(t);
+    __syncthreads();
+    float best = -INFINITY; int bi = 0x7fffffff;
+    if (jj < nn) {
+        if (rg == 0) collse[(size_t)p * L + jj] = lc;
+        const float l1 = z1[(size_t)p * L + jj];
+        for (int i = rg; i < mm; i += RG) {
+            const float sc = lg_score(col[i * CW], rowlse[(size_t)p * L + i], lc, z0[(size_t)p * L + i], l1);
             if (sc > best) { best = sc; bi = i; }
         }
     }
@@ -531,7 +600,10 @@ void launch_lg_assign(hipStream_t s, const float* sim, const float* z0, const fl
                       const int* m, const int* n, float thr, float* scores_opt, float* rowlse, float* collse,
                       int32_t* a0, float* mx0, int32_t* a1, int32_t* S, int32_t* pairs, float* ms, int scores_pair) {
     hipLaunchKernelGGL(lg_rowlse_kernel, dim3((L + 3) / 4, P), dim3(256), 0, s, sim, L, m, n, rowlse);
-    if ((long long)P * ((L + 31) / 32) < 128)   // a few pairs: narrower stripes, 4x the threads per workgroup
+    static const bool col_lds = tune_int("RFE_LG_COL_LDS", 1) != 0;   // tuning switch: 0 = the three-walk kernel for every shape
+    if (col_lds && L <= 1024 && L % 32 == 0 && (long long)P * (L / 32) >= 256)   // throughput shape: stripe resident in LDS, read from HBM once
+        hipLaunchKernelGGL(lg_col_lds_kernel, dim3(L / 32, P), dim3(1024), 0, s, sim, z0, z1, rowlse, L, m, n, collse, a1);
+    else if ((long long)P * ((L + 31) / 32) < 128)   // a few pairs: narrower stripes, 4x the threads per workgroup
         hipLaunchKernelGGL((lg_col_kernel<16, 64>), dim3((L + 15) / 16, P), dim3(1024), 0, s, sim, z0, z1, rowlse, L, m, n, collse, a1);
     else
         hipLaunchKernelGGL((lg_col_kernel<32, 8>), dim3((L + 31) / 32, P), dim3(256), 0, s, sim, z0, z1, rowlse, L, m, n, collse, a1);

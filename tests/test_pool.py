@@ -7,6 +7,9 @@ members sharing the one device of the box through the COPY transport equal (a) s
 borderline flips: smaller shards select other tilings).  RCCL between DIFFERENT devices needs an N-GPU node: unmeasured here.
 Reference contrast: one device, src/Extractors/superpoint_onnx.cc:19."""
 import ctypes as C
+import os
+import shutil
+import subprocess
 
 import numpy as np
 import pytest
@@ -51,6 +54,30 @@ def test_pool_fails_loudly_without_gpu_and_on_bad_arguments():
         with pytest.raises(capi.RfeError) as e:
             capi.Pool([0])
         assert "no HIP device" in str(e.value)
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build_pool_driver(tmp_path):
+    exe = str(tmp_path / "pool_driver")
+    cmd = ["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "pool_driver.c"),
+           "-o", exe, "-L" + os.path.join(ROOT, "rover-slam_amd"), "-lrover_fe", "-L/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath," + os.path.join(ROOT, "rover-slam_amd"), "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="no gcc")
+def test_plain_c_host_of_the_pool_compiles_and_fails_loudly_without_gpu(tmp_path):
+    """include/rover_fe.h is C-clean (C99, -Wall -Werror) and a plain-C host links against librover_fe.so alone (no RCCL, no torch)."""
+    import torch
+    exe = _build_pool_driver(tmp_path)
+    (tmp_path / "f.u8").write_bytes(bytes(2 * 64 * 64))
+    r = subprocess.run([exe, str(tmp_path / "f.u8"), "2", "64", "64", "32", "1", "0", "none", "none", str(tmp_path / "o.bin")], capture_output=True, text=True)
+    if torch.cuda.device_count() == 0:
+        assert r.returncode == 1 and "no HIP device" in r.stderr
 
 
 def _same_matches(a, b, lo=0, hi=None, b_lo=0):
@@ -115,7 +142,7 @@ def test_pool_of_one_through_rccl_equals_single_ctx(wsets):
 @pytest.mark.gpu
 def test_pool_three_members_on_one_device_copy_transport(wsets, oracle):
     from rover_slam_amd import capi
-    from tolerances import lists_agree
+    from tolerances import LG_SCORE_TOL_SMALL, lists_agree
     F, kmax = 11, 256                                      # 10 pairs over 3 members: 4 + 3 + 3
     frames, _ = synth.make_frames(F, 240, 320, seed=9)
     pool = capi.Pool([0, 0, 0])
@@ -152,5 +179,40 @@ def test_pool_three_members_on_one_device_copy_transport(wsets, oracle):
     assert whole["S"].sum() > 0
     for p in range(F - 1):
         a, b = int(got["S"][p]), int(whole["S"][p])
-        ok, dev = lists_agree(got["pairs"][p, :a], got["ms"][p, :a], whole["pairs"][p, :b], whole["ms"][p, :b], slack=1e-4)
-        assert ok and dev < 1e-4, (p, a, b, dev)
+        # two fp32 evaluations (4- / 3-pair shards against the 10-pair batch: other GEMM / attention tilings), each within
+        # LG_SCORE_TOL_SMALL of the oracle at <= 256 keypoints, may sit twice that apart
+        ok, dev = lists_agree(got["pairs"][p, :a], got["ms"][p, :a], whole["pairs"][p, :b], whole["ms"][p, :b], slack=2 * LG_SCORE_TOL_SMALL)
+        assert ok and dev < 2 * LG_SCORE_TOL_SMALL, (p, a, b, dev)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="no gcc")
+def test_plain_c_host_runs_the_pool(tmp_path, wsets):
+    """tests/cpp/pool_driver.c (C99, no Python in the process): two members on the box's one device, weights from RFEW files, results
+    equal to the ctypes pool call."""
+    from rover_slam_amd import capi
+    F, H, W, kmax = 7, 240, 320, 256
+    frames, _ = synth.make_frames(F, H, W, seed=21)
+    frames.tofile(str(tmp_path / "frames.u8"))
+    Wt.save(str(tmp_path / "sp.rfew"), wsets[0], 1); Wt.save(str(tmp_path / "lg.rfew"), wsets[1], 2)
+    exe = _build_pool_driver(tmp_path)
+    r = subprocess.run([exe, str(tmp_path / "frames.u8"), str(F), str(H), str(W), str(kmax), "2", "0", str(tmp_path / "sp.rfew"),
+                        str(tmp_path / "lg.rfew"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "member 1: frames [3, 7), 3 pairs" in r.stdout
+    raw = np.fromfile(str(tmp_path / "out.bin"), np.int32)
+    P = F - 1
+    o = 0
+    got = {}
+    for nm, cnt, shape in (("n", F, (F,)), ("S", P, (P,)), ("kxy", F * kmax * 2, (F, kmax, 2)), ("pairs", P * kmax * 2, (P, kmax, 2)), ("ms", P * kmax, (P, kmax))):
+        got[nm] = raw[o:o + cnt].reshape(shape); o += cnt
+    got["ms"] = got["ms"].view(np.float32)
+    assert o == raw.size
+    pool = capi.Pool([0, 0])
+    try:
+        pool.set_weights(capi.KIND_SUPERPOINT, wsets[0]); pool.set_weights(capi.KIND_LIGHTGLUE, wsets[1])
+        ref = pool.extract_match_stream(frames, kmax=kmax, with_desc=False)
+    finally:
+        pool.close()
+    assert ref["S"].sum() > 0
+    assert np.array_equal(got["n"], ref["n"]) and np.array_equal(got["kxy"], ref["kxy"]) and _same_matches(got, ref)
