@@ -251,6 +251,142 @@ __global__ __launch_bounds__(256, PFK ? 2 : 4) void lg_attention_kernel(   // 4 
     }
 }
 
+// ---- LDS-DMA variant of the throughput attention (cross blocks: no rotary on K).
+// lg_attention_kernel fetches a K/V tile AFTER the barrier that frees the single LDS buffer, so each of the four workgroups of a CU
+// sits out one global round trip per tile, and workgroups that compete for the same matrix pipes drift into step (PMC: 0.21 of the
+// wave cycles at s_waitcnt / s_barrier, matrix pipe 0.83 busy).  A register prefetch costs the fourth workgroup (146 VGPRs, round 2).
+// Here the tiles never touch a VGPR: 32-key tiles are copied by global_load_lds_dwordx4 into a DOUBLE-buffered LDS tile (2 x (8 + 8) KB
+// = the 32 KB of the single 64-key buffer), tile t+1 is requested right after the barrier and has the whole compute phase of tile t
+// to land; one barrier per 32 keys (as before: two per 64).  K image: row = key, sixteen 16-byte slots per row, slot c stored at
+// c ^ (key & 15) -- the swizzle is applied on the SOURCE address (the LDS side of the copy is lane-linear) -- so that the A fragment
+// of S^T = K . Q^T is ONE conflict-free ds_read_b128 per four k-steps (lane (j, h) reads K[j][8 g + 4 h .. + 3]); MFMA step (g, e)
+// therefore multiplies k = 8 g + e and 8 g + 4 + e: the sum over the head dimension runs in a permuted order (tolerance-checked
+// like every LightGlue kernel), Q is loaded in that order with eight float4 loads.  V image: plain [key][64].  Keys past the
+// sequence length are read from the last valid row (finite) and masked in S.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+constexpr int AD_K = 32;
+__global__ __launch_bounds__(256, 4) void lg_attention_dma_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld, float* __restrict__ out,
+    int Lq, int Lk, int nqb, const int* __restrict__ qlen, const int* __restrict__ klen, const int* __restrict__ kv_map,
+    int prio, int nseq_total) {
+    __shared__ __attribute__((aligned(16))) float Kd[2][AD_K * 64];
+    __shared__ __attribute__((aligned(16))) float Vd[2][AD_K * 64];
+    const int Lb = blockIdx.x, xcd = Lb & 7, t_ = Lb >> 3;
+    const int qb = t_ % nqb, unit = (t_ / nqb) * 8 + xcd;
+    if (unit >= 4 * nseq_total) return;
+    const int seq = unit >> 2, head = unit & 3;
+    const int kvseq = kv_map ? kv_map[seq] : seq;
+    const int nq = qlen ? qlen[seq] : Lq;
+    const int nk = klen ? klen[kvseq] : Lk;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (qb * AT_Q >= nq) {
+        for (int e = tid; e < AT_Q * 64; e += 256) {
+            const int row = qb * AT_Q + (e >> 6);
+            if (row < Lq) out[((size_t)seq * Lq + row) * 256 + head * 64 + (e & 63)] = 0.f;
+        }
+        return;
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int qrow = qb * AT_Q + wave * 32 + j;
+    const size_t qrow_c = (size_t)seq * Lq + (qrow < Lq ? qrow : Lq - 1);
+    constexpr float kScale = 0.125f * 1.44269504088896341f;
+    float qreg[32];   // qreg[4 g + e] = Q[query][8 g + 4 h + e] * scale
+    {
+        const float4* qp4 = reinterpret_cast<const float4*>(q + qrow_c * ld + head * 64) + h;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float4 t = qp4[2 * g];
+            qreg[4 * g] = t.x * kScale; qreg[4 * g + 1] = t.y * kScale; qreg[4 * g + 2] = t.z * kScale; qreg[4 * g + 3] = t.w * kScale;
+        }
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const float* kbase = k + (size_t)kvseq * Lk * ld + head * 64;
+    const float* vbase = v + (size_t)kvseq * Lk * ld + head * 64;
+    // copy geometry: a wave instruction moves 64 granules of 16 B = 4 rows; wave w owns rows 8 w .. 8 w + 7 of a tile (two instructions
+    // for K, two for V).  Granule (row, slot') of the K image holds global chunk slot' ^ (row & 15).
+    const int crow = lane >> 4, cslot = lane & 15;
+    auto issue = [&](int k0, int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row = wave * 8 + u * 4 + crow;
+            int key = k0 + row; key = key < nk ? key : nk - 1;
+            const float* ksrc = kbase + (size_t)key * ld + ((cslot ^ (row & 15)) << 2);
+            const float* vsrc = vbase + (size_t)key * ld + (cslot << 2);
+            __builtin_amdgcn_global_load_lds((gptr_t)ksrc, (lds_ptr_t)(Kd[buf] + (wave * 8 + u * 4) * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)vsrc, (lds_ptr_t)(Vd[buf] + (wave * 8 + u * 4) * 64), 16, 0, 0);
+        }
+    };
+    if (nk > 0) issue(0, 0);
+    int buf = 0;
+    const int jsw = j & 15;
+    for (int k0 = 0; k0 < nk; k0 += AD_K) {
+        __syncthreads();   // tile k0 has landed (vmcnt(0) in front of the barrier, every wave); the other buffer is no longer read
+        if (k0 + AD_K < nk) issue(k0 + AD_K, buf ^ 1);
+        f32x16 st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+        const float* ka = Kd[buf] + j * 64;
+        if (prio) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(ka + (((2 * g + h) ^ jsw) << 2));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], qreg[4 * g + e], st, 0, 0, 0);
+        }
+        if (prio) __builtin_amdgcn_s_setprio(0);
+        if (k0 + AD_K > nk) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (key >= nk) st[r] = -INFINITY;
+            }
+        }
+        float mx = st[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (__any(mx > m_run + AT_DEFER)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        }
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[r] = __builtin_amdgcn_exp2f(st[r] - m_run); ps += st[r]; }
+        ps += __shfl_xor(ps, 32);
+        l_run += ps;
+        const float* va = Vd[buf] + (4 * h) * 64 + j;
+        if (prio) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kr = (r & 3) + 8 * (r >> 2);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[kr * 64], st[r], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[kr * 64 + 32], st[r], o1, 0, 0, 0);
+        }
+        if (prio) __builtin_amdgcn_s_setprio(0);
+        buf ^= 1;
+    }
+    if (qrow < Lq) {
+        const float inv = (qrow < nq && l_run > 0.f) ? 1.0f / l_run : 0.f;
+        float* op = out + ((size_t)seq * Lq + qrow) * 256 + head * 64;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = (r & 3) + 8 * (r >> 2) + 4 * h;
+            op[d] = o0[r] * inv;
+            op[d + 32] = o1[r] * inv;
+        }
+    }
+}
+
 // merges the key ranges of the split variant: out = sum_s o_s 2^(m_s - m) / sum_s l_s 2^(m_s - m), m = max_s m_s
 __global__ __launch_bounds__(256) void lg_attention_combine_kernel(const float* __restrict__ part, int ns, int nseq, int Lq,
                                                                    const int* __restrict__ qlen, float* __restrict__ out) {
@@ -326,7 +462,10 @@ void launch_lg_attention(hipStream_t s, const float* q, const float* k, const fl
     if (abl == 3) { hipLaunchKernelGGL((lg_attention_kernel<3>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, 0, nullptr, nseq, rope_csn); return; }
 #endif
     static const int prio = tune_int("RFE_ATT_PRIO", 1);   // s_setprio(1) around the MFMA clusters (+0.8 %); RFE_ATT_PRIO=0 disables
-    if (rope)
+    static const bool dma = tune_int("RFE_ATT_DMA", 1) != 0;   // tuning switch: 0 = register-staged tiles for the cross blocks too
+    if (!rope && dma && (ld % 4) == 0)
+        hipLaunchKernelGGL(lg_attention_dma_kernel, dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nseq);
+    else if (rope)
         hipLaunchKernelGGL((lg_attention_kernel<0, false, true>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nullptr, nseq, rope_csn);
     else
         hipLaunchKernelGGL((lg_attention_kernel<0, false, false>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nullptr, nseq, rope_csn);
@@ -510,10 +649,12 @@ __global__ __launch_bounds__(1024) void lg_col_lds_kernel(const float* __restric
     __shared__ __attribute__((aligned(16))) float stripe[1024 * CW];
     __shared__ float rb[RG][CW + 1];
     __shared__ int ri[RG][CW + 1];
+    __shared__ float rl[1024], zr[1024];        // rowlse / z0 of this pair: the argmax walk reads them per row (a dependent global load per row otherwise)
     const int p = blockIdx.y, tid = threadIdx.x, c = tid % CW, rg = tid / CW;
     const int j0 = blockIdx.x * CW, jj = j0 + c;
     const int mm = m[p], nn = n[p];
     if (j0 >= nn) return;                       // the whole stripe lies past this pair's keypoints (workgroup-uniform)
+    if (tid < mm) { rl[tid] = rowlse[(size_t)p * L + tid]; zr[tid] = z0[(size_t)p * L + tid]; }
     const float* base = sim + (size_t)p * L * L + j0;
     {
         const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -545,7 +686,7 @@ __global__ __launch_bounds__(1024) void lg_col_lds_kernel(const float* __restric
         if (rg == 0) collse[(size_t)p * L + jj] = lc;
         const float l1 = z1[(size_t)p * L + jj];
         for (int i = rg; i < mm; i += RG) {
-            const float sc = lg_score(col[i * CW], rowlse[(size_t)p * L + i], lc, z0[(size_t)p * L + i], l1);
+            const float sc = lg_score(col[i * CW], rl[i], lc, zr[i], l1);
             if (sc > best) { best = sc; bi = i; }
         }
     }
