@@ -95,12 +95,12 @@ def pmc_traffic(stage):
     bench command (profiles/rNN_pmc_traffic.json, made by tools/profile_round.sh + tools/rocpd_pmc.py):
     (2*FETCH_SIZE + WRITE_SIZE)*1024 as the MI355X guide prescribes.  None when no PMC pass covers it."""
     keys = STAGE_KERNEL.get(stage)
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
         if not keys or not os.path.exists(path):
             continue
         kernels = json.load(open(path))["kernels"]
-        for key in keys:        # round 2 profiles hold one call-weighted entry for the attention's self (rotary) and cross variants
+        for key in keys:        # from round 2 on the profiles hold one call-weighted entry for the attention's self (rotary) and cross kernels
             for name, v in kernels.items():
                 if key in name:
                     return v["traffic_bytes"], f"profiles/{rnd}_pmc_traffic.json:" + name

@@ -35,6 +35,40 @@ constexpr float AT_DEFER = 16.0f;   // log2 units
 constexpr int AT_SPLIT_MAX = 8;               // key ranges of the split variant
 constexpr size_t AT_SPLIT_MAX_ROWS = 8192;    // only problems this small are latency-bound enough to split
 
+// Online softmax step on one 32-key x 32-query S^T block, trimmed for VALU count: on gfx950 the fp32 MFMA runs at the vector rate
+// (64 FLOP / clk / SIMD) and every VALU instruction of ANY wave of the SIMD measurably costs matrix-pipe time (the softmax removed:
+// +12 % with the staging gone, profiles/r01_pmc.md; LayerNorm + GELU on ffn.3's operand path: its full VALU time), so the steady
+// state does as little as it can:
+//   * the reference maximum is subtracted INSIDE the accumulation -- the accumulator starts at -m_run instead of 0 (at_softmax_init) --
+//     so no subtraction per element;
+//   * the tile maximum is a v_max3 tree per lane, compared against the deferred-rescale threshold WITHOUT combining the two half-waves
+//     (__any covers both); only the rare branch (always the first tile) combines them, moves the reference and shifts the block;
+//   * the row sum stays a per-half-wave partial; the halves are added once after the last tile (at_softmax_finish).
+// st: in = S^T block relative to the reference, out = P^T block.  first: wave-uniform, the first tile of this wave's key range.
+__device__ __forceinline__ float at_softmax_init(bool first, float m_run) { return first ? 0.f : -m_run; }
+__device__ __forceinline__ void at_softmax_step(f32x16& st, bool first, float& m_run, float& l_run, f32x16& o0, f32x16& o1) {
+    float mx = fmaxf(fmaxf(st[0], st[1]), st[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, st[r]), st[r + 1]);
+    mx = fmaxf(mx, st[15]);
+    if (__any(first || mx > AT_DEFER)) {
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float ref = first ? 0.f : m_run;            // what the accumulator already subtracted
+        const float m_new = fmaxf(m_run, mx + ref);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // m_run = -inf on the first tile -> 0
+        const float d = ref - m_new;
+        l_run *= alpha;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[r] += d; o0[r] *= alpha; o1[r] *= alpha; }
+    }
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { st[r] = __builtin_amdgcn_exp2f(st[r]); ps += st[r]; }
+    l_run += ps;
+}
+__device__ __forceinline__ float at_softmax_finish(float l_run) { return l_run + __shfl_xor(l_run, 32); }
+
 // ABL: timing ablations only (wrong results): 1 = no softmax VALU, 2 = stage only the first K/V tile, 3 = both
 // SPLIT: split-key variant for latency-bound problems (one pair = 64 (sequence, head, query block) units for 256 CUs and
 // a 2048-MFMA serial chain per wave): blockIdx.y selects one of gridDim.y key ranges, the workgroup writes its
@@ -165,10 +199,14 @@ __global__ __launch_bounds__(256, PFK ? 2 : 4) void lg_attention_kernel(   // 4 
 #pragma unroll
         for (int sub = 0; sub < AT_K / 32; ++sub) {
             if (k0 + sub * 32 >= nk) break;
-            // ---- S^T[key][query] = sum_d K[key][d] * Q[query][d]
+            // ---- S^T[key][query] = sum_d K[key][d] * Q[query][d] (relative to the running reference maximum: at_softmax_step)
             f32x16 st;
+            const bool first = k0 == kbeg && sub == 0;
+            {
+                const float init = (ABL & 1) ? 0.f : at_softmax_init(first, m_run);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+                for (int r = 0; r < 16; ++r) st[r] = init;
+            }
             const float* ka = Ks[buf] + (sub * 32 + j) * AT_LDK + h;
             if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -184,26 +222,7 @@ __global__ __launch_bounds__(256, PFK ? 2 : 4) void lg_attention_kernel(   // 4 
                     if (key >= nk) st[r] = -INFINITY;
                 }
             }
-            float mx = st[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            // deferred rescale: the running reference max only moves when some query's tile max exceeds it by more
-            // than 2^AT_DEFER (fp32 has the headroom: p <= 2^16, l <= 2^26); after the first tile this wave-uniform
-            // branch is almost never taken, which removes the accumulator rescale from the steady state.
-            if (__any(mx > m_run + AT_DEFER)) {
-                const float m_new = fmaxf(m_run, mx);
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // m_run = -inf on the first tile -> 0
-                l_run *= alpha;
-                m_run = m_new;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-            }
-            float ps = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { st[r] = __builtin_amdgcn_exp2f(st[r] - m_run); ps += st[r]; }
-            ps += __shfl_xor(ps, 32);
-            l_run += ps;
+            at_softmax_step(st, first, m_run, l_run, o0, o1);
             } else { l_run = 1.f; }
             // ---- O^T[d][query] += sum_key V[key][d] * P[key][query]; k-step r uses key(r,h)
             const float* va = Vs[buf] + (sub * 32 + 4 * h) * 64 + j;
@@ -222,6 +241,7 @@ __global__ __launch_bounds__(256, PFK ? 2 : 4) void lg_attention_kernel(   // 4 
             buf ^= 1;
         }
     }
+    if (!(ABL & 1)) l_run = at_softmax_finish(l_run);
     if (SPLIT) {
         if (qrow < Lq) {
             const size_t prow = ((size_t)blockIdx.y * nseq_total + seq) * Lq + qrow;
@@ -329,8 +349,12 @@ __global__ __launch_bounds__(256, 4) void lg_attention_dma_kernel(
         __syncthreads();   // tile k0 has landed (vmcnt(0) in front of the barrier, every wave); the other buffer is no longer read
         if (k0 + AD_K < nk) issue(k0 + AD_K, buf ^ 1);
         f32x16 st;
+        const bool first = k0 == 0;
+        {
+            const float init = at_softmax_init(first, m_run);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+            for (int r = 0; r < 16; ++r) st[r] = init;
+        }
         const float* ka = Kd[buf] + j * 64;
         if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -347,23 +371,7 @@ __global__ __launch_bounds__(256, 4) void lg_attention_dma_kernel(
                 if (key >= nk) st[r] = -INFINITY;
             }
         }
-        float mx = st[0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        if (__any(mx > m_run + AT_DEFER)) {
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            l_run *= alpha;
-            m_run = m_new;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-        }
-        float ps = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { st[r] = __builtin_amdgcn_exp2f(st[r] - m_run); ps += st[r]; }
-        ps += __shfl_xor(ps, 32);
-        l_run += ps;
+        at_softmax_step(st, first, m_run, l_run, o0, o1);
         const float* va = Vd[buf] + (4 * h) * 64 + j;
         if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -375,6 +383,7 @@ __global__ __launch_bounds__(256, 4) void lg_attention_dma_kernel(
         if (prio) __builtin_amdgcn_s_setprio(0);
         buf ^= 1;
     }
+    l_run = at_softmax_finish(l_run);
     if (qrow < Lq) {
         const float inv = (qrow < nq && l_run > 0.f) ? 1.0f / l_run : 0.f;
         float* op = out + ((size_t)seq * Lq + qrow) * 256 + head * 64;

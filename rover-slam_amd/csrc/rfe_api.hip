@@ -190,11 +190,12 @@ extern "C" int64_t rfe_weight_count(int kind) {
 
 // Read-only weights are shared: Rover-SLAM keeps 2-3 extractors and 3 matchers per process, each with a private runner
 // (src/Tracking.cc:645-651, :70; LocalMapping.cc:45; LoopClosing.cc:46).  Every ctx that loads the same blob on the same
-// device points at ONE device copy (keyed by device, kind and a 64-bit FNV-1a hash of the floats); the copy is freed
-// when the last ctx holding it is destroyed or loads something else.
+// device points at ONE device copy (looked up by device, kind and a 64-bit FNV-1a hash of the floats, and CONFIRMED by comparing
+// the blob with the host copy the entry keeps: two different blobs with one hash get two entries); the copy is freed when the
+// last ctx holding it is destroyed or loads something else.
 namespace {
 struct SpShared {
-    rfe::SpWeightsDev w; int device = 0;
+    rfe::SpWeightsDev w; int device = 0; std::vector<float> host;
     ~SpShared() {
         (void)hipSetDevice(device);
         if (w.conv1a_w) (void)hipFree(w.conv1a_w);
@@ -202,11 +203,11 @@ struct SpShared {
     }
 };
 struct LgShared {
-    rfe::LgWeightsDev w; int device = 0;
+    rfe::LgWeightsDev w; int device = 0; std::vector<float> host;
     ~LgShared() { (void)hipSetDevice(device); if (w.blob) (void)hipFree(w.blob); if (w.extra) (void)hipFree(w.extra); }
 };
 std::mutex g_weights_mu;
-std::map<std::tuple<int, int, uint64_t>, std::weak_ptr<void>> g_weights;   // (device, kind, hash) -> device copy
+std::map<std::tuple<int, int, uint64_t, int>, std::weak_ptr<void>> g_weights;   // (device, kind, hash, collision index) -> device copy
 
 uint64_t fnv1a64(const float* p, size_t n) {
     const unsigned char* b = reinterpret_cast<const unsigned char*>(p);
@@ -227,35 +228,47 @@ static int set_sp_upload(rfe_ctx* c, const float* blob);
 static int set_lg_upload(rfe_ctx* c, const float* blob);
 
 static int set_sp(rfe_ctx* c, const float* blob) {
-    const auto key = std::make_tuple(c->device, (int)RFE_KIND_SUPERPOINT, fnv1a64(blob, (size_t)SP_COUNT) ^ (uint64_t)conv_ck());
+    const uint64_t hash = fnv1a64(blob, (size_t)SP_COUNT) ^ (uint64_t)conv_ck();
     std::lock_guard<std::mutex> lk(g_weights_mu);
-    if (auto it = g_weights.find(key); it != g_weights.end())
-        if (auto sp = it->second.lock()) {
-            c->sp_hold = sp; c->sp = static_cast<SpShared*>(sp.get())->w; c->has_sp = true;
-            return RFE_OK;
-        }
+    auto key = std::make_tuple(c->device, (int)RFE_KIND_SUPERPOINT, hash, 0);
+    for (;; ++std::get<3>(key)) {   // same hash, different contents -> next collision index
+        auto it = g_weights.find(key);
+        if (it == g_weights.end()) break;
+        auto sp = it->second.lock();
+        if (!sp) break;             // expired entry: reuse its slot
+        if (memcmp(static_cast<SpShared*>(sp.get())->host.data(), blob, (size_t)SP_COUNT * sizeof(float)) != 0) continue;
+        c->sp_hold = sp; c->sp = static_cast<SpShared*>(sp.get())->w; c->has_sp = true;
+        return RFE_OK;
+    }
     c->has_sp = false; c->sp_hold.reset(); c->sp = SpWeightsDev();
     int rc = set_sp_upload(c, blob);
     auto sp = std::make_shared<SpShared>();
     sp->w = c->sp; sp->device = c->device;      // takes ownership of whatever was allocated, also after a partial failure
     if (rc) { c->sp = SpWeightsDev(); return rc; }
+    sp->host.assign(blob, blob + SP_COUNT);
     c->sp_hold = sp; g_weights[key] = sp;
     return RFE_OK;
 }
 
 static int set_lg(rfe_ctx* c, const float* blob) {
-    const auto key = std::make_tuple(c->device, (int)RFE_KIND_LIGHTGLUE, fnv1a64(blob, (size_t)LG_COUNT));
+    const uint64_t hash = fnv1a64(blob, (size_t)LG_COUNT);
     std::lock_guard<std::mutex> lk(g_weights_mu);
-    if (auto it = g_weights.find(key); it != g_weights.end())
-        if (auto lg = it->second.lock()) {
-            c->lg_hold = lg; c->lg = static_cast<LgShared*>(lg.get())->w; c->has_lg = true;
-            return RFE_OK;
-        }
+    auto key = std::make_tuple(c->device, (int)RFE_KIND_LIGHTGLUE, hash, 0);
+    for (;; ++std::get<3>(key)) {
+        auto it = g_weights.find(key);
+        if (it == g_weights.end()) break;
+        auto lg = it->second.lock();
+        if (!lg) break;
+        if (memcmp(static_cast<LgShared*>(lg.get())->host.data(), blob, (size_t)LG_COUNT * sizeof(float)) != 0) continue;
+        c->lg_hold = lg; c->lg = static_cast<LgShared*>(lg.get())->w; c->has_lg = true;
+        return RFE_OK;
+    }
     c->has_lg = false; c->lg_hold.reset(); c->lg = LgWeightsDev();
     int rc = set_lg_upload(c, blob);
     auto lg = std::make_shared<LgShared>();
     lg->w = c->lg; lg->device = c->device;
     if (rc) { c->lg = LgWeightsDev(); return rc; }
+    lg->host.assign(blob, blob + LG_COUNT);
     c->lg_hold = lg; g_weights[key] = lg;
     return RFE_OK;
 }

@@ -35,20 +35,20 @@ def main(tag, rnd=None):
     d = json.loads(bench)
     open(os.path.join(P, f"{rnd}_bench.json"), "w").write(bench + "\n")
     ks = capture(rocpd_stats.main, os.path.join(O, "trace", "t_results.db")).replace(ROOT + "/", "")
-    att = [(m.group(1), int(m.group(2)), float(m.group(3))) for m in re.finditer(r"`(lg_attention_kernel<0, false(?:, (?:true|false))+>)` \| (\d+) \| [\d.]+ \| ([\d.]+)", ks)]
+    att = [(m.group(1), int(m.group(2)), float(m.group(3))) for m in re.finditer(r"`(lg_attention_kernel<0, false(?:, (?:true|false))+>|lg_attention_dma_kernel)` \| (\d+) \| [\d.]+ \| ([\d.]+)", ks)]
     att_avg = sum(c * a for _, c, a in att) / max(sum(c for _, c, _ in att), 1)
     head = f"""# Round {int(rnd[1:])} — rocprofv3 --kernel-trace summary (final round-{int(rnd[1:])} kernels)
 
 Command (MI355X box, tools/profile_round.sh {tag}): `rocprofv3 --kernel-trace --stats -d gpurun_out/{tag}/trace -o t -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variants --sustained-steps 0` (1 warm-up + 3 fully instrumented + 3 timed steps of 33 frames + 32 pairs, plus the steps of the PCIe-inclusive loop; rocpd sqlite summarised by tools/rocpd_stats.py).
 
-Un-profiled bench.py line from the same box just before: profiles/{rnd}_bench.json ({d['value']} frames/s, {d['ms_per_step']} ms/step; lg_attention avg {d['roofline']['avg_launch_ms'] * 1e3:.1f} us by HIP events in the timed region, {att_avg:.1f} us in this trace over its self (rotary) and cross variants: {', '.join(f'{n} {a:.1f} us x {c}' for n, c, a in att)}).
+Un-profiled bench.py line from the same box just before: profiles/{rnd}_bench.json ({d['value']} frames/s, {d['ms_per_step']} ms/step; lg_attention avg {d['roofline']['avg_launch_ms'] * 1e3:.1f} us by HIP events in the timed region, {att_avg:.1f} us in this trace over its self (rotary, register-staged) and cross (LDS-DMA) kernels: {', '.join(f'{n} {a:.1f} us x {c}' for n, c, a in att)}).
 
 """
     open(os.path.join(P, f"{rnd}_kernel_stats.md"), "w").write(head + ks)
     hbm_tab, hj = split(capture(rocpd_pmc.main, [os.path.join(O, "pmc_fetch", "f_results.db"), os.path.join(O, "pmc_write", "w_results.db")]))
     sq_tab, _ = split(capture(rocpd_pmc.main, [os.path.join(O, "pmc_sq", "s_results.db")]))
     # bench.py's roofline.traffic looks the dominant stage up by kernel-name substring: give the attention one merged entry
-    am = [v for k, v in hj.items() if k.startswith("lg_attention_kernel<0, false")]
+    am = [v for k, v in hj.items() if k.startswith("lg_attention_kernel<0, false") or k == "lg_attention_dma_kernel"]
     if am:
         tot = sum(v["calls"] for v in am)
         hj["lg_attention_kernel (self + cross variants, call-weighted)"] = {k: sum(v[k] * v["calls"] for v in am) / tot for k in ("FETCH_SIZE", "WRITE_SIZE", "traffic_bytes", "avg_us")} | {"calls": tot}
