@@ -7,8 +7,12 @@ through SuperPoint, odd cases: constructed sets with hundreds of true matches, e
   * a float64 numpy evaluation of the same graph (this file; "exact" for the purpose of fp32 rounding),
   * the HIP path with RFE_OPT_LG_FOLD_WO = 0 (graph node for node) and = 1 (Wo folded into ffn.0),
 and the maximum absolute match-score deviation between them is tabulated, together with whether the match lists are
-identical.  Test infrastructure (uses oracle/); run on the GPU box:  python tools/lg_tolerance_study.py [--cases 20]
-Writes a markdown table to stdout (committed as profiles/r02_lg_tolerance.md).
+identical.  Test infrastructure (uses oracle/); run on the GPU box:  python tools/lg_tolerance_study.py [--cases 20] [--batched]
+Writes a markdown table to stdout (committed as profiles/rNN_lg_tolerance.md).
+--batched (round 3): every case is ALSO matched inside a 16-pair call (the cases that share a LightGlue weight seed, cycled up to 16
+pairs = 32 768 token rows), i.e. through the THROUGHPUT tiling the benchmark times -- 128x256 k-permuted GEMM tiles, LayerNorm + GELU
+fused across ffn.0 / ffn.3, the register-staged self attention and the LDS-DMA cross attention with one workgroup per query block --
+where the plain study (one pair per call) takes the 64-row latency tiles and the split-key attention.
 """
 import argparse
 import os
@@ -103,6 +107,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--kmax", type=int, default=1024)
+    ap.add_argument("--batched", action="store_true", help="also match every case inside a 16-pair call (throughput tiling)")
     args = ap.parse_args()
     from rover_slam_amd import capi
     from oracle import oracle as O
@@ -147,8 +152,30 @@ def main():
             r[f"same{fold}"], r[f"dev{fold}"] = score_dev(got[fold][0], got[fold][1], ref["pairs"], ref["ms"])
             r[f"same{fold}_64"], r[f"dev{fold}_64"] = score_dev(got[fold][0], got[fold][1], p64, m64)
         r["same_o64"], r["dev_o64"] = score_dev(ref["pairs"], ref["ms"], p64, m64)
+        r["_in"] = (k0, k1, d0, d1, ref, p64, m64)
         rows.append(r)
         print(f"# case {case}: {r}", file=sys.stderr, flush=True)
+    if args.batched:
+        PB = 16
+        for seed in sorted({r["lg_seed"] for r in rows}):
+            grp = [r for r in rows if r["lg_seed"] == seed]
+            ctx.set_weights(capi.KIND_LIGHTGLUE, Wt.make_lightglue(seed=seed))
+            for g0 in range(0, len(grp), PB):
+                part = grp[g0:g0 + PB]
+                cyc = [part[i % len(part)] for i in range(PB)]           # cycled up to 16 pairs: >= 32768 token rows
+                kb0 = np.zeros((PB, K, 2), np.float32); kb1 = np.zeros((PB, K, 2), np.float32)
+                db0 = np.zeros((PB, K, 256), np.float32); db1 = np.zeros((PB, K, 256), np.float32)
+                for i, r in enumerate(cyc):
+                    k0, k1, d0, d1 = r["_in"][:4]
+                    kb0[i, :r["n0"]] = k0; kb1[i, :r["n1"]] = k1; db0[i, :r["n0"]] = d0; db1[i, :r["n1"]] = d1
+                for fold in (0, 1):
+                    ctx.set_option(capi.OPT_LG_FOLD_WO, fold)
+                    S, pairs, ms = ctx.match(kb0, kb1, db0, db1, [r["n0"] for r in cyc], [r["n1"] for r in cyc])
+                    for i, r in enumerate(part):
+                        ref, p64, m64 = r["_in"][4:]
+                        r[f"bsame{fold}"], r[f"bdev{fold}"] = score_dev(pairs[i, :S[i]], ms[i, :S[i]], ref["pairs"], ref["ms"])
+                        r[f"bsame{fold}_64"], r[f"bdev{fold}_64"] = score_dev(pairs[i, :S[i]], ms[i, :S[i]], p64, m64)
+            print(f"# batched seed {seed} done", file=sys.stderr, flush=True)
     ctx.close()
     mx = lambda k: max(r[k] for r in rows)
     al = lambda k: all(r[k] for r in rows)
@@ -166,6 +193,15 @@ def main():
               f"| {r['dev_o64']:.2e} | {yn(r['same_o64'])} | {r['dev0_64']:.2e} | {r['dev1_64']:.2e} |")
     print(f"| **max** | | | | | **{mx('dev0'):.2e}** | {yn(al('same0'))} | **{mx('dev1'):.2e}** | {yn(al('same1'))} | **{mx('dev_o64'):.2e}** "
           f"| {yn(al('same_o64'))} | **{mx('dev0_64'):.2e}** | **{mx('dev1_64'):.2e}** |")
+    if args.batched:
+        print("\n## The same cases inside 16-pair calls (throughput tiling: >= 32 768 token rows per call)\n")
+        print("| case | S | gpu0 batched vs oracle | lists | gpu1 batched vs oracle | lists | gpu0 batched vs f64 | lists | gpu1 batched vs f64 | lists |")
+        print("|---:|---:|---:|:-:|---:|:-:|---:|:-:|---:|:-:|")
+        for r in rows:
+            print(f"| {r['case']} | {r['S']} | {r['bdev0']:.2e} | {yn(r['bsame0'])} | {r['bdev1']:.2e} | {yn(r['bsame1'])} | {r['bdev0_64']:.2e} | {yn(r['bsame0_64'])} "
+                  f"| {r['bdev1_64']:.2e} | {yn(r['bsame1_64'])} |")
+        print(f"| **max** | | **{mx('bdev0'):.2e}** | {yn(al('bsame0'))} | **{mx('bdev1'):.2e}** | {yn(al('bsame1'))} | **{mx('bdev0_64'):.2e}** | {yn(al('bsame0_64'))} "
+              f"| **{mx('bdev1_64'):.2e}** | {yn(al('bsame1_64'))} |")
 
 
 if __name__ == "__main__":
