@@ -416,6 +416,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the short Kmax = 256 / 512 and K < Kmax (dustbin weights) runs of SURVEY 8(d) (N=1)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the short PCIe-inclusive measurement (N=1)")
+    ap.add_argument("--no-pool", action="store_true", help="skip the short run through the C-ABI pool (rfe_pool_*, N=1)")
     ap.add_argument("--gather-desc", action="store_true", help="also gather scores and the 256-d descriptors to rank 0")
     ap.add_argument("--lg-fold", type=int, default=None, choices=[0, 1], help="override RFE_OPT_LG_FOLD_WO (default: the library's)")
     ap.add_argument("--check-launch", action="store_true", help="N-rank flow only (gloo, CPU tensors, no GPU): launcher / collective self-test")
@@ -710,6 +711,37 @@ def main():
                     raise RuntimeError(f"PCIe pipeline: {nm} of buffer set {si} differs from the resident path "
                                        f"({int((h_ != t_.cpu()).sum())} elements)")
 
+    pool_line = None
+    if world == 1 and not args.no_pool and args.workload == "c4":
+        # The same 33-frame step through the C-ABI pool a C / C++ host would use (rfe_pool_*, rover-slam_amd/csrc/rfe_pool.hip): HOST frames in,
+        # HOST results out (pageable memory, no overlap between calls), one member on this device, its rows gathered into the root buffer
+        # through RCCL when librccl could be opened (self send / receive), copies otherwise.  Never the headline value.
+        pool = capi.Pool([dev.index or 0])
+        try:
+            pool.set_weights(capi.KIND_SUPERPOINT, wsp); pool.set_weights(capi.KIND_LIGHTGLUE, wlg)
+            if args.lg_fold is not None:
+                pool.set_option(capi.OPT_LG_FOLD_WO, args.lg_fold)
+            tr = capi.POOL_RCCL if pool.has_rccl else capi.POOL_COPY
+            po = pool.extract_match_stream(frames_np, kmax=KMAX, transport=tr, with_desc=False)
+            t1 = time.perf_counter()
+            npl = 5
+            for _ in range(npl):
+                po = pool.extract_match_stream(frames_np, kmax=KMAX, transport=tr, with_desc=False)
+            dtp = time.perf_counter() - t1
+            S_h, p_h, m_h = S.cpu().numpy(), pairs.cpu().numpy(), ms.cpu().numpy()
+            same = bool(np.array_equal(po["n"], n.cpu().numpy()) and np.array_equal(po["kxy"], kxy.cpu().numpy()) and np.array_equal(po["S"], S_h)
+                        and all(np.array_equal(po["pairs"][q, :S_h[q]], p_h[q, :S_h[q]]) and np.array_equal(po["ms"][q, :S_h[q]], m_h[q, :S_h[q]])
+                                for q in range(B - 1)))
+            pool_line = {"value": round(FRAMES_PER_GPU * npl / dtp, 2), "unit": "frames/s", "members": pool.size,
+                         "transport": "rccl (grouped ncclSend / ncclRecv into the root buffer)" if tr == capi.POOL_RCCL else "copy",
+                         "equals_resident_path": same,
+                         "note": "rfe_pool_extract_match_stream: frames from pageable host memory, counts / keypoints / matches back to host arrays, "
+                                 "calls not overlapped; the C-ABI route to configs[3], not the headline value"}
+            if not same:
+                print("bench.py: the pool call's results differ from the resident path", file=sys.stderr)
+        finally:
+            pool.close()
+
     bad_exit = 0
     gathered_ok = None
     if pg and rank == 0:   # the gathered payload of the last step really holds every rank's results
@@ -763,6 +795,8 @@ def main():
             out["sustained"] = sustained
         if variants is not None:
             out["variants"] = variants
+        if pool_line is not None:
+            out["pool_c_abi"] = pool_line
         if pcie is not None:
             out["pcie_inclusive"] = {"value": round(pcie, 2), "unit": "frames/s",
                                      "note": "same step with H2D of the 33 u8 frames and D2H of all results (descriptors included) per step, pinned host memory, double buffered on a copy stream; not the headline value"}

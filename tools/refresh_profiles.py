@@ -39,7 +39,7 @@ def main(tag, rnd=None):
     att_avg = sum(c * a for _, c, a in att) / max(sum(c for _, c, _ in att), 1)
     head = f"""# Round {int(rnd[1:])} — rocprofv3 --kernel-trace summary (final round-{int(rnd[1:])} kernels)
 
-Command (MI355X box, tools/profile_round.sh {tag}): `rocprofv3 --kernel-trace --stats -d gpurun_out/{tag}/trace -o t -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variants --sustained-steps 0` (1 warm-up + 3 fully instrumented + 3 timed steps of 33 frames + 32 pairs, plus the steps of the PCIe-inclusive loop; rocpd sqlite summarised by tools/rocpd_stats.py).
+Command (MI355X box, tools/profile_round.sh {tag}): `rocprofv3 --kernel-trace --stats -d gpurun_out/{tag}/trace -o t -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variants --no-pool --sustained-steps 0` (1 warm-up + 3 fully instrumented + 3 timed steps of 33 frames + 32 pairs, plus the steps of the PCIe-inclusive loop; rocpd sqlite summarised by tools/rocpd_stats.py).
 
 Un-profiled bench.py line from the same box just before: profiles/{rnd}_bench.json ({d['value']} frames/s, {d['ms_per_step']} ms/step; lg_attention avg {d['roofline']['avg_launch_ms'] * 1e3:.1f} us by HIP events in the timed region, {att_avg:.1f} us in this trace over its self (rotary, register-staged) and cross (LDS-DMA) kernels: {', '.join(f'{n} {a:.1f} us x {c}' for n, c, a in att)}).
 
@@ -63,7 +63,7 @@ Un-profiled bench.py line from the same box just before: profiles/{rnd}_bench.js
         notes = open(p).read()[open(p).read().index("## Notes"):]
     headp = f"""# Round {int(rnd[1:])} — PMC passes (final round-{int(rnd[1:])} kernels)
 
-Separate rocprofv3 runs, kernel-trace only (tools/profile_round.sh {tag}): `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, `--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE`; each `-- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants --sustained-steps 0`.
+Separate rocprofv3 runs, kernel-trace only (tools/profile_round.sh {tag}): `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, `--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE`; each `-- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants --no-pool --sustained-steps 0`.
 FETCH_SIZE / WRITE_SIZE: KiB per dispatch averaged per kernel. HBM traffic per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 B (gfx950 FETCH_SIZE counts half of wide coalesced reads, MI355X guide HBM section; WRITE_SIZE uncalibrated).
 SQ rows are per XCD/SE slice: MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (32 * GRBM_GUI_ACTIVE); clock = GRBM_GUI_ACTIVE / duration.
 

@@ -28,7 +28,7 @@ def main():
             for kv in filter(None, envs.split(",")):
                 k, _, val = kv.partition("=")
                 env[k] = val
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(a.steps), "--warmup", "3", "--no-cpu-baseline", "--no-pcie",
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(a.steps), "--warmup", "3", "--no-cpu-baseline", "--no-pcie", "--no-pool",
                                 "--sustained-steps", "0"] + a.extra.split(), env=env, capture_output=True, text=True)
             try:
                 d = json.loads(r.stdout.strip().splitlines()[-1])
