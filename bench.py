@@ -666,6 +666,29 @@ def main():
                                                   "threshold, every frame has its own keypoint count (ragged sequences, masked attention / assignment)")
         ctx.set_weights(capi.KIND_SUPERPOINT, wsp)
         step(); fence()      # the resident results are those of the bench weights again (cpu_baseline checks them)
+        # RFE_OPT_LG_FP16X2 (default off, include/rover_fe.h): LightGlue's Linears and attention as split products on the f16 matrix pipe (gemm_h2.hip, lg_attention_h2.hip).
+        # Same frames, weights and Kmax as the headline; compared here with the fp32 path's resident results, never the headline.
+        S32, p32, m32 = S.cpu().numpy().copy(), pairs.cpu().numpy().copy(), ms.cpu().numpy().copy()
+        ctx.set_option(capi.OPT_LG_FP16X2, 1)
+        try:
+            run_variant(KMAX, "fp16x2", "RFE_OPT_LG_FP16X2 = 1: every LightGlue Linear and the fused attention of the batched call as fp16 (hi + lo) x fp16 (hi + lo), "
+                                        "three products on v_mfma_f32_32x32x16_f16 with fp32 accumulation; softmax, LayerNorm / GELU, assignment and SuperPoint unchanged (fp32)")
+            ctx.profile_filter(None); ctx.profile(True); ctx.profile_reset()
+            for _ in range(3):
+                step()
+            fence()
+            ph2 = ctx.profile_read()
+            ctx.profile(False)
+            variants["fp16x2"]["stages_ms_per_step"] = {k: round(v[0] / 3, 4) for k, v in sorted(ph2.items(), key=lambda kv: -kv[1][0])
+                                                                if k.startswith("lg_")}
+            Sh, ph, mh = S.cpu().numpy(), pairs.cpu().numpy(), ms.cpu().numpy()
+            same = bool(np.array_equal(Sh, S32) and all(np.array_equal(ph[q, :S32[q]], p32[q, :S32[q]]) for q in range(B - 1)))
+            devh = max([float(np.abs(mh[q, :S32[q]] - m32[q, :S32[q]]).max()) for q in range(B - 1) if S32[q] > 0 and Sh[q] == S32[q]] or [0.0]) if same else None
+            variants["fp16x2"].update({"match_lists_identical_to_fp32_path": same, "match_score_max_dev_vs_fp32_path": devh,
+                                               "matches_total": int(S32.sum())})
+        finally:
+            ctx.set_option(capi.OPT_LG_FP16X2, 0)
+        step(); fence()      # ... and of the fp32 path
 
     pcie = None
     if world == 1 and not args.no_pcie:
@@ -716,6 +739,11 @@ def main():
         # The same 33-frame step through the C-ABI pool a C / C++ host would use (rfe_pool_*, rover-slam_amd/csrc/rfe_pool.hip): HOST frames in,
         # HOST results out (pageable memory, no overlap between calls), one member on this device, its rows gathered into the root buffer
         # through RCCL when librccl could be opened (self send / receive), copies otherwise.  Never the headline value.
+        # (RCCL's version banner goes to C stdout when the pool's communicator comes up: fd 1 points at stderr for the duration)
+        import ctypes as _ctp
+        sys.stdout.flush()
+        _saved1 = os.dup(1)
+        os.dup2(2, 1)
         pool = capi.Pool([dev.index or 0])
         try:
             pool.set_weights(capi.KIND_SUPERPOINT, wsp); pool.set_weights(capi.KIND_LIGHTGLUE, wlg)
@@ -741,6 +769,9 @@ def main():
                 print("bench.py: the pool call's results differ from the resident path", file=sys.stderr)
         finally:
             pool.close()
+            _ctp.CDLL(None).fflush(None)
+            os.dup2(_saved1, 1)
+            os.close(_saved1)
 
     bad_exit = 0
     gathered_ok = None

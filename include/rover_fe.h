@@ -80,8 +80,18 @@ uint64_t rfe_weights_id(rfe_ctx* ctx, int kind);
  *   message is simply never rounded to fp32.  0 keeps the graph of lightglue_sim.onnx node for node.  Measured over 40
  *   cases at K = 1024 (profiles/r02_lg_tolerance.md): match lists identical either way; match scores move by <= 3.2e-4
  *   (folded) / <= 2.0e-4 (unfolded) against the fp32 CPU oracle, which itself sits up to 2.6e-4 from a float64 evaluation
- *   of the same graph (HIP vs float64: 2.4e-4 / 1.8e-4) -- the stated tolerance is 5e-4 for both. */
+ *   of the same graph (HIP vs float64: 2.4e-4 / 1.8e-4) -- the stated tolerance is 5e-4 for both.
+ * RFE_OPT_LG_FP16X2 (default 0 = every LightGlue matrix product on the fp32 matrix instructions): 1 = the Linears AND the fused attention
+ *   of batched calls (>= 32 768 token rows: the shapes that take the throughput tiles) run as SPLIT products on the f16 matrix pipe --
+ *   every fp32 operand as fp16 hi + fp16 lo (22 of 24 significand bits), three of the four cross products, fp32 accumulation, softmax
+ *   and LayerNorm / GELU in fp32 as before (rover-slam_amd/csrc/gemm_h2.hip, lg_attention_h2.hip).  Stand-alone the Linears are
+ *   2.1-2.8x and the attention 2.4x faster than the fp32 kernels; error against float64: Linears rms 3.2e-8 of sum|a||b| (fp32 fmaf
+ *   chain: 2.8e-8), attention context 3.7e-6 (fp32 kernels: 4.8e-6) (profiles/r03_ab_notes.md, tests/test_gpu_attention.py); end to end
+ *   over the 40-case study the match lists are identical and the scores deviate from float64 no more than the fp32 path's
+ *   (profiles/r03_lg_tolerance.md).  Valid while activations stay below fp16's 65504 in magnitude (LightGlue's are O(1..100)).  The
+ *   assignment and all of SuperPoint stay fp32; bench.py reports it as `variants.fp16x2`, never as the headline. */
 #define RFE_OPT_LG_FOLD_WO 1
+#define RFE_OPT_LG_FP16X2 2
 int rfe_set_option(rfe_ctx* ctx, int option, int value);
 int rfe_get_option(rfe_ctx* ctx, int option, int* value);
 
@@ -282,6 +292,12 @@ int rfe_k_lightglue_taps(rfe_ctx* ctx, const float* k0n, const float* k1n, const
  * (x, second, out: device [rows,256]; out may not alias x), self (cross = 0) or cross block of `layer`.  Goes through the forward's
  * own code, so the row count selects the tiling: >= 32768 rows = throughput tiles with the fused LayerNorm + GELU. */
 int rfe_k_lightglue_ffn(rfe_ctx* ctx, int layer, int cross, const float* x_dev, const float* second_dev, int rows, float* out_dev);
+/* The fused attention alone: out[seq][q][head*64 + d] = softmax(Q K^T / 8) V per (sequence, head), 4 heads of 64 (device pointers, row
+ * stride ld floats for q / k / v, out [nseq*Lq, 256]); qlen / klen: valid rows per sequence or NULL, kv_map: sequence -> sequence whose
+ * k / v it attends to or NULL, rope: LightGlue's rotary table [nseq*Lq, 32] of (cos, sin) pairs applied to q and k, or NULL.  Goes through
+ * the forward's launcher, so nseq * Lq and RFE_OPT_LG_FP16X2 select the kernel exactly as inside a match call. */
+int rfe_k_attention(rfe_ctx* ctx, const float* q_dev, const float* k_dev, const float* v_dev, int ld, float* out_dev, int nseq, int Lq, int Lk,
+                    const int32_t* qlen_dev, const int32_t* klen_dev, const int32_t* kv_map_dev, const float* rope_dev);
 /* One-shot tap for the NEXT LightGlue forward of this ctx, whichever entry point runs it (rfe_match[_dev] with P pairs,
  * rfe_extract_match_stream_dev, rfe_stereo_frame_dev) and therefore whichever tiling it selects: after the last layer the final
  * token states of pair `pair` are copied to x0_dev / x1_dev ([L,256] each, L = max(Mmax,Nmax) rounded up to 4; rows past the

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("RFE_LIBRARY") or os.path.join(_HERE, "librover_fe.so"
 
 KIND_SUPERPOINT, KIND_LIGHTGLUE = 1, 2
 OPT_LG_FOLD_WO = 1
+OPT_LG_FP16X2 = 2   # LightGlue Linears + attention of batched calls as split products on the f16 matrix pipe (default off)
 
 EXPORTS = [
     "rfe_init", "rfe_destroy", "rfe_last_error", "rfe_version", "rfe_load_weights", "rfe_set_weights",
@@ -23,7 +24,7 @@ EXPORTS = [
     "rfe_pool_create", "rfe_pool_destroy", "rfe_pool_last_error", "rfe_pool_size", "rfe_pool_ctx", "rfe_pool_has_rccl", "rfe_pool_set_weights",
     "rfe_pool_load_weights", "rfe_pool_set_option", "rfe_pool_shard", "rfe_pool_extract_match_stream",
     "rfe_profile_enable", "rfe_profile_filter", "rfe_profile_reset", "rfe_profile_read",
-    "rfe_k_conv3x3", "rfe_k_linear", "rfe_k_scoremap", "rfe_k_lightglue_taps", "rfe_k_set_lightglue_tap", "rfe_k_lightglue_ffn",
+    "rfe_k_conv3x3", "rfe_k_linear", "rfe_k_scoremap", "rfe_k_lightglue_taps", "rfe_k_set_lightglue_tap", "rfe_k_lightglue_ffn", "rfe_k_attention",
 ]
 
 if not os.path.exists(LIB_PATH):
@@ -88,6 +89,7 @@ lib.rfe_k_scoremap.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_
 lib.rfe_k_lightglue_taps.argtypes = [C.c_void_p, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]
 lib.rfe_k_set_lightglue_tap.argtypes = [C.c_void_p, C.c_int, _fp, _fp, _fp]
 lib.rfe_k_lightglue_ffn.argtypes = [C.c_void_p, C.c_int, C.c_int, _fp, _fp, C.c_int, _fp]
+lib.rfe_k_attention.argtypes = [C.c_void_p, _fp, _fp, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _fp]
 
 
 POOL_AUTO, POOL_RCCL, POOL_COPY = 0, 1, 2

@@ -363,6 +363,9 @@ int launch_gemm_nt(hipStream_t s, const GemmArgs& g_in) {
 #endif
     const int batch = g.batch > 0 ? g.batch : 1;
     auto tiles = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * batch; };
+    // RFE_OPT_LG_FP16X2: a LightGlue Linear whose weights come with fp16 (hi, lo) planes and whose shape takes the throughput tile
+    if (g.Bh && g.Bl && batch == 1 && !g.m_valid && !g.relu && g.N % 256 == 0 && g.K % 32 == 0 && (!g.A2 || g.K1 % 32 == 0) && tiles(128, 256) >= 256)
+        return launch_gemm_h2(s, g);
     const bool res = g.R != nullptr, lna = g.stats_in != nullptr;
     static const bool lni = tune_int("RFE_LN_INTERLEAVE", 1) != 0;   // tuning switch
 

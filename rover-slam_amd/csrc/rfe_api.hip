@@ -130,6 +130,7 @@ extern "C" int rfe_set_option(rfe_ctx* c, int option, int value) {
     if (!c) return RFE_ERR_INVALID;
     switch (option) {
         case RFE_OPT_LG_FOLD_WO: c->opt_lg_fold = value != 0; return RFE_OK;
+        case RFE_OPT_LG_FP16X2: c->opt_lg_fp16x2 = value != 0; return RFE_OK;
         default: return fail(c, RFE_ERR_INVALID, "rfe_set_option: unknown option");
     }
 }
@@ -137,6 +138,7 @@ extern "C" int rfe_get_option(rfe_ctx* c, int option, int* value) {
     if (!c || !value) return RFE_ERR_INVALID;
     switch (option) {
         case RFE_OPT_LG_FOLD_WO: *value = c->opt_lg_fold ? 1 : 0; return RFE_OK;
+        case RFE_OPT_LG_FP16X2: *value = c->opt_lg_fp16x2 ? 1 : 0; return RFE_OK;
         default: return fail(c, RFE_ERR_INVALID, "rfe_get_option: unknown option");
     }
 }
@@ -204,7 +206,7 @@ struct SpShared {
 };
 struct LgShared {
     rfe::LgWeightsDev w; int device = 0; std::vector<float> host;
-    ~LgShared() { (void)hipSetDevice(device); if (w.blob) (void)hipFree(w.blob); if (w.extra) (void)hipFree(w.extra); }
+    ~LgShared() { (void)hipSetDevice(device); if (w.blob) (void)hipFree(w.blob); if (w.extra) (void)hipFree(w.extra); if (w.h2) (void)hipFree(w.h2); }
 };
 std::mutex g_weights_mu;
 std::map<std::tuple<int, int, uint64_t, int>, std::weak_ptr<void>> g_weights;   // (device, kind, hash, collision index) -> device copy
@@ -371,6 +373,14 @@ static int set_lg_upload(rfe_ctx* c, const float* blob) {
         RFE_HIP(c, hipMemcpy(L.cbqkv, L.cbqk, 256 * 4, hipMemcpyDeviceToDevice));
         RFE_HIP(c, hipMemcpy(L.cbqkv + 256, L.cbv, 256 * 4, hipMemcpyDeviceToDevice));
     }
+    // fp16 (hi, lo) planes of both weight buffers for RFE_OPT_LG_FP16X2 (gemm_h2.hip): split once here, 2 x 2 bytes per float
+    if (W.h2) { RFE_HIP(c, hipFree(W.h2)); W.h2 = nullptr; }
+    W.n_blob = ((size_t)LG_COUNT + 63) & ~(size_t)63; W.n_extra = per * LG_LAYERS;     // plane starts stay 128-byte aligned (LG_COUNT is odd)
+    RFE_HIP(c, hipMalloc((void**)&W.h2, 2 * (W.n_blob + W.n_extra) * sizeof(uint16_t)));
+    launch_split_f16(c->stream, W.blob, W.h2, W.h2 + W.n_blob, (size_t)LG_COUNT);
+    launch_split_f16(c->stream, W.extra, W.h2 + 2 * W.n_blob, W.h2 + 2 * W.n_blob + W.n_extra, W.n_extra);
+    RFE_HIP(c, hipGetLastError());
+    RFE_HIP(c, hipStreamSynchronize(c->stream));
     c->has_lg = true;
     return RFE_OK;
 }
@@ -467,6 +477,17 @@ GemmArgs gemm_plain(const float* A, int lda, const float* Bw, int ldb, const flo
 GemmArgs gemm_lg(const float* A, int lda, const float* Bw, int ldb, const float* bias, float* C, int ldc, int M, int N, int K) {
     GemmArgs g = gemm_plain(A, lda, Bw, ldb, bias, C, ldc, M, N, K);
     g.kperm = 1;
+    return g;
+}
+// A LightGlue Linear whose weight matrix Bw lives in the ctx's weight buffers: with RFE_OPT_LG_FP16X2 on, the fp16 (hi, lo) planes of
+// the same matrix ride along and launch_gemm_nt takes the split GEMM for the throughput shapes (gemm_h2.hip)
+GemmArgs gemm_lgw(const rfe_ctx* c, const float* A, int lda, const float* Bw, int ldb, const float* bias, float* C, int ldc, int M, int N, int K) {
+    GemmArgs g = gemm_lg(A, lda, Bw, ldb, bias, C, ldc, M, N, K);
+    const LgWeightsDev& W = c->lg;
+    if (c->opt_lg_fp16x2 && W.h2) {
+        if (Bw >= W.blob && Bw < W.blob + LG_COUNT) { g.Bh = W.h2 + (Bw - W.blob); g.Bl = g.Bh + W.n_blob; }
+        else if (Bw >= W.extra && Bw < W.extra + W.n_extra) { g.Bh = W.h2 + 2 * W.n_blob + (Bw - W.extra); g.Bl = g.Bh + W.n_extra; }
+    }
     return g;
 }
 
@@ -645,13 +666,13 @@ void lg_ffn(rfe_ctx* c, LgBuffers& b, float* x, const float* second, int rows, c
     static const bool ln_fuse = tune_int("RFE_LN_FUSE", 1) != 0;
     int P = 0;
     { ProfScope p(c, "lg_ffn1");   // A = [x | second]: second is the message, or the attention context when Wo is folded into W1
-      GemmArgs a = gemm_lg(x, 256, w1, 512, b1, b.h, 512, rows, 512, 512);
+      GemmArgs a = gemm_lgw(c, x, 256, w1, 512, b1, b.h, 512, rows, 512, 512);
       a.A2 = second; a.lda2 = 256; a.K1 = 256;
       if (ln_fuse) a.stats_out = b.lnstat;
       P = launch_gemm_nt(s, a); }
     if (P == 0) { ProfScope p(c, "lg_ln_gelu"); launch_lg_ln_gelu(s, b.h, g, be, rows); }   // small problems (and RFE_LN_FUSE=0): stand-alone pass
     { ProfScope p(c, "lg_ffn2");
-      GemmArgs a = gemm_lg(b.h, 512, w2, 512, b2, x, 256, rows, 256, 512);
+      GemmArgs a = gemm_lgw(c, b.h, 512, w2, 512, b2, x, 256, rows, 256, 512);
       a.R = x; a.ldr = 256;
       if (P > 0) { a.stats_in = b.lnstat; a.stats_p = P; a.ln_g = g; a.ln_b = be; }
       launch_gemm_nt(s, a); }
@@ -662,13 +683,13 @@ void lg_self_block(rfe_ctx* c, LgBuffers& b, const LgLayerDev& Lw, float* x, con
     hipStream_t s = c->stream;
     const int rows = nseq * L;
     // q,k,v = Wqkv x + b (plain epilogue); the rotary of q and k is applied by the attention kernel as it loads them
-    { ProfScope p(c, "lg_qkv"); launch_gemm_nt(s, gemm_lg(x, 256, Lw.wqkv, 256, Lw.bqkv, b.qkv, 768, rows, 768, 256)); }
+    { ProfScope p(c, "lg_qkv"); launch_gemm_nt(s, gemm_lgw(c, x, 256, Lw.wqkv, 256, Lw.bqkv, b.qkv, 768, rows, 768, 256)); }
     { ProfScope p(c, "lg_attention");
-      launch_lg_attention(s, b.qkv, b.qkv + 256, b.qkv + 512, 768, b.ctx, nseq, L, L, lens, lens, nullptr, lg_part(b, nseq, L), csn); }
+      launch_lg_attention(s, b.qkv, b.qkv + 256, b.qkv + 512, 768, b.ctx, nseq, L, L, lens, lens, nullptr, lg_part(b, nseq, L), csn, c->opt_lg_fp16x2); }
     if (c->opt_lg_fold) {
         lg_ffn(c, b, x, b.ctx, rows, Lw.w1f, Lw.b1f, Lw.lng, Lw.lnb, Lw.w2, Lw.b2);
     } else {
-        { ProfScope p(c, "lg_proj"); launch_gemm_nt(s, gemm_lg(b.ctx, 256, Lw.wo, 256, Lw.bo, b.msg, 256, rows, 256, 256)); }
+        { ProfScope p(c, "lg_proj"); launch_gemm_nt(s, gemm_lgw(c, b.ctx, 256, Lw.wo, 256, Lw.bo, b.msg, 256, rows, 256, 256)); }
         lg_ffn(c, b, x, b.msg, rows, Lw.w1, Lw.b1, Lw.lng, Lw.lnb, Lw.w2, Lw.b2);
     }
 }
@@ -686,18 +707,18 @@ int lg_forward(rfe_ctx* c, LgBuffers& b, int P, int L, float thr, int cap, int32
         const LgLayerDev& Lw = W.L[l];
         if (l > 0 || !first_self_done) lg_self_block(c, b, Lw, b.x, b.csn, b.lens, nseq, L);
         // ---- cross block
-        { ProfScope p(c, "lg_cross_qkv"); launch_gemm_nt(s, gemm_lg(b.x, 256, Lw.cwqkv, 256, Lw.cbqkv, b.qkv, 512, rows, 512, 256)); }
-        { ProfScope p(c, "lg_attention"); launch_lg_attention(s, b.qkv, b.qkv, b.qkv + 256, 512, b.ctx, nseq, L, L, b.lens, b.lens, b.kvmap, lg_part(b, nseq, L)); }
+        { ProfScope p(c, "lg_cross_qkv"); launch_gemm_nt(s, gemm_lgw(c, b.x, 256, Lw.cwqkv, 256, Lw.cbqkv, b.qkv, 512, rows, 512, 256)); }
+        { ProfScope p(c, "lg_attention"); launch_lg_attention(s, b.qkv, b.qkv, b.qkv + 256, 512, b.ctx, nseq, L, L, b.lens, b.lens, b.kvmap, lg_part(b, nseq, L), nullptr, c->opt_lg_fp16x2); }
         if (c->opt_lg_fold) {
             lg_ffn(c, b, b.x, b.ctx, rows, Lw.cw1f, Lw.cb1f, Lw.clng, Lw.clnb, Lw.cw2, Lw.cb2);
         } else {
-            { ProfScope p(c, "lg_proj"); launch_gemm_nt(s, gemm_lg(b.ctx, 256, Lw.cwo, 256, Lw.cbo, b.msg, 256, rows, 256, 256)); }
+            { ProfScope p(c, "lg_proj"); launch_gemm_nt(s, gemm_lgw(c, b.ctx, 256, Lw.cwo, 256, Lw.cbo, b.msg, 256, rows, 256, 256)); }
             lg_ffn(c, b, b.x, b.msg, rows, Lw.cw1, Lw.cb1, Lw.clng, Lw.clnb, Lw.cw2, Lw.cb2);
         }
     }
     // ---- assignment
     { ProfScope p(c, "lg_proj");
-      GemmArgs a = gemm_lg(b.x, 256, W.wp, 256, W.bp, b.md, 256, rows, 256, 256);
+      GemmArgs a = gemm_lgw(c, b.x, 256, W.wp, 256, W.bp, b.md, 256, rows, 256, 256);
       a.alpha = 0.25f;  // / 256^(1/4)
       launch_gemm_nt(s, a); }
     { ProfScope p(c, "lg_sim");
@@ -1295,6 +1316,22 @@ extern "C" int rfe_k_lightglue_ffn(rfe_ctx* c, int layer, int cross, const float
     else lg_ffn(c, b, out, second, rows, Lw.w1, Lw.b1, Lw.lng, Lw.lnb, Lw.w2, Lw.b2);
     RFE_HIP(c, hipGetLastError());
     RFE_HIP(c, hipStreamSynchronize(c->stream));
+    return RFE_OK;
+}
+
+extern "C" int rfe_k_attention(rfe_ctx* c, const float* q, const float* k, const float* v, int ld, float* out, int nseq, int Lq, int Lk,
+                               const int32_t* qlen, const int32_t* klen, const int32_t* kv_map, const float* rope) {
+    if (!c) return RFE_ERR_INVALID;
+    if (!q || !k || !v || !out || nseq <= 0 || Lq <= 0 || Lk <= 0 || ld < 256) return fail(c, RFE_ERR_INVALID, "k_attention: bad argument");
+    RFE_HIP(c, hipSetDevice(c->device));
+    float* part = nullptr;
+    const size_t pb = lg_attention_part_bytes(nseq, Lq);
+    if (pb) RFE_HIP(c, hipMalloc((void**)&part, pb));
+    launch_lg_attention(c->stream, q, k, v, ld, out, nseq, Lq, Lk, qlen, klen, kv_map, part, rope, c->opt_lg_fp16x2);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (part) (void)hipFree(part);
+    RFE_HIP(c, e);
     return RFE_OK;
 }
 

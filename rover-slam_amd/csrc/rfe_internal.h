@@ -60,6 +60,10 @@ struct LgWeightsDev {
     float* wr;
     LgLayerDev L[LG_LAYERS];
     float *wp, *bp, *wm, *bm;
+    // fp16 (hi, lo) planes of every float of `blob` and `extra`, made at load time for RFE_OPT_LG_FP16X2 (gemm_h2.hip):
+    // h2 = [hi blob | lo blob | hi extra | lo extra]; the planes of a weight matrix sit at the matrix' own offset inside its buffer
+    uint16_t* h2 = nullptr;
+    size_t n_blob = 0, n_extra = 0;
 };
 
 // ---------------------------------------------------------------- profiling
@@ -83,6 +87,9 @@ struct GemmArgs {
     // launch_gemm_nt --, the consumer normalises its A operand while staging it: gelu(((a - mean) * rstd) * ln_g[k] + ln_b[k])
     float* stats_out;
     const float* stats_in; int stats_p; const float* ln_g; const float* ln_b;
+    // optional fp16 (hi, lo) planes of B, same [N][K] layout and ldb (RFE_OPT_LG_FP16X2): the shapes that would take the 128 x 256
+    // throughput tile run gemm_h2.hip's split GEMM on the f16 matrix pipe instead; everything else ignores them
+    const uint16_t* Bh; const uint16_t* Bl;
     // kperm != 0: the caller does not need the k-ascending reduction order (LightGlue: tolerance-checked, not bit-exact).  The 128-row
     // tiles then use the 16-byte-swizzled LDS layout with 128-bit fragment reads, which consume k in the order (s, 16 + s) per K tile.
     int kperm;
@@ -102,6 +109,7 @@ struct rfe_ctx {
     std::string err;
     bool has_sp = false, has_lg = false;
     bool opt_lg_fold = true;             // RFE_OPT_LG_FOLD_WO
+    bool opt_lg_fp16x2 = false;          // RFE_OPT_LG_FP16X2
     rfe::SpWeightsDev sp;                // views into *sp_hold / *lg_hold
     rfe::LgWeightsDev lg;
     std::shared_ptr<void> sp_hold, lg_hold;   // device copies, shared by every ctx of the process that loaded the same blob on the same device
@@ -157,6 +165,8 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
 void launch_conv1ab_fused(hipStream_t s, const uint8_t* img, int stride, int B, int H, int W, const float* w1a,
                           const float* b1a, const float* wp, const float* bias, float* out);
 // gemm.hip
+int launch_gemm_h2(hipStream_t s, const GemmArgs& g);   // gemm_h2.hip: split GEMM on the f16 matrix pipe (GemmArgs::Bh / Bl), called by launch_gemm_nt
+void launch_split_f16(hipStream_t s, const float* x, uint16_t* hi, uint16_t* lo, size_t n);
 int launch_gemm_nt(hipStream_t s, const GemmArgs& g);   // returns the number of partial-statistics pairs per row it wrote (0 without stats_out)
 // sp_post.hip
 void launch_softmax65_d2s(hipStream_t s, const float* logits, int ld, int B, int Hc, int Wc, float* score);
@@ -174,7 +184,10 @@ void launch_lg_attention(hipStream_t s, const float* q, const float* k, const fl
                          float* out, int nseq, int Lq, int Lk, const int* qlen, const int* klen,
                          const int* kv_map /*seq -> kv seq index, or null = identity*/,
                          float* part /*lg_attention_part_bytes(nseq, Lq) of scratch for the split-key variant, or null*/,
-                         const float* rope_csn = nullptr /*self blocks: rotary table [nseq*Lq, 32] of (cos, sin) pairs, applied to q and k on load*/);
+                         const float* rope_csn = nullptr /*self blocks: rotary table [nseq*Lq, 32] of (cos, sin) pairs, applied to q and k on load*/,
+                         bool fp16x2 = false /*RFE_OPT_LG_FP16X2: problems of >= 32 768 query rows take lg_attention_h2.hip's split products on the f16 matrix pipe*/);
+void launch_lg_attention_h2(hipStream_t s, const float* q, const float* k, const float* v, int ld, float* out, int nseq, int Lq, int Lk,
+                            const int* qlen, const int* klen, const int* kv_map, const float* rope_csn);   // lg_attention_h2.hip
 size_t lg_attention_part_bytes(int nseq, int Lq);
 void launch_lg_ln_gelu(hipStream_t s, float* h, const float* g, const float* b, int64_t rows);
 void launch_lg_assign(hipStream_t s, const float* sim, const float* z0, const float* z1, int P, int L,

@@ -1,0 +1,101 @@
+"""The fused attention kernels alone (rfe_k_attention) against a float64 evaluation: softmax(Q K^T / 8) V per (sequence, head), with
+LightGlue's rotary on q / k (self blocks) or a kv_map (cross blocks), ragged lengths, at the THROUGHPUT shape (32 sequences of 1024 =
+32 768 query rows).  Both arithmetic routes of the throughput path are measured against the same float64 result:
+  * the default fp32-MFMA kernels (lg_attention_kernel / lg_attention_dma_kernel, lg_kernels.hip),
+  * RFE_OPT_LG_FP16X2 = 1: lg_attention_h2.hip (fp16 hi + lo operand pairs, three products, fp32 accumulation),
+and the split route may not be less accurate than fp32-class: the bound is the same for both.  The reference evaluates this inside
+Session::Run(lightglue_sim.onnx), src/Matchers/lightglue_onnx.cpp:210-214."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ATT_TOL = 2e-5   # max |context - float64| for O(1) values; the fp32 kernels sit at ~1e-6
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from rover_slam_amd import capi
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _attention_f64(q, k, v, nq, nk, rope_q=None, rope_k=None):
+    """q [Lq,256], k / v [Lk,256] float32 -> context [Lq,256] float64; rows >= nq are zero."""
+    def rot(x, cs):
+        if cs is None:
+            return x.astype(np.float64)
+        x = x.astype(np.float64).reshape(x.shape[0], 4, 32, 2)
+        c, s = cs[:, None, :, 0].astype(np.float64), cs[:, None, :, 1].astype(np.float64)
+        a, b = x[..., 0], x[..., 1]
+        return np.stack([a * c - b * s, b * c + a * s], -1).reshape(x.shape[0], 256)
+    qq, kk, vv = rot(q, rope_q)[:nq], rot(k, rope_k)[:nk], v.astype(np.float64)[:nk]
+    out = np.zeros((q.shape[0], 256))
+    for h in range(4):
+        s = qq[:, 64 * h:64 * h + 64] @ kk[:, 64 * h:64 * h + 64].T * 0.125
+        s -= s.max(1, keepdims=True)
+        p = np.exp(s)
+        p /= p.sum(1, keepdims=True)
+        out[:nq, 64 * h:64 * h + 64] = p @ vv[:, 64 * h:64 * h + 64]
+    return out
+
+
+def _run(ctx, capi, x, offs, ld, nseq, L, lens, kvmap, rope, fp16x2):
+    bufs = []
+    def up(a):
+        b = ctx.alloc(a.nbytes); b.upload(a); bufs.append(b); return b
+    dq = up(x)
+    dout = ctx.alloc(nseq * L * 1024); bufs.append(dout)
+    dlen = up(lens.astype(np.int32))
+    dmap = up(kvmap.astype(np.int32)) if kvmap is not None else None
+    drope = up(rope) if rope is not None else None
+    ctx.set_option(capi.OPT_LG_FP16X2, 1 if fp16x2 else 0)
+    try:
+        ctx._chk(capi.lib.rfe_k_attention(ctx.h, dq.ptr + offs[0] * 4, dq.ptr + offs[1] * 4, dq.ptr + offs[2] * 4, ld, dout.ptr, nseq, L, L, dlen.ptr, dlen.ptr,
+                                          dmap.ptr if dmap else None, drope.ptr if drope else None))
+    finally:
+        ctx.set_option(capi.OPT_LG_FP16X2, 0)
+    out = dout.download((nseq, L, 256), np.float32)
+    for b in bufs:
+        b.free()
+    return out
+
+
+@pytest.mark.parametrize("kind", ["self_rope", "cross"])
+def test_attention_throughput_shape_vs_float64(ctx, kind):
+    from rover_slam_amd import capi
+    rng = np.random.default_rng(5 if kind == "cross" else 6)
+    nseq, L = 32, 1024
+    lens = np.full(nseq, L, np.int32)
+    lens[[1, 6, 7, 20]] = [650, 1001, 257, 32]          # ragged: partial last tiles, a sequence shorter than one query block
+    if kind == "self_rope":
+        ld, offs, kvmap = 768, (0, 256, 512), None       # [q | k | v] rows as the self block's projection writes them
+        rope = np.empty((nseq * L, 32, 2), np.float32)
+        th = rng.uniform(-3.0, 3.0, (nseq * L, 32))
+        rope[..., 0], rope[..., 1] = np.cos(th), np.sin(th)
+    else:
+        ld, offs, rope = 512, (0, 0, 256), None          # [qk | v]: the cross block's shared query / key projection
+        kvmap = np.arange(nseq) ^ 1                      # sequence 2 p attends to 2 p + 1 and back
+    x = rng.standard_normal((nseq * L, ld)).astype(np.float32)
+    x[:, :ld - 256] *= 1.5                               # q / k: logits with a standard deviation of ~2.3, peaky rows
+    x[::7, 3] += 6.0                                     # a few dominant keys / queries: exercises the moving softmax reference
+    xs = x.reshape(nseq, L, ld)
+    check = [0, 1, 6, 7, 20, 21, 31]
+    ref = {}
+    for s in check:
+        t = kvmap[s] if kvmap is not None else s
+        r = rope.reshape(nseq, L, 32, 2) if rope is not None else None
+        ref[s] = _attention_f64(xs[s][:, offs[0]:offs[0] + 256], xs[t][:, offs[1]:offs[1] + 256], xs[t][:, offs[2]:offs[2] + 256],
+                                int(lens[s]), int(lens[t]), r[s] if r is not None else None, r[t] if r is not None else None)
+    errs = {}
+    for fp16x2 in (0, 1):
+        out = _run(ctx, capi, x, offs, ld, nseq, L, lens, kvmap, rope, fp16x2)
+        assert np.isfinite(out).all()
+        worst = 0.0
+        for s in check:
+            worst = max(worst, float(np.abs(out[s] - ref[s]).max()))
+            assert not out[s][lens[s]:].any(), "context rows past the sequence length must be zero"
+        errs[fp16x2] = worst
+    print(f"attention {kind}: max |context - float64|  fp32 kernels {errs[0]:.2e}   fp16x2 split kernel {errs[1]:.2e}")
+    assert errs[0] < ATT_TOL and errs[1] < ATT_TOL, errs

@@ -183,3 +183,45 @@ def test_fused_layernorm_rows_with_large_mean(ctx):
     for b in (dx, dsec, dout):
         b.free()
     c2.close()
+
+
+def test_lightglue_batch16_fp16x2_vs_oracle(ctx, oracle):
+    """RFE_OPT_LG_FP16X2 (default off): the Linears and the attention of a 16-pair call as split products on the f16 matrix pipe (gemm_h2.hip,
+    lg_attention_h2.hip: fp16 hi + lo operands, three products, fp32 accumulation).  Same bar as the fp32 path: every pair against the oracle -- match list (borderline
+    rule), match scores within LG_SCORE_TOL, > 400 matches -- and one pair's final token states / log-assignment matrix through the tap.
+    Also: the option really changes the arithmetic (results differ from the fp32 path in the last bits) and switches back."""
+    from rover_slam_amd import capi
+    P, K, tap_pair = 16, 1024, 5
+    lens0 = [1024] * P; lens1 = [1024] * P
+    lens0[2], lens1[7], lens0[11], lens1[11] = 650, 980, 777, 1003
+    k0, k1, d0, d1 = _constructed_batch(P, K, 91, lens0, lens1)
+    dx0, dx1, dsc = ctx.alloc(K * 1024), ctx.alloc(K * 1024), ctx.alloc(K * K * 4)
+    assert ctx.get_option(capi.OPT_LG_FP16X2) == 0
+    S32, pairs32, ms32 = ctx.match(k0, k1, d0, d1, lens0, lens1)
+    ctx.set_option(capi.OPT_LG_FP16X2, 1)
+    try:
+        assert ctx.get_option(capi.OPT_LG_FP16X2) == 1
+        ctx._chk(capi.lib.rfe_k_set_lightglue_tap(ctx.h, tap_pair, dx0.ptr, dx1.ptr, dsc.ptr))
+        S, pairs, ms = ctx.match(k0, k1, d0, d1, lens0, lens1)
+    finally:
+        ctx.set_option(capi.OPT_LG_FP16X2, 0)
+    total, worst = 0, 0.0
+    for p in range(P):
+        m, n = lens0[p], lens1[p]
+        ref = oracle.lightglue(Wt.make_lightglue(seed=11), k0[p, :m], k1[p, :n], d0[p, :m], d1[p, :n], debug=True)
+        ok, dev, only = lists_agree_borderline(pairs[p, :S[p]], ms[p, :S[p]], ref["pairs"], ref["ms"], ref["scores"], K)
+        assert ok and dev < LG_SCORE_TOL, (p, int(S[p]), ref["S"], dev, only)
+        assert ref["S"] > 400
+        total += int(S[p]); worst = max(worst, dev)
+        if p == tap_pair:
+            x0 = dx0.download((K, 256), np.float32)[:m]; x1 = dx1.download((K, 256), np.float32)[:n]
+            assert np.abs(x0 - ref["x0"]).max() < LG_STATE_TOL and np.abs(x1 - ref["x1"]).max() < LG_STATE_TOL
+            sc = dsc.download((K, K), np.float32)[:m, :n]
+            assert np.abs(np.exp(sc) - np.exp(ref["scores"])).max() < LG_SCORE_TOL
+    differs = any(not np.array_equal(ms[p, :S[p]], ms32[p, :S32[p]]) for p in range(P) if S[p] == S32[p])
+    assert differs, "RFE_OPT_LG_FP16X2 = 1 produced bit-identical scores: the split GEMM did not run"
+    S_b, pairs_b, ms_b = ctx.match(k0, k1, d0, d1, lens0, lens1)          # option off again: the fp32 path, bit for bit
+    assert np.array_equal(S_b, S32) and all(np.array_equal(ms_b[p, :S32[p]], ms32[p, :S32[p]]) for p in range(P))
+    print(f"batch16 fp16x2: {total} matches over {P} pairs, max |score dev| vs oracle {worst:.2e}")
+    for b in (dx0, dx1, dsc):
+        b.free()

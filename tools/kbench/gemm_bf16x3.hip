@@ -15,6 +15,7 @@
 #include <vector>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
@@ -31,6 +32,24 @@ __device__ __forceinline__ void split2(float x, float y, uint32_t& p0, uint32_t&
     p1 = cvt_pk_bf16(rx, ry);
     const float sx = rx - __uint_as_float(p1 << 16), sy = ry - __uint_as_float(p1 & 0xffff0000u);
     p2 = cvt_pk_bf16(sx, sy);
+}
+
+// two-term fp16 split of two floats: a = a0 + a1 with a0 = fp16(a) (11 significand bits, round to nearest), a1 = fp16(a - a0) (the next
+// 11): 22 bits of the 24 -- the representation error is 2^-22 |a| (plus fp16's absolute floor 2^-25 for the residual of small values:
+// fp16 subnormals), i.e. about 4 fp32 ulps.  Planes p0, p1 hold (lo, hi) packed.
+__device__ __forceinline__ void split2_f16(float x, float y, uint32_t& p0, uint32_t& p1) {
+    const _Float16 hx = (_Float16)x, hy = (_Float16)y;
+    const _Float16 lx = (_Float16)(x - (float)hx), ly = (_Float16)(y - (float)hy);
+    p0 = (uint32_t)__builtin_bit_cast(uint16_t, hx) | ((uint32_t)__builtin_bit_cast(uint16_t, hy) << 16);
+    p1 = (uint32_t)__builtin_bit_cast(uint16_t, lx) | ((uint32_t)__builtin_bit_cast(uint16_t, ly) << 16);
+}
+__global__ void presplit_f16_kernel(const float* __restrict__ x, uint16_t* __restrict__ out, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (i >= n) return;
+    uint32_t p0, p1;
+    split2_f16(x[i], x[i + 1], p0, p1);
+    *reinterpret_cast<uint32_t*>(out + i) = p0;
+    *reinterpret_cast<uint32_t*>(out + n + i) = p1;
 }
 
 // one-off: fp32 [rows][K] -> three bf16 planes [3][rows][K]
@@ -51,11 +70,12 @@ __global__ void presplit_kernel(const float* __restrict__ x, uint16_t* __restric
 // PF: the next K tile is fetched into registers before the MFMA loop of the current one.  XM: XCD-aware block mapping -- the N/256
 // column tiles of one 128-row panel are consecutive workgroups of ONE XCD (block b runs on XCD b % 8), so the panel's second and
 // third read hit that XCD's L2.
-template <bool SPLIT_A, int NPROD, bool PF = false, bool XM = false, int ORD = 0>
+// F16: the planes are fp16 (two of them: split2_f16): NPROD = 3 -> a0b0 + a0b1 + a1b0, NPROD = 4 -> + a1b1.
+template <bool SPLIT_A, int NPROD, bool PF = false, bool XM = false, int ORD = 0, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_b3_kernel(const void* __restrict__ Aany, const uint16_t* __restrict__ Bp, const float* __restrict__ bias,
                                                          float* __restrict__ C, int M, int N, int K) {
     constexpr int BM = 128, BN = 256, BK = 32, MB = 2, NB = 4;
-    constexpr int NPL = NPROD == 1 ? 1 : NPROD == 3 ? 2 : 3;          // planes needed
+    constexpr int NPL = F16 ? 2 : NPROD == 1 ? 1 : NPROD == 3 ? 2 : 3;          // planes needed
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * (BM + BN) * 64];
     unsigned char* const As = lds;                    // [3][BM][64 B]
     unsigned char* const Bs = lds + 3 * BM * 64;      // [3][BN][64 B]
@@ -109,9 +129,9 @@ __global__ __launch_bounds__(256, 2) void gemm_b3_kernel(const void* __restrict_
         if (SPLIT_A) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                uint32_t p0a, p1a, p2a, p0b, p1b, p2b;
-                split2(fa[it].x, fa[it].y, p0a, p1a, p2a);
-                split2(fa[it].z, fa[it].w, p0b, p1b, p2b);
+                uint32_t p0a, p1a, p2a = 0, p0b, p1b, p2b = 0;
+                if (F16) { split2_f16(fa[it].x, fa[it].y, p0a, p1a); split2_f16(fa[it].z, fa[it].w, p0b, p1b); }
+                else { split2(fa[it].x, fa[it].y, p0a, p1a, p2a); split2(fa[it].z, fa[it].w, p0b, p1b, p2b); }
                 const int row = (tid >> 3) + 32 * it, kq = tid & 7;          // 4 k = half a 16-byte slot: slot kq / 2, byte 8 (kq & 1)
                 const int off = row * 64 + (((kq >> 1) ^ ((row >> 2) & 3)) << 4) + ((kq & 1) << 3);
                 *reinterpret_cast<u32x2*>(As + off) = u32x2{p0a, p0b};
@@ -138,6 +158,23 @@ __global__ __launch_bounds__(256, 2) void gemm_b3_kernel(const void* __restrict_
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) a[mb][pl] = *reinterpret_cast<const bf16x8*>(As + pl * BM * 64 + ((wm * MB + mb) * 32 + i) * 64 + slot);
+            if (F16) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    f16x8 hb[2];
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) hb[pl] = *reinterpret_cast<const f16x8*>(Bs + pl * BN * 64 + ((wn * NB + nb) * 32 + i) * 64 + slot);
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        const f16x8 ha0 = __builtin_bit_cast(f16x8, a[mb][0]), ha1 = __builtin_bit_cast(f16x8, a[mb][1]);
+                        if (NPROD == 4) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha1, hb[1], acc[mb][nb], 0, 0, 0);
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha1, hb[0], acc[mb][nb], 0, 0, 0);
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha0, hb[1], acc[mb][nb], 0, 0, 0);
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha0, hb[0], acc[mb][nb], 0, 0, 0);
+                    }
+                }
+                continue;
+            }
             if (ORD == 2 && NPROD == 6) {   // product outer, the eight accumulators inner: eight MFMAs between two uses of an accumulator
                 bf16x8 b[NB][3];
 #pragma unroll
@@ -451,6 +488,8 @@ static void run_shape(const char* name, int M, int N, int K, bool wide_range) {
     CK(hipMemcpy(db, hb.data(), N * 4, hipMemcpyHostToDevice));
     presplit_kernel<<<(unsigned)((hA.size() / 2 + 255) / 256), 256>>>(dA, pA, hA.size());
     presplit_kernel<<<(unsigned)((hB.size() / 2 + 255) / 256), 256>>>(dB, pB, hB.size());
+    uint16_t* hB16; CK(hipMalloc(&hB16, hB.size() * 4));
+    presplit_f16_kernel<<<(unsigned)((hB.size() / 2 + 255) / 256), 256>>>(dB, hB16, hB.size());
     CK(hipMalloc(&pkB, hB.size() * 6));
     pack_b_kernel<<<(unsigned)((hB.size() / 2 + 255) / 256), 256>>>(dB, pkB, N, K);
     CK(hipDeviceSynchronize());
@@ -482,9 +521,11 @@ static void run_shape(const char* name, int M, int N, int K, bool wide_range) {
     report("bf16x3, 6 products, split A, prefetch + XCD map", timeit([&] { gemm_b3_kernel<true, 6, true, true><<<dim3((N / 256) * (M / 128)), 256>>>(dA, pB, db, dC, M, N, K); }));
     report("bf16x3 wide 256x256, packed B via LDS-DMA", timeit([&] { gemm_b3w_kernel<false><<<dim3(N / 256, M / 256), 512>>>(dA, pkB, db, dC, M, N, K); }));
     report("bf16x3 wide 256x256, packed B, XCD map", timeit([&] { gemm_b3w_kernel<true><<<dim3((N / 256) * (M / 256)), 512>>>(dA, pkB, db, dC, M, N, K); }));
+    report("fp16x2, 3 products (a0b0 + a0b1 + a1b0), A split at staging", timeit([&] { gemm_b3_kernel<true, 3, false, false, 0, true><<<grid, 256>>>(dA, hB16, db, dC, M, N, K); }));
+    report("fp16x2, 4 products (+ a1b1), A split at staging", timeit([&] { gemm_b3_kernel<true, 4, false, false, 0, true><<<grid, 256>>>(dA, hB16, db, dC, M, N, K); }));
     report("bf16x2, 3 products, A split at staging", timeit([&] { gemm_b3_kernel<true, 3><<<grid, 256>>>(dA, pB, db, dC, M, N, K); }));
     report("plain bf16, 1 product, A converted at staging", timeit([&] { gemm_b3_kernel<true, 1><<<grid, 256>>>(dA, pB, db, dC, M, N, K); }));
-    CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(db)); CK(hipFree(dC)); CK(hipFree(pA)); CK(hipFree(pB)); CK(hipFree(pkB));
+    CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(db)); CK(hipFree(dC)); CK(hipFree(pA)); CK(hipFree(pB)); CK(hipFree(pkB)); CK(hipFree(hB16));
 }
 
 int main(int argc, char** argv) {

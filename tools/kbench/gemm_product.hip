@@ -40,5 +40,25 @@ int main() {
     { GemmArgs g = plain(x, 256, w, 256, bias, qkv, 768, M, 768, 256); timeit("qkv", g); g.kperm = 1; timeit("qkv, k-permuted LDS path", g); }
     { GemmArgs g = plain(x, 256, w, 256, bias, qkv, 512, M, 512, 256); timeit("cross qkv", g); }
     { GemmArgs g = plain(x, 256, w, 256, bias, ctx, 256, M, 256, 256); timeit("proj 256x256", g); }
+    // RFE_OPT_LG_FP16X2 (gemm_h2.hip): the same shapes with the weights' fp16 (hi, lo) planes attached, beside the fp32 k-permuted kernel
+    uint16_t* wh; hipMalloc(&wh, (size_t)768 * 512 * 2 * 2);
+    uint16_t* wl = wh + (size_t)768 * 512;
+    launch_split_f16(0, w, wh, wl, (size_t)768 * 512);
+    float* stat; hipMalloc(&stat, (size_t)M * 8 * 2 * 4);
+    printf("fp32 k-permuted kernel / fp16x2 split kernel (gemm_h2.hip):\n");
+    for (int h2 = 0; h2 < 2; ++h2) {
+        auto with = [&](GemmArgs g) { g.kperm = 1; if (h2) { g.Bh = wh; g.Bl = wl; } return g; };
+        const char* tag = h2 ? "h2 " : "f32";
+        char nm[64];
+        { GemmArgs g = with(plain(x, 256, w, 512, bias, h, 512, M, 512, 512)); g.A2 = ctx; g.lda2 = 256; g.K1 = 256;
+          snprintf(nm, 64, "%s ffn1", tag); timeit(nm, g);
+          g.stats_out = stat; snprintf(nm, 64, "%s ffn1 + LN partials", tag); timeit(nm, g); }
+        { GemmArgs g = with(plain(h, 512, w, 512, bias, x, 256, M, 256, 512)); g.R = x; g.ldr = 256;
+          snprintf(nm, 64, "%s ffn2 + residual", tag); timeit(nm, g);
+          g.stats_in = stat; g.stats_p = 4; g.ln_g = bias; g.ln_b = bias;
+          snprintf(nm, 64, "%s ffn2 + res + LN/GELU on A", tag); timeit(nm, g); }
+        { GemmArgs g = with(plain(x, 256, w, 256, bias, qkv, 768, M, 768, 256)); snprintf(nm, 64, "%s qkv", tag); timeit(nm, g); }
+        { GemmArgs g = with(plain(x, 256, w, 256, bias, qkv, 512, M, 512, 256)); snprintf(nm, 64, "%s cross qkv", tag); timeit(nm, g); }
+    }
     return 0;
 }

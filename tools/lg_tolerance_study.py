@@ -175,6 +175,14 @@ def main():
                         ref, p64, m64 = r["_in"][4:]
                         r[f"bsame{fold}"], r[f"bdev{fold}"] = score_dev(pairs[i, :S[i]], ms[i, :S[i]], ref["pairs"], ref["ms"])
                         r[f"bsame{fold}_64"], r[f"bdev{fold}_64"] = score_dev(pairs[i, :S[i]], ms[i, :S[i]], p64, m64)
+                    # RFE_OPT_LG_FP16X2: the Linears of the same call as a split GEMM on the f16 matrix pipe (gemm_h2.hip)
+                    ctx.set_option(capi.OPT_LG_FP16X2, 1)
+                    S, pairs, ms = ctx.match(kb0, kb1, db0, db1, [r["n0"] for r in cyc], [r["n1"] for r in cyc])
+                    ctx.set_option(capi.OPT_LG_FP16X2, 0)
+                    for i, r in enumerate(part):
+                        ref, p64, m64 = r["_in"][4:]
+                        r[f"hsame{fold}"], r[f"hdev{fold}"] = score_dev(pairs[i, :S[i]], ms[i, :S[i]], ref["pairs"], ref["ms"])
+                        r[f"hsame{fold}_64"], r[f"hdev{fold}_64"] = score_dev(pairs[i, :S[i]], ms[i, :S[i]], p64, m64)
             print(f"# batched seed {seed} done", file=sys.stderr, flush=True)
     ctx.close()
     mx = lambda k: max(r[k] for r in rows)
@@ -202,6 +210,14 @@ def main():
                   f"| {r['bdev1_64']:.2e} | {yn(r['bsame1_64'])} |")
         print(f"| **max** | | **{mx('bdev0'):.2e}** | {yn(al('bsame0'))} | **{mx('bdev1'):.2e}** | {yn(al('bsame1'))} | **{mx('bdev0_64'):.2e}** | {yn(al('bsame0_64'))} "
               f"| **{mx('bdev1_64'):.2e}** | {yn(al('bsame1_64'))} |")
+        print("\n## ... with RFE_OPT_LG_FP16X2 = 1 (Linears as fp16 hi + lo split GEMMs on the f16 matrix pipe, rover-slam_amd/csrc/gemm_h2.hip; default off)\n")
+        print("| case | S | gpu0 fp16x2 vs oracle | lists | gpu1 fp16x2 vs oracle | lists | gpu0 fp16x2 vs f64 | lists | gpu1 fp16x2 vs f64 | lists |")
+        print("|---:|---:|---:|:-:|---:|:-:|---:|:-:|---:|:-:|")
+        for r in rows:
+            print(f"| {r['case']} | {r['S']} | {r['hdev0']:.2e} | {yn(r['hsame0'])} | {r['hdev1']:.2e} | {yn(r['hsame1'])} | {r['hdev0_64']:.2e} | {yn(r['hsame0_64'])} "
+                  f"| {r['hdev1_64']:.2e} | {yn(r['hsame1_64'])} |")
+        print(f"| **max** | | **{mx('hdev0'):.2e}** | {yn(al('hsame0'))} | **{mx('hdev1'):.2e}** | {yn(al('hsame1'))} | **{mx('hdev0_64'):.2e}** | {yn(al('hsame0_64'))} "
+              f"| **{mx('hdev1_64'):.2e}** | {yn(al('hsame1_64'))} |")
 
 
 if __name__ == "__main__":
