@@ -10,11 +10,12 @@
 // equivalence).  The reference runs these Linears inside Session::Run(lightglue_sim.onnx), src/Matchers/lightglue_onnx.cpp:210-214.
 //
 // Weights (B) are split ONCE at load time into two fp16 planes (rfe_api.hip: set_lg_upload); activations (A) are split while they
-// are staged into LDS (11 VALU per element pair; LNA: LayerNorm + GELU of ffn.3's operand is applied in the same pass, before the
+// are staged into LDS (3 VALU per element pair, h2_split.h; LNA: LayerNorm + GELU of ffn.3's operand is applied in the same pass, before the
 // split).  Tile 128 x 256 x 32, 256 threads = 2x2 waves of 64 x 128, two workgroups per CU (as gemm.hip); LDS: per plane [rows][32
 // fp16] = 64-byte rows of four 16-byte slots, slot s = 2 c + h stored at s ^ ((row >> 2) & 3) -- ds_read_b128 fragment reads and the
 // staging writes are bank-conflict free.  Epilogue (bias in the accumulator, alpha, residual, LayerNorm partials) as gemm.hip.
 #include "rfe_internal.h"
+#include "h2_split.h"
 
 namespace rfe {
 
@@ -22,12 +23,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ void split2_f16(float x, float y, uint32_t& hi, uint32_t& lo) {
-    const _Float16 hx = (_Float16)x, hy = (_Float16)y;
-    const _Float16 lx = (_Float16)(x - (float)hx), ly = (_Float16)(y - (float)hy);
-    hi = (uint32_t)__builtin_bit_cast(uint16_t, hx) | ((uint32_t)__builtin_bit_cast(uint16_t, hy) << 16);
-    lo = (uint32_t)__builtin_bit_cast(uint16_t, lx) | ((uint32_t)__builtin_bit_cast(uint16_t, ly) << 16);
-}
+__device__ __forceinline__ void split2_f16(float x, float y, uint32_t& hi, uint32_t& lo) { h2_split2(x, y, hi, lo); }   // h2_split.h
 
 // fp32 [n] -> fp16 planes hi [n], lo [n] (n even)
 __global__ void split_f16_kernel(const float* __restrict__ x, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, size_t n) {
@@ -60,7 +56,14 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GemmArgs g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int i = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware block order (blocks are dealt round-robin to the 8 XCDs): the N / 256 column tiles of one 128-row panel are consecutive
+    // workgroups of ONE XCD, so the panel's second (third) read of A hits that XCD's L2 instead of HBM -- at the f16 rate these
+    // kernels run within 1.5x of their HBM time, and A read once instead of N / 256 times is a third of the traffic
+    const int ncol = g.N / BN;
+    const int xb = blockIdx.x & 7, tb = blockIdx.x >> 3;
+    const int bx = tb % ncol, by = (tb / ncol) * 8 + xb;
+    if (by * BM >= g.M) return;
+    const int m0 = by * BM, n0 = bx * BN;
     const int M = g.M;
 
     f32x16 acc[MB][NB];
@@ -236,8 +239,8 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GemmArgs g) {
             const int r = i & 15;
             const int m = m0 + (wm * MB + (i >> 4)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (m < M) {
-                const int P = (int)gridDim.x * 2;
-                float* sp = g.stats_out + ((size_t)m * P + blockIdx.x * 2 + wn) * 2;
+                const int P = ncol * 2;
+                float* sp = g.stats_out + ((size_t)m * P + bx * 2 + wn) * 2;
                 sp[0] = sm[0]; sp[1] = s2[0];
             }
         }
@@ -247,7 +250,8 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GemmArgs g) {
 // Called by launch_gemm_nt for the shapes it would give the 128 x 256 throughput tile (N % 256 == 0, K % 32 == 0, no batch / m_valid /
 // relu): returns the number of partial-statistics pairs per row it wrote (0 without stats_out), like launch_gemm_nt.
 int launch_gemm_h2(hipStream_t s, const GemmArgs& g) {
-    const dim3 grid(g.N / 256, (g.M + 127) / 128);
+    const int panels8 = (((g.M + 127) / 128) + 7) / 8 * 8;   // row panels padded to a multiple of 8: the block -> (panel, column tile) decode stays bijective
+    const dim3 grid((unsigned)(panels8 * (g.N / 256)));
     const bool res = g.R != nullptr, lna = g.stats_in != nullptr;
     if (lna && res) hipLaunchKernelGGL((gemm_h2_kernel<true, true>), grid, dim3(256), 0, s, g);
     else if (lna) hipLaunchKernelGGL((gemm_h2_kernel<false, true>), grid, dim3(256), 0, s, g);

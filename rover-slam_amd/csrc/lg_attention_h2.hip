@@ -25,6 +25,7 @@
 // (|x| < 6.1e-5: small P, low planes) are carried as fp16 subnormals -- absolute error <= 2^-25 per element, against a row sum >= 1.
 // Rotary (self blocks): applied to q and k with the same three fp32 operations as lg_attention_kernel, before the split.
 #include "rfe_internal.h"
+#include "h2_split.h"
 
 namespace rfe {
 
@@ -37,13 +38,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 constexpr int AH_Q = 256, AH_K = 64;
 constexpr float AH_DEFER = 11.0f;   // log2 units: P <= 2^11 between two moves of the reference
 
-// (x, y) -> packed fp16 (hi, hi), (lo, lo): v_cvt_pk_f16_f32, two v_cvt_f32_f16, two v_sub, v_cvt_pk_f16_f32
-__device__ __forceinline__ void ah_split2(float x, float y, uint32_t& hi, uint32_t& lo) {
-    const f16x2 hv = {(_Float16)x, (_Float16)y};
-    const f16x2 lv = {(_Float16)(x - (float)hv[0]), (_Float16)(y - (float)hv[1])};
-    hi = __builtin_bit_cast(uint32_t, hv);
-    lo = __builtin_bit_cast(uint32_t, lv);
-}
+__device__ __forceinline__ void ah_split2(float x, float y, uint32_t& hi, uint32_t& lo) { h2_split2(x, y, hi, lo); }   // h2_split.h: 3 VALU per pair
 __device__ __forceinline__ void ah_split8(const float* x, f16x8& hi, f16x8& lo) {
     u32x4 h, l;
 #pragma unroll
@@ -75,7 +70,7 @@ __device__ __forceinline__ void ah_softmax_step(f32x16& st, bool first, float& m
     l_run += ps;
 }
 
-template <bool ROPE>
+template <bool ROPE, int ABL = 0>   // ABL: timing ablations (tuning build only, wrong results): 1 no softmax VALU, 2 stage only tile 0, 4 no MFMA
 __global__ __launch_bounds__(256, 2) void lg_attention_h2_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld, float* __restrict__ out,
     int Lq, int Lk, int nqb, const int* __restrict__ qlen, const int* __restrict__ klen, const int* __restrict__ kv_map,
@@ -148,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void lg_attention_h2_kernel(
     const int skey = tid >> 3, soct = tid & 7;
     const int vdq = lane & 15, vp = lane >> 4, vkk = ((vp & 1) << 1) | (vp >> 1);
     float4 rk[2][2], rv[4];
-    auto fetch = [&](int k0) {
+    auto fetchK = [&](int k0) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             int key = k0 + skey + 32 * it; key = key < nk ? key : nk - 1;   // rows past the end: the last valid row (finite), masked in S
@@ -162,12 +157,15 @@ __global__ __launch_bounds__(256, 2) void lg_attention_h2_kernel(
             }
             rk[it][0] = a; rk[it][1] = bq;
         }
+    };
+    auto fetchV = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int key = k0 + 16 * wave + 4 * vkk + i; key = key < nk ? key : nk - 1;
             rv[i] = *reinterpret_cast<const float4*>(vbase + (size_t)key * ld + vdq * 4);
         }
     };
+    auto fetch = [&](int k0) { fetchK(k0); fetchV(k0); };
     auto stash = [&](int buf) {
         unsigned char* const Kh = lds + buf * (4 * AH_K * 128);
         unsigned char* const Kl = Kh + AH_K * 128;
@@ -214,8 +212,10 @@ __global__ __launch_bounds__(256, 2) void lg_attention_h2_kernel(
     fetch(0);
     int buf = 0;
     for (int k0 = 0; k0 < nk; k0 += AH_K) {
+        if (!(ABL & 2) || k0 == 0) {
         stash(buf);                             // buffer `buf` was last read for tile k0 - 128: every wave has passed the barrier of tile k0 - 64 since
         if (k0 + AH_K < nk) fetch(k0 + AH_K);   // in flight under this tile's products
+        }
         __syncthreads();
         if (wactive) {
             const unsigned char* const Kh = lds + buf * (4 * AH_K * 128);
@@ -241,12 +241,14 @@ __global__ __launch_bounds__(256, 2) void lg_attention_h2_kernel(
                     const int off = krow + (((2 * s + h) ^ kfrag_sw) << 4);
                     const f16x8 kh = *reinterpret_cast<const f16x8*>(Kh + off);
                     const f16x8 kl = *reinterpret_cast<const f16x8*>(Kl + off);
+                    // small terms first; the two query blocks alternate so that no instruction waits for its predecessor's accumulator
+                    if (ABL & 4) { st[0][s] += (float)kh[0] + (float)kl[1]; continue; }
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) {   // small terms first
-                        st[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[b][s], st[b], 0, 0, 0);
-                        st[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[b][s], st[b], 0, 0, 0);
-                        st[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[b][s], st[b], 0, 0, 0);
-                    }
+                    for (int b = 0; b < 2; ++b) st[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[b][s], st[b], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) st[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[b][s], st[b], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) st[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[b][s], st[b], 0, 0, 0);
                 }
                 __builtin_amdgcn_s_setprio(0);
                 // ---- online softmax, then P as (hi, lo) planes: registers 8 s .. 8 s + 7 are the B operand of PV's k-step s
@@ -259,6 +261,15 @@ __global__ __launch_bounds__(256, 2) void lg_attention_h2_kernel(
                             const int key = k0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                             if (key >= nk) st[b][r] = -INFINITY;
                         }
+                    }
+                    if (ABL & 1) {
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) {
+                            ph[b][s] = __builtin_bit_cast(f16x8, f32x4{st[b][8 * s], st[b][8 * s + 1], st[b][8 * s + 2], st[b][8 * s + 3]});
+                            pl[b][s] = __builtin_bit_cast(f16x8, f32x4{st[b][8 * s + 4], st[b][8 * s + 5], st[b][8 * s + 6], st[b][8 * s + 7]});
+                        }
+                        l_run[b] = 1.f; m_run[b] = 0.f;
+                        continue;
                     }
                     ah_softmax_step(st[b], first, m_run[b], l_run[b], o[b][0], o[b][1]);
 #pragma unroll
@@ -278,12 +289,13 @@ __global__ __launch_bounds__(256, 2) void lg_attention_h2_kernel(
                         const int off = vrow_off[db] + (((2 * (2 * sub + s) + h) ^ vfrag_sw[db]) << 4);
                         const f16x8 vh = *reinterpret_cast<const f16x8*>(Vh + off);
                         const f16x8 vl = *reinterpret_cast<const f16x8*>(Vl + off);
+                        if (ABL & 4) { o[0][db][s] += (float)vh[0] + (float)vl[1] + (float)ph[0][s][1] + (float)pl[1][s][2] + (float)ph[1][s][3] + (float)pl[0][s][0]; continue; }
 #pragma unroll
-                        for (int b = 0; b < 2; ++b) {
-                            o[b][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[b][s], o[b][db], 0, 0, 0);
-                            o[b][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[b][s], o[b][db], 0, 0, 0);
-                            o[b][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[b][s], o[b][db], 0, 0, 0);
-                        }
+                        for (int b = 0; b < 2; ++b) o[b][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[b][s], o[b][db], 0, 0, 0);
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) o[b][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[b][s], o[b][db], 0, 0, 0);
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) o[b][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[b][s], o[b][db], 0, 0, 0);
                     }
                 __builtin_amdgcn_s_setprio(0);
             }
@@ -319,6 +331,14 @@ void launch_lg_attention_h2(hipStream_t s, const float* q, const float* k, const
                             const int* qlen, const int* klen, const int* kv_map, const float* rope_csn) {
     const int nqb = (Lq + AH_Q - 1) / AH_Q;
     const int units8 = (4 * nseq + 7) / 8 * 8;
+#ifdef RFE_TUNING
+    switch (tune_int("RFE_DBG_AH_ABL", 0)) {   // timing ablations (cross variant), tuning build only: profiles/r03_ab_notes.md
+#define RFE_AH_ABL(n) case n: hipLaunchKernelGGL((lg_attention_h2_kernel<false, n>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, nseq, rope_csn); return;
+        RFE_AH_ABL(1) RFE_AH_ABL(2) RFE_AH_ABL(3) RFE_AH_ABL(4) RFE_AH_ABL(6)
+#undef RFE_AH_ABL
+        default: break;
+    }
+#endif
     if (rope_csn)
         hipLaunchKernelGGL((lg_attention_h2_kernel<true>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, nseq, rope_csn);
     else

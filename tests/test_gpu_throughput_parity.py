@@ -100,8 +100,10 @@ def test_lightglue_batch16_tap_equals_single_pair_tap(ctx):
         b.free()
 
 
-def test_stream_b33_filter0_vs_oracle(ctx, oracle):
-    """configs[3]'s per-GPU shard through rfe_extract_match_stream_dev (B = 33 frames 640x480, Kmax = 1024: per-frame layer-0 self
+@pytest.mark.parametrize("fp16x2", [0, 1])
+def test_stream_b33_filter0_vs_oracle(ctx, oracle, fp16x2):
+    """(fp16x2 = 1: the same stream with RFE_OPT_LG_FP16X2 on -- split Linears and attention, same bars.)
+    configs[3]'s per-GPU shard through rfe_extract_match_stream_dev (B = 33 frames 640x480, Kmax = 1024: per-frame layer-0 self
     block, throughput tiles) with filter_thr = 0.0, so EVERY mutual pair is emitted (with random weights only a handful pass 0.1).
     Frames 9, 17 and 25 repeat their predecessor: those pairs give 200+ mutual matches, the others of the bench stream the 50-100
     mutual nearest neighbours random weights leave.  Six pairs against the oracle (borderline rule, scores); pair 16
@@ -116,10 +118,14 @@ def test_stream_b33_filter0_vs_oracle(ctx, oracle):
     dn, dk, ds, dd = ctx.alloc(B * 4), ctx.alloc(B * K * 8), ctx.alloc(B * K * 4), ctx.alloc(B * K * 1024)
     dS, dp, dm = ctx.alloc((B - 1) * 4), ctx.alloc((B - 1) * K * 8), ctx.alloc((B - 1) * K * 4)
     dx0, dx1, dsc = ctx.alloc(K * 1024), ctx.alloc(K * 1024), ctx.alloc(K * K * 4)
-    ctx._chk(capi.lib.rfe_k_set_lightglue_tap(ctx.h, tap_pair, dx0.ptr, dx1.ptr, dsc.ptr))
-    ctx._chk(capi.lib.rfe_extract_match_stream_dev(ctx.h, dimg.ptr, H, W, W, B, K, 0.0005, 0.0, dn.ptr, dk.ptr, ds.ptr, dd.ptr,
-                                                   dS.ptr, dp.ptr, dm.ptr))
-    ctx.synchronize()
+    ctx.set_option(capi.OPT_LG_FP16X2, fp16x2)
+    try:
+        ctx._chk(capi.lib.rfe_k_set_lightglue_tap(ctx.h, tap_pair, dx0.ptr, dx1.ptr, dsc.ptr))
+        ctx._chk(capi.lib.rfe_extract_match_stream_dev(ctx.h, dimg.ptr, H, W, W, B, K, 0.0005, 0.0, dn.ptr, dk.ptr, ds.ptr, dd.ptr,
+                                                       dS.ptr, dp.ptr, dm.ptr))
+        ctx.synchronize()
+    finally:
+        ctx.set_option(capi.OPT_LG_FP16X2, 0)
     n, kxy, desc = dn.download((B,), np.int32), dk.download((B, K, 2), np.int32), dd.download((B, K, 256), np.float32)
     S, pairs, ms = dS.download((B - 1,), np.int32), dp.download((B - 1, K, 2), np.int32), dm.download((B - 1, K), np.float32)
     x0, x1, sc = dx0.download((K, 256), np.float32), dx1.download((K, 256), np.float32), dsc.download((K, K), np.float32)
@@ -138,7 +144,7 @@ def test_stream_b33_filter0_vs_oracle(ctx, oracle):
             dprob = np.abs(np.exp(sc[:n[i], :n[i + 1]]) - np.exp(r["scores"])).max()
             print(f"tap pair {i}: max |log-score dev| {dlog:.2e} (max |log-score| {np.abs(r['scores']).max():.1f}), max |probability dev| {dprob:.2e}")
             assert dprob < LG_SCORE_TOL and dlog < LG_LOGSCORE_ATOL, (dlog, dprob)
-    print(f"stream B=33 filter 0: {total} matches over 6 pairs, max |score dev| {worst:.2e}, S = {S.tolist()}")
+    print(f"stream B=33 filter 0 (fp16x2 = {fp16x2}): {total} matches over 6 pairs, max |score dev| {worst:.2e}, S = {S.tolist()}")
     for d in (dimg, dn, dk, ds, dd, dS, dp, dm, dx0, dx1, dsc):
         d.free()
 

@@ -2,6 +2,7 @@
 // the real epilogue options, to separate kernel efficiency from pipeline effects (tuning harness, not product code).
 // hipcc --offload-arch=gfx950 -O3 -I../../rover-slam_amd/csrc gemm_product.hip -L../../rover-slam_amd -lrover_fe -o gemm_product
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "rfe_internal.h"
