@@ -142,7 +142,7 @@ def test_pool_of_one_through_rccl_equals_single_ctx(wsets):
 @pytest.mark.gpu
 def test_pool_three_members_on_one_device_copy_transport(wsets, oracle):
     from rover_slam_amd import capi
-    from tolerances import LG_SCORE_TOL_SMALL, lists_agree
+    from tolerances import LG_SCORE_TOL, lists_agree
     F, kmax = 11, 256                                      # 10 pairs over 3 members: 4 + 3 + 3
     frames, _ = synth.make_frames(F, 240, 320, seed=9)
     pool = capi.Pool([0, 0, 0])
@@ -179,10 +179,12 @@ def test_pool_three_members_on_one_device_copy_transport(wsets, oracle):
     assert whole["S"].sum() > 0
     for p in range(F - 1):
         a, b = int(got["S"][p]), int(whole["S"][p])
-        # two fp32 evaluations (4- / 3-pair shards against the 10-pair batch: other GEMM / attention tilings), each within
-        # LG_SCORE_TOL_SMALL of the oracle at <= 256 keypoints, may sit twice that apart
-        ok, dev = lists_agree(got["pairs"][p, :a], got["ms"][p, :a], whole["pairs"][p, :b], whole["ms"][p, :b], slack=2 * LG_SCORE_TOL_SMALL)
-        assert ok and dev < 2 * LG_SCORE_TOL_SMALL, (p, a, b, dev)
+        # two fp32 evaluations (4- / 3-pair shards against the 10-pair batch: other GEMM / attention tilings).  Measured on this very stream
+        # (tools/diag_pool_pair.py -> profiles/r03_pool_pair_diag.md): nine pairs agree to <= 8.5e-5, pair 5 to 2.0e-4 -- there the fp32 CPU
+        # oracle itself sits 2.65e-4 from a float64 evaluation, the whole-stream call 9e-5 from the oracle and the shard call 1.4e-4 from
+        # float64: the fp32 noise floor of a match score is not smaller at 256 keypoints than at 1024, so the stated LG_SCORE_TOL applies
+        ok, dev = lists_agree(got["pairs"][p, :a], got["ms"][p, :a], whole["pairs"][p, :b], whole["ms"][p, :b], slack=LG_SCORE_TOL)
+        assert ok and dev < LG_SCORE_TOL, (p, a, b, dev)
 
 
 @pytest.mark.gpu
