@@ -419,6 +419,9 @@ def main():
     ap.add_argument("--no-pool", action="store_true", help="skip the short run through the C-ABI pool (rfe_pool_*, N=1)")
     ap.add_argument("--gather-desc", action="store_true", help="also gather scores and the 256-d descriptors to rank 0")
     ap.add_argument("--lg-fold", type=int, default=None, choices=[0, 1], help="override RFE_OPT_LG_FOLD_WO (default: the library's)")
+    ap.add_argument("--lg-fp16x2", type=int, default=0, choices=[0, 1],
+                    help="DIAGNOSTIC runs only (profiling the option): 1 = the whole run with RFE_OPT_LG_FP16X2 on; the line is then labelled as such and is "
+                         "not the headline configuration (the default run reports the option as variants.fp16x2)")
     ap.add_argument("--check-launch", action="store_true", help="N-rank flow only (gloo, CPU tensors, no GPU): launcher / collective self-test")
     ap.add_argument("--workload", default="c4", choices=["c2", "c3", "c4", "c5"],
                     help="BASELINE.json configs: c4 (default, the metric's workload) = 33 frames + 32 pairs per GPU; "
@@ -495,6 +498,8 @@ def main():
     ctx.set_weights(capi.KIND_LIGHTGLUE, wlg)
     if args.lg_fold is not None:
         ctx.set_option(capi.OPT_LG_FOLD_WO, args.lg_fold)
+    if args.lg_fp16x2:
+        ctx.set_option(capi.OPT_LG_FP16X2, 1)
     stream = torch.cuda.Stream(dev)          # library kernels and the RCCL gather share this stream
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
@@ -635,7 +640,7 @@ def main():
     # ---- variants ("also report K in {256, 512}" and "a second weight set with dustbin bias to exercise K < Kmax and
     # variable-K batching"): the same 33-frame / 32-pair step at other keypoint budgets, short runs, never the headline
     variants = None
-    if world == 1 and not args.no_variants and args.workload == "c4":
+    if world == 1 and not args.no_variants and args.workload == "c4" and not args.lg_fp16x2:
         variants = {}
 
         def run_variant(kmax, tag, note):
@@ -818,6 +823,12 @@ def main():
             "stages_note": f"separate untimed pass of {full_steps} steps with events around every stage (costs ~2 %); the timed "
                            "region instruments the dominant kernel only",
         }
+        if args.lg_fp16x2:
+            out["dtype"] = "f32; LightGlue Linears + attention as fp16 hi + lo split products on the f16 matrix pipe, fp32 accumulation (RFE_OPT_LG_FP16X2)"
+            out["diagnostic"] = "--lg-fp16x2 1: a profiling run of the OPTION, not the headline configuration (default runs keep the option off and report it as variants.fp16x2)"
+            if dom_name.startswith("lg_") and achieved:
+                pk = 2500.0 / 3.0   # f16 dense peak / three products per fp32 product
+                out["roofline"].update({"peak": round(pk, 1), "frac": round(achieved / pk, 4), "unit": "TFLOP/s fp32-equivalent"})
         if rccl is not None:
             out["rccl"] = rccl
             out["gather"] = {"collectives_per_step": 1, "payload_bytes_per_rank": gather.nbytes, "with_descriptors": bool(args.gather_desc),
