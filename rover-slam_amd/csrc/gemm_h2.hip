@@ -112,10 +112,12 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GemmArgs g) {
         }
     }
 
-    for (int k0 = 0; k0 < g.K; k0 += BK) {
-        float4 fa[4], rg, rbeta;
-        u32x4 rh[4], rl[4];
-        if (LNA) { rg = *reinterpret_cast<const float4*>(g.ln_g + k0 + lkq * 4); rbeta = *reinterpret_cast<const float4*>(g.ln_b + k0 + lkq * 4); }
+    // LNA (ffn.3): the A rows of K tile t + 1 are requested right after tile t is published and land under its MFMAs -- the LayerNorm /
+    // GELU / split pass then starts on data that is already there (89.5 -> 74.5 us).  The plain variants keep all twelve loads at the top
+    // of the tile they belong to: with the prefetch they measured 3 % slower (ffn.0, cross-qkv), and with the weight planes prefetched as
+    // well (48 more live registers) everything spills -- profiles/r03_ab_notes.md.
+    float4 fa[4];
+    auto fetchA = [&](int k0) {
         if (A2t && k0 >= g.K1) {
             const float* base = A2t + (k0 - g.K1);
 #pragma unroll
@@ -125,6 +127,13 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GemmArgs g) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) fa[it] = *reinterpret_cast<const float4*>(base + aoff[it]);
         }
+    };
+    if (LNA) fetchA(0);
+    for (int k0 = 0; k0 < g.K; k0 += BK) {
+        if (!LNA) fetchA(k0);
+        float4 rg, rbeta;
+        u32x4 rh[4], rl[4];
+        if (LNA) { rg = *reinterpret_cast<const float4*>(g.ln_g + k0 + lkq * 4); rbeta = *reinterpret_cast<const float4*>(g.ln_b + k0 + lkq * 4); }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             rh[p] = *reinterpret_cast<const u32x4*>(Bh + (size_t)64 * p * g.ldb + k0);
@@ -152,6 +161,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GemmArgs g) {
             *reinterpret_cast<u32x4*>(Bs + BN * 64 + p * 64 * 64 + sw_off) = rl[p];
         }
         __syncthreads();
+        if (LNA && k0 + BK < g.K) fetchA(k0 + BK);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int slot = ((2 * c + h) ^ frag_sw) << 4;
