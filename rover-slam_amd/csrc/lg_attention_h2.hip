@@ -35,7 +35,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int AH_Q = 256, AH_K = 64;
+constexpr int AH_K = 64;
 constexpr float AH_DEFER = 11.0f;   // log2 units: P <= 2^11 between two moves of the reference
 
 __device__ __forceinline__ void ah_split2(float x, float y, uint32_t& hi, uint32_t& lo) { h2_split2(x, y, hi, lo); }   // h2_split.h: 3 VALU per pair
@@ -70,13 +70,15 @@ __device__ __forceinline__ void ah_softmax_step(f32x16& st, bool first, float& m
     l_run += ps;
 }
 
-template <bool ROPE, int ABL = 0>   // ABL: timing ablations (tuning build only, wrong results): 1 no softmax VALU, 2 stage only tile 0, 4 no MFMA
-__global__ __launch_bounds__(256, 2) void lg_attention_h2_kernel(
+// NQB: 32-query blocks per wave (workgroup = 128 NQB queries); DBUF: double-buffered tiles (one barrier per tile) or one buffer (two)
+template <bool ROPE, int ABL = 0, int NQB = 2, bool DBUF = true>   // ABL: timing ablations (tuning build only, wrong results): 1 no softmax VALU, 2 stage only tile 0, 4 no MFMA
+__global__ __launch_bounds__(256, NQB == 2 ? 2 : 3) void lg_attention_h2_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld, float* __restrict__ out,
     int Lq, int Lk, int nqb, const int* __restrict__ qlen, const int* __restrict__ klen, const int* __restrict__ kv_map,
     int nseq_total, const float* __restrict__ rope_csn) {
     // [buffer][K hi, K lo, V^T hi, V^T lo][64 rows x 128 B]
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 4 * AH_K * 128];
+    constexpr int AH_Q = 128 * NQB;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[(DBUF ? 2 : 1) * 4 * AH_K * 128];
     // XCD-aware decode as lg_attention_kernel: the query blocks of one (sequence, head) run on one XCD
     const int Lb = blockIdx.x, xcd = Lb & 7, t_ = Lb >> 3;
     const int qb = t_ % nqb, unit = (t_ / nqb) * 8 + xcd;
@@ -95,14 +97,14 @@ __global__ __launch_bounds__(256, 2) void lg_attention_h2_kernel(
     }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
-    const bool wactive = qb * AH_Q + wave * 64 < nq;   // wave-uniform: a wave whose 64 queries are all padding only stages tiles
+    const bool wactive = qb * AH_Q + wave * (32 * NQB) < nq;   // wave-uniform: a wave whose 64 queries are all padding only stages tiles
     constexpr float kScale = 0.125f * 1.44269504088896341f;  // 1/sqrt(64) * log2(e): softmax in base 2, folded into Q
 
     // ---- Q fragments: lane (j, h) of block b holds Q[query][16 s + 8 h .. + 7], s = 0..3, as (hi, lo) planes
-    f16x8 qh[2][4], ql[2][4];
+    f16x8 qh[NQB][4], ql[NQB][4];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int qrow = qb * AH_Q + wave * 64 + b * 32 + j;
+    for (int b = 0; b < NQB; ++b) {
+        const int qrow = qb * AH_Q + wave * (32 * NQB) + b * 32 + j;
         const size_t qrow_c = (size_t)seq * Lq + (qrow < Lq ? qrow : Lq - 1);
         const float* qp = q + qrow_c * ld + head * 64 + 8 * h;
 #pragma unroll
@@ -127,14 +129,16 @@ __global__ __launch_bounds__(256, 2) void lg_attention_h2_kernel(
         }
     }
 
-    f32x16 o[2][2];
+    f32x16 o[NQB][2];
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NQB; ++b)
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[b][db][r] = 0.f;
-    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    float m_run[NQB], l_run[NQB];
+#pragma unroll
+    for (int b = 0; b < NQB; ++b) { m_run[b] = -INFINITY; l_run[b] = 0.f; }
 
     const float* kbase = k + (size_t)kvseq * Lk * ld + head * 64;
     const float* vbase = v + (size_t)kvseq * Lk * ld + head * 64;
@@ -212,8 +216,9 @@ __global__ __launch_bounds__(256, 2) void lg_attention_h2_kernel(
     fetch(0);
     int buf = 0;
     for (int k0 = 0; k0 < nk; k0 += AH_K) {
+        if (!DBUF) __syncthreads();             // one buffer: the previous tile has been consumed by every wave
         if (!(ABL & 2) || k0 == 0) {
-        stash(buf);                             // buffer `buf` was last read for tile k0 - 128: every wave has passed the barrier of tile k0 - 64 since
+        stash(buf);                             // DBUF: buffer `buf` was last read for tile k0 - 128: every wave has passed the barrier of tile k0 - 64 since
         if (k0 + AH_K < nk) fetch(k0 + AH_K);   // in flight under this tile's products
         }
         __syncthreads();
@@ -227,9 +232,9 @@ __global__ __launch_bounds__(256, 2) void lg_attention_h2_kernel(
                 if (k0 + sub * 32 >= nk) break;
                 const bool first = k0 == 0 && sub == 0;
                 // ---- S^T[key][query] relative to the running reference maximum, both query blocks
-                f32x16 st[2];
+                f32x16 st[NQB];
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
+                for (int b = 0; b < NQB; ++b) {
                     const float init = first ? 0.f : -m_run[b];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) st[b][r] = init;
@@ -244,17 +249,17 @@ __global__ __launch_bounds__(256, 2) void lg_attention_h2_kernel(
                     // small terms first; the two query blocks alternate so that no instruction waits for its predecessor's accumulator
                     if (ABL & 4) { st[0][s] += (float)kh[0] + (float)kl[1]; continue; }
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) st[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[b][s], st[b], 0, 0, 0);
+                    for (int b = 0; b < NQB; ++b) st[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[b][s], st[b], 0, 0, 0);
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) st[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[b][s], st[b], 0, 0, 0);
+                    for (int b = 0; b < NQB; ++b) st[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[b][s], st[b], 0, 0, 0);
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) st[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[b][s], st[b], 0, 0, 0);
+                    for (int b = 0; b < NQB; ++b) st[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[b][s], st[b], 0, 0, 0);
                 }
                 __builtin_amdgcn_s_setprio(0);
                 // ---- online softmax, then P as (hi, lo) planes: registers 8 s .. 8 s + 7 are the B operand of PV's k-step s
-                f16x8 ph[2][2], pl[2][2];
+                f16x8 ph[NQB][2], pl[NQB][2];
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
+                for (int b = 0; b < NQB; ++b) {
                     if (k0 + sub * 32 + 32 > nk) {   // only the last key block can contain keys >= nk
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
@@ -289,29 +294,29 @@ __global__ __launch_bounds__(256, 2) void lg_attention_h2_kernel(
                         const int off = vrow_off[db] + (((2 * (2 * sub + s) + h) ^ vfrag_sw[db]) << 4);
                         const f16x8 vh = *reinterpret_cast<const f16x8*>(Vh + off);
                         const f16x8 vl = *reinterpret_cast<const f16x8*>(Vl + off);
-                        if (ABL & 4) { o[0][db][s] += (float)vh[0] + (float)vl[1] + (float)ph[0][s][1] + (float)pl[1][s][2] + (float)ph[1][s][3] + (float)pl[0][s][0]; continue; }
+                        if (ABL & 4) { o[0][db][s] += (float)vh[0] + (float)vl[1] + (float)ph[0][s][1] + (float)pl[NQB - 1][s][2] + (float)ph[NQB - 1][s][3] + (float)pl[0][s][0]; continue; }
 #pragma unroll
-                        for (int b = 0; b < 2; ++b) o[b][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[b][s], o[b][db], 0, 0, 0);
+                        for (int b = 0; b < NQB; ++b) o[b][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[b][s], o[b][db], 0, 0, 0);
 #pragma unroll
-                        for (int b = 0; b < 2; ++b) o[b][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[b][s], o[b][db], 0, 0, 0);
+                        for (int b = 0; b < NQB; ++b) o[b][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[b][s], o[b][db], 0, 0, 0);
 #pragma unroll
-                        for (int b = 0; b < 2; ++b) o[b][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[b][s], o[b][db], 0, 0, 0);
+                        for (int b = 0; b < NQB; ++b) o[b][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[b][s], o[b][db], 0, 0, 0);
                     }
                 __builtin_amdgcn_s_setprio(0);
             }
         }
-        buf ^= 1;
+        if (DBUF) buf ^= 1;
     }
     if (!wactive) {   // all 64 queries of this wave are padding: zero context rows
-        for (int e = lane; e < 64 * 64; e += 64) {
-            const int row = qb * AH_Q + wave * 64 + (e >> 6);
+        for (int e = lane; e < 32 * NQB * 64; e += 64) {
+            const int row = qb * AH_Q + wave * (32 * NQB) + (e >> 6);
             if (row < Lq) out[((size_t)seq * Lq + row) * 256 + head * 64 + (e & 63)] = 0.f;
         }
         return;
     }
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int qrow = qb * AH_Q + wave * 64 + b * 32 + j;
+    for (int b = 0; b < NQB; ++b) {
+        const int qrow = qb * AH_Q + wave * (32 * NQB) + b * 32 + j;
         const float l = l_run[b] + __shfl_xor(l_run[b], 32);
         if (qrow < Lq) {
             const float inv = (qrow < nq && l > 0.f) ? 1.0f / l : 0.f;  // padded rows -> 0
@@ -329,6 +334,8 @@ __global__ __launch_bounds__(256, 2) void lg_attention_h2_kernel(
 // Same contract as launch_lg_attention's throughput path (lg_kernels.hip); called by it when the option is on and the problem is large.
 void launch_lg_attention_h2(hipStream_t s, const float* q, const float* k, const float* v, int ld, float* out, int nseq, int Lq, int Lk,
                             const int* qlen, const int* klen, const int* kv_map, const float* rope_csn) {
+    static const int nqb_sel = tune_int("RFE_AH_NQB", 2);   // tuning switch: 1 = 128-query workgroups of 32-query waves, one tile buffer, three workgroups per CU
+    const int AH_Q = 128 * (nqb_sel == 1 ? 1 : 2);
     const int nqb = (Lq + AH_Q - 1) / AH_Q;
     const int units8 = (4 * nseq + 7) / 8 * 8;
 #ifdef RFE_TUNING
@@ -339,6 +346,11 @@ void launch_lg_attention_h2(hipStream_t s, const float* q, const float* k, const
         default: break;
     }
 #endif
+    if (nqb_sel == 1) {
+        if (rope_csn) hipLaunchKernelGGL((lg_attention_h2_kernel<true, 0, 1, false>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, nseq, rope_csn);
+        else hipLaunchKernelGGL((lg_attention_h2_kernel<false, 0, 1, false>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, nseq, rope_csn);
+        return;
+    }
     if (rope_csn)
         hipLaunchKernelGGL((lg_attention_h2_kernel<true>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, nseq, rope_csn);
     else
