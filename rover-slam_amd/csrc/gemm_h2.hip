@@ -46,12 +46,22 @@ __device__ __forceinline__ float gelu_short_h2(float t) {   // = gemm.hip:gelu_s
     return 0.5f * t * (1.0f + copysignf(er, x));
 }
 
-template <bool RES, bool LNA>
+// DMA: the weight planes never touch a register -- they are copied by global_load_lds_dwordx4 into a DOUBLE-buffered LDS tile (2 x 32 KB;
+// with the 16 KB A tile = 80 KB per workgroup: exactly two workgroups per CU, tools/kbench/lds_occupancy.hip), tile t + 1 requested
+// right after tile t is published, together with the A rows of tile t + 1 (16 registers); the 16-byte-slot swizzle is applied on the
+// SOURCE address (the LDS side of the copy is lane-linear: lane l of a wave instruction fills bytes 16 l .. of 1 KB = 16 rows).
+// Without it (register staging of all twelve loads of a tile at its top) both workgroups of a CU end up waiting for L2 / HBM together.
+typedef __attribute__((address_space(3))) void* h2_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* h2_gptr_t;
+template <bool RES, bool LNA, bool DMA>
 __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GemmArgs g) {
     constexpr int BM = 128, BN = 256, BK = 32, MB = 2, NB = 4;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (BM + BN) * 64];
+    constexpr int BPL = BN * 64;                      // bytes of one B plane of one K tile
+    __shared__ __attribute__((aligned(16))) unsigned char lds_static[DMA ? 16 : 2 * (BM + BN) * 64];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];   // DMA: 2 * BM * 64 + 2 * 2 * BPL = 80 KB
+    unsigned char* const lds = DMA ? lds_dyn : lds_static;
     unsigned char* const As = lds;                    // [2 planes][BM][64 B]
-    unsigned char* const Bs = lds + 2 * BM * 64;      // [2 planes][BN][64 B]
+    unsigned char* const Bs = lds + 2 * BM * 64;      // [2 planes][BN][64 B] (DMA: x 2 buffers)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -128,18 +138,21 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GemmArgs g) {
             for (int it = 0; it < 4; ++it) fa[it] = *reinterpret_cast<const float4*>(base + aoff[it]);
         }
     };
-    if (LNA) fetchA(0);
-    for (int k0 = 0; k0 < g.K; k0 += BK) {
-        if (!LNA) fetchA(k0);
-        float4 rg, rbeta;
-        u32x4 rh[4], rl[4];
-        if (LNA) { rg = *reinterpret_cast<const float4*>(g.ln_g + k0 + lkq * 4); rbeta = *reinterpret_cast<const float4*>(g.ln_b + k0 + lkq * 4); }
+    // DMA: one wave instruction copies 64 x 16 B = 1 KB = 16 rows of one plane; wave w issues the row groups 4 w .. 4 w + 3 of both planes.
+    // Lane l fills row 16 grp + l / 4, physical slot l & 3, which holds logical slot (l & 3) ^ ((row >> 2) & 3) = (l & 3) ^ (l >> 4).
+    auto dmaB = [&](int k0, int b) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            rh[p] = *reinterpret_cast<const u32x4*>(Bh + (size_t)64 * p * g.ldb + k0);
-            rl[p] = *reinterpret_cast<const u32x4*>(Bl + (size_t)64 * p * g.ldb + k0);
+        for (int u = 0; u < 4; ++u) {
+            const int grp = wave * 4 + u;
+            const size_t src = (size_t)(n0 + grp * 16 + (lane >> 2)) * g.ldb + k0 + 8 * ((lane & 3) ^ (lane >> 4));
+            unsigned char* const dst = Bs + b * (2 * BPL) + grp * 1024;
+            __builtin_amdgcn_global_load_lds((h2_gptr_t)(g.Bh + src), (h2_lds_ptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((h2_gptr_t)(g.Bl + src), (h2_lds_ptr_t)(dst + BPL), 16, 0, 0);
         }
-        __syncthreads();   // previous tile consumed
+    };
+    auto stageA = [&](int k0) {   // [LayerNorm + GELU,] split, write the A planes
+        float4 rg, rbeta;
+        if (LNA) { rg = *reinterpret_cast<const float4*>(g.ln_g + k0 + lkq * 4); rbeta = *reinterpret_cast<const float4*>(g.ln_b + k0 + lkq * 4); }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             float4 v = fa[it];
@@ -155,13 +168,38 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GemmArgs g) {
             *reinterpret_cast<u32x2*>(As + adst[it]) = u32x2{h0, h1};
             *reinterpret_cast<u32x2*>(As + BM * 64 + adst[it]) = u32x2{l0, l1};
         }
+    };
+    if (DMA) { dmaB(0, 0); fetchA(0); }
+    else if (LNA) fetchA(0);
+    int bbuf = 0;
+    for (int k0 = 0; k0 < g.K; k0 += BK) {
+        const unsigned char* Bt = Bs;                 // this tile's B planes
+        if (DMA) {
+            // #1: this tile's weight planes and A rows have landed (requested one tile ago); every wave has finished the previous tile
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            stageA(k0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // #2: the A planes are visible
+            if (k0 + BK < g.K) { dmaB(k0 + BK, bbuf ^ 1); fetchA(k0 + BK); }   // in flight under this tile's MFMAs
+            Bt = Bs + bbuf * (2 * BPL);
+            bbuf ^= 1;
+        } else {
+            if (!LNA) fetchA(k0);
+            u32x4 rh[4], rl[4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            *reinterpret_cast<u32x4*>(Bs + p * 64 * 64 + sw_off) = rh[p];
-            *reinterpret_cast<u32x4*>(Bs + BN * 64 + p * 64 * 64 + sw_off) = rl[p];
+            for (int p = 0; p < 4; ++p) {
+                rh[p] = *reinterpret_cast<const u32x4*>(Bh + (size_t)64 * p * g.ldb + k0);
+                rl[p] = *reinterpret_cast<const u32x4*>(Bl + (size_t)64 * p * g.ldb + k0);
+            }
+            __syncthreads();   // previous tile consumed
+            stageA(k0);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                *reinterpret_cast<u32x4*>(Bs + p * 64 * 64 + sw_off) = rh[p];
+                *reinterpret_cast<u32x4*>(Bs + BN * 64 + p * 64 * 64 + sw_off) = rl[p];
+            }
+            __syncthreads();
+            if (LNA && k0 + BK < g.K) fetchA(k0 + BK);
         }
-        __syncthreads();
-        if (LNA && k0 + BK < g.K) fetchA(k0 + BK);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int slot = ((2 * c + h) ^ frag_sw) << 4;
@@ -173,8 +211,8 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GemmArgs g) {
             }
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                const f16x8 bh = *reinterpret_cast<const f16x8*>(Bs + ((wn * NB + nb) * 32 + i) * 64 + slot);
-                const f16x8 bl = *reinterpret_cast<const f16x8*>(Bs + BN * 64 + ((wn * NB + nb) * 32 + i) * 64 + slot);
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(Bt + ((wn * NB + nb) * 32 + i) * 64 + slot);
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(Bt + BN * 64 + ((wn * NB + nb) * 32 + i) * 64 + slot);
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {   // small terms first
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mb], bh, acc[mb][nb], 0, 0, 0);
@@ -263,10 +301,24 @@ int launch_gemm_h2(hipStream_t s, const GemmArgs& g) {
     const int panels8 = (((g.M + 127) / 128) + 7) / 8 * 8;   // row panels padded to a multiple of 8: the block -> (panel, column tile) decode stays bijective
     const dim3 grid((unsigned)(panels8 * (g.N / 256)));
     const bool res = g.R != nullptr, lna = g.stats_in != nullptr;
-    if (lna && res) hipLaunchKernelGGL((gemm_h2_kernel<true, true>), grid, dim3(256), 0, s, g);
-    else if (lna) hipLaunchKernelGGL((gemm_h2_kernel<false, true>), grid, dim3(256), 0, s, g);
-    else if (res) hipLaunchKernelGGL((gemm_h2_kernel<true, false>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((gemm_h2_kernel<false, false>), grid, dim3(256), 0, s, g);
+    static const bool dma = tune_int("RFE_H2_DMA", 1) != 0;   // tuning switch: 0 = weight planes staged through registers
+    constexpr int kDmaLds = 2 * 128 * 64 + 2 * 2 * 256 * 64;   // 80 KB
+#define RFE_H2_LAUNCH(RES_, LNA_)                                                                                                     \
+    do {                                                                                                                              \
+        if (dma) {                                                                                                                    \
+            static const hipError_t attr = hipFuncSetAttribute((const void*)gemm_h2_kernel<RES_, LNA_, true>,                         \
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLds);                  \
+            (void)attr;                                                                                                               \
+            hipLaunchKernelGGL((gemm_h2_kernel<RES_, LNA_, true>), grid, dim3(256), kDmaLds, s, g);                                   \
+        } else {                                                                                                                      \
+            hipLaunchKernelGGL((gemm_h2_kernel<RES_, LNA_, false>), grid, dim3(256), 0, s, g);                                        \
+        }                                                                                                                             \
+    } while (0)
+    if (lna && res) RFE_H2_LAUNCH(true, true);
+    else if (lna) RFE_H2_LAUNCH(false, true);
+    else if (res) RFE_H2_LAUNCH(true, false);
+    else RFE_H2_LAUNCH(false, false);
+#undef RFE_H2_LAUNCH
     return g.stats_out ? 2 * (g.N / 256) : 0;
 }
 
