@@ -179,7 +179,10 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GemmArgs g) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             stageA(k0);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // #2: the A planes are visible
-            if (k0 + BK < g.K) { dmaB(k0 + BK, bbuf ^ 1); fetchA(k0 + BK); }   // in flight under this tile's MFMAs
+            // in flight under this tile's MFMAs.  UNCONDITIONAL (the last tile re-requests itself into the idle buffer): behind a branch
+            // the compiler merges the loaded registers with copies and waits for the loads right here
+            { const int kn = k0 + BK < g.K ? k0 + BK : k0; dmaB(kn, bbuf ^ 1); fetchA(kn); }
+            __builtin_amdgcn_sched_barrier(0);   // ... and without this fence the scheduler sinks the A loads below the MFMAs, next to the barrier that waits for them
             Bt = Bs + bbuf * (2 * BPL);
             bbuf ^= 1;
         } else {
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GemmArgs g) {
                 *reinterpret_cast<u32x4*>(Bs + BN * 64 + p * 64 * 64 + sw_off) = rl[p];
             }
             __syncthreads();
-            if (LNA && k0 + BK < g.K) fetchA(k0 + BK);
+            if (LNA) { fetchA(k0 + BK < g.K ? k0 + BK : k0); __builtin_amdgcn_sched_barrier(0); }   // unconditional, fenced: see the DMA branch
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
