@@ -53,7 +53,7 @@ __device__ __forceinline__ float gelu_short_h2(float t) {   // = gemm.hip:gelu_s
 // Without it (register staging of all twelve loads of a tile at its top) both workgroups of a CU end up waiting for L2 / HBM together.
 typedef __attribute__((address_space(3))) void* h2_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* h2_gptr_t;
-template <bool RES, bool LNA, bool DMA>
+template <bool RES, bool LNA, bool DMA, int ABL = 0>   // ABL: timing ablations of the DMA variant (tuning build only, wrong results): 1 A staged once, 2 no barriers, 4 weights copied once, 8 no epilogue stores
 __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GemmArgs g) {
     constexpr int BM = 128, BN = 256, BK = 32, MB = 2, NB = 4;
     constexpr int BPL = BN * 64;                      // bytes of one B plane of one K tile
@@ -176,12 +176,14 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GemmArgs g) {
         const unsigned char* Bt = Bs;                 // this tile's B planes
         if (DMA) {
             // #1: this tile's weight planes and A rows have landed (requested one tile ago); every wave has finished the previous tile
+            if (ABL & 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); else
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            stageA(k0);
+            if (!(ABL & 1) || k0 == 0) stageA(k0);
+            if (ABL & 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // #2: the A planes are visible
             // in flight under this tile's MFMAs.  UNCONDITIONAL (the last tile re-requests itself into the idle buffer): behind a branch
             // the compiler merges the loaded registers with copies and waits for the loads right here
-            { const int kn = k0 + BK < g.K ? k0 + BK : k0; dmaB(kn, bbuf ^ 1); fetchA(kn); }
+            { const int kn = k0 + BK < g.K ? k0 + BK : k0; if (!(ABL & 4)) dmaB(kn, bbuf ^ 1); if (!(ABL & 1)) fetchA(kn); }
             __builtin_amdgcn_sched_barrier(0);   // ... and without this fence the scheduler sinks the A loads below the MFMAs, next to the barrier that waits for them
             Bt = Bs + bbuf * (2 * BPL);
             bbuf ^= 1;
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GemmArgs g) {
         }
     }
 
-    {   // alpha (+residual) epilogue: 128-B coalesced accesses straight from the D layout (gemm.hip)
+    if (!(ABL & 8)) {   // alpha (+residual) epilogue: 128-B coalesced accesses straight from the D layout (gemm.hip)
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -317,6 +319,15 @@ int launch_gemm_h2(hipStream_t s, const GemmArgs& g) {
             hipLaunchKernelGGL((gemm_h2_kernel<RES_, LNA_, false>), grid, dim3(256), 0, s, g);                                        \
         }                                                                                                                             \
     } while (0)
+#ifdef RFE_TUNING
+    if (!lna && !res) switch (tune_int("RFE_DBG_H2_ABL", 0)) {
+#define RFE_H2_ABL(n) case n: { static const hipError_t a_ = hipFuncSetAttribute((const void*)gemm_h2_kernel<false, false, true, n>, hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLds); (void)a_; \
+                                hipLaunchKernelGGL((gemm_h2_kernel<false, false, true, n>), grid, dim3(256), kDmaLds, s, g); return 0; }
+        RFE_H2_ABL(1) RFE_H2_ABL(2) RFE_H2_ABL(3) RFE_H2_ABL(4) RFE_H2_ABL(7) RFE_H2_ABL(8) RFE_H2_ABL(15)
+#undef RFE_H2_ABL
+        default: break;
+    }
+#endif
     if (lna && res) RFE_H2_LAUNCH(true, true);
     else if (lna) RFE_H2_LAUNCH(false, true);
     else if (res) RFE_H2_LAUNCH(true, false);
