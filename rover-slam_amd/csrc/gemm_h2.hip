@@ -30,7 +30,7 @@ __global__ void split_f16_kernel(const float* __restrict__ x, uint16_t* __restri
     const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
     if (i >= n) return;
     uint32_t h, l;
-    split2_f16(x[i], i + 1 < n ? x[i + 1] : 0.f, h, l);
+    h2_split2_sat(x[i], i + 1 < n ? x[i + 1] : 0.f, h, l);   // load-time pass: the saturating form costs nothing here
     if (i + 1 < n) { *reinterpret_cast<uint32_t*>(hi + i) = h; *reinterpret_cast<uint32_t*>(lo + i) = l; }
     else { hi[i] = (uint16_t)h; lo[i] = (uint16_t)l; }
 }

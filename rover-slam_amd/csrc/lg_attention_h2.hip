@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256, NQB == 2 ? 2 : 3) void lg_attention_h2_kernel(
     int nseq_total, const float* __restrict__ rope_csn) {
     // [buffer][K hi, K lo, V^T hi, V^T lo][64 rows x 128 B]
     constexpr int AH_Q = 128 * NQB;
+    h2_saturate_mode();
     __shared__ __attribute__((aligned(16))) unsigned char lds[(DBUF ? 2 : 1) * 4 * AH_K * 128];
     // XCD-aware decode as lg_attention_kernel: the query blocks of one (sequence, head) run on one XCD
     const int Lb = blockIdx.x, xcd = Lb & 7, t_ = Lb >> 3;

@@ -99,3 +99,23 @@ def test_attention_throughput_shape_vs_float64(ctx, kind):
         errs[fp16x2] = worst
     print(f"attention {kind}: max |context - float64|  fp32 kernels {errs[0]:.2e}   fp16x2 split kernel {errs[1]:.2e}")
     assert errs[0] < ATT_TOL and errs[1] < ATT_TOL, errs
+
+
+def test_attention_split_kernel_saturates_outside_fp16_range(ctx):
+    """RFE_OPT_LG_FP16X2's domain is |operand| < 65504 (fp16).  Outside it the split kernels run with MODE.FP16_OVFL = 1 (h2_split.h): hi
+    saturates at 65504, lo takes up the rest -- values up to 131008 are still carried to fp16's 11 bits -- instead of inf - inf = NaN for
+    every query that attends to the offending key.  V entries of +-9e4 here: finite everywhere and within 1e-3 relative of float64."""
+    from rover_slam_amd import capi
+    rng = np.random.default_rng(11)
+    nseq, L, ld, offs = 32, 1024, 768, (0, 256, 512)
+    x = rng.standard_normal((nseq * L, ld)).astype(np.float32)
+    big = rng.integers(0, nseq * L, 64)
+    x[big, 512 + rng.integers(0, 256, 64)] = rng.choice([-9.0e4, 9.0e4], 64).astype(np.float32)
+    lens = np.full(nseq, L, np.int32)
+    out = _run(ctx, capi, x, offs, ld, nseq, L, lens, None, None, 1)
+    assert np.isfinite(out).all(), "the split attention produced non-finite context rows"
+    xs = x.reshape(nseq, L, ld)
+    for s in (0, 13, 31):
+        ref = _attention_f64(xs[s][:, :256], xs[s][:, 256:512], xs[s][:, 512:], L, L)
+        scale = np.abs(ref).max()
+        assert np.abs(out[s] - ref).max() < 1e-3 * scale, (s, float(np.abs(out[s] - ref).max()), float(scale))
