@@ -88,9 +88,10 @@ uint64_t rfe_weights_id(rfe_ctx* ctx, int kind);
  *   2.2-2.8x and the attention 2.4-2.6x faster than the fp32 kernels; error against float64: Linears rms 3.2e-8 of sum|a||b| (fp32 fmaf
  *   chain: 2.8e-8), attention context 3.7e-6 (fp32 kernels: 4.8e-6) (profiles/r03_ab_notes.md, tests/test_gpu_attention.py); end to end
  *   over the 40-case study the match lists are identical and the scores sit 1.6e-4 (Wo folded) / 2.6e-4 (unfolded) from float64, inside
- *   the spread of the fp32 evaluations of the same graph (1.8e-4 .. 2.6e-4, profiles/r03_lg_tolerance.md).  Valid while activations stay below fp16's 65504 in magnitude (LightGlue's are O(1..100)); past it the
- *   attention's operands saturate (finite results), a Linear's input overflows to infinity.  The
- *   assignment and all of SuperPoint stay fp32; bench.py reports it as `variants.fp16x2`, never as the headline. */
+ *   the spread of the fp32 evaluations of the same graph (1.8e-4 .. 2.6e-4, profiles/r03_lg_tolerance.md).  Valid while activations
+ *   stay below fp16's 65504 in magnitude (LightGlue's are O(1..100)); past it the attention's operands saturate (finite results), a
+ *   Linear's input overflows to infinity.  The assignment and all of SuperPoint stay fp32; bench.py reports it as `variants.fp16x2`,
+ *   never as the headline. */
 #define RFE_OPT_LG_FOLD_WO 1
 #define RFE_OPT_LG_FP16X2 2
 int rfe_set_option(rfe_ctx* ctx, int option, int value);
