@@ -44,11 +44,22 @@ __device__ __forceinline__ float gelu_short(float t) {
 // eight different slots -> all 32 banks).  MFMA step (g, c) therefore multiplies k = 4 g + c and k = 16 + 4 g + c: every product
 // of the K tile is summed, in a different order than k ascending -- LightGlue only (SuperPoint's 1x1 heads stay bit-exact on the
 // padded path).  LDS instructions per K tile and wave: 36 instead of 144.
-template <int MB, int NB, bool RES, bool PFT = false, bool LNA = false, bool KP = false>
+// DMAB (KP throughput tile only; not batched): the B tile (weights) never touches a register -- it is copied by global_load_lds_dwordx4
+// into a DOUBLE-buffered LDS tile (2 x 32 KB; with the 16 KB A tile = 80 KB per workgroup: still two workgroups per CU,
+// tools/kbench/lds_occupancy.hip), tile t + 1 requested right after tile t is published; the 16-byte-slot swizzle is applied on the SOURCE
+// address (the LDS side of the copy is lane-linear: lane l of a wave instruction fills bytes 16 l .. of 1 KB = 8 rows).  Eight of the
+// twelve ds_write_b128 per thread and K tile and 32 staging VGPRs go away; the barriers are raw (s_waitcnt + s_barrier) so that the
+// copies stay in flight across the one that publishes the A tile.
+typedef __attribute__((address_space(3))) void* gemm_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gemm_gptr_t;
+template <int MB, int NB, bool RES, bool PFT = false, bool LNA = false, bool KP = false, bool DMAB = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     constexpr int BM = MB * 64, BN = NB * 64;
     constexpr int LDR = KP ? BK : LDT;          // LDS row stride in words
-    __shared__ __attribute__((aligned(16))) float lds_ab[(BM + BN) * LDR];   // A tile | B tile
+    static_assert(!DMAB || (KP && PFT && !LNA && MB == 2), "DMAB: k-permuted throughput tile only");
+    __shared__ __attribute__((aligned(16))) float lds_static[DMAB ? 4 : (BM + BN) * LDR];   // A tile | B tile
+    extern __shared__ __attribute__((aligned(16))) float lds_dynamic[];                      // DMAB: A tile | B tile x 2 = (BM + 2 BN) * LDR words
+    float* const lds_ab = DMAB ? lds_dynamic : lds_static;
     float* const As = lds_ab;
     float* const Bs = lds_ab + BM * LDR;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -142,9 +153,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
             for (int it = 0; it < A_IT; ++it) ra[it] = *reinterpret_cast<const float4*>(base + aoff[it]);
         }
+        if (DMAB) return;   // the B tile goes through dma_b
         const float* base = Bt + k0;
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) rb[it] = *reinterpret_cast<const float4*>(base + boff[it]);
+    };
+    // one wave instruction copies 64 x 16 B = 1 KB = 8 rows of 128 B; wave w issues the row groups (BN / 32) w .. of the tile.  Lane l fills
+    // row 8 grp + l / 8, physical slot l & 7, which holds logical slot (l & 7) ^ (row & 7) = (l & 7) ^ (l >> 3)
+    auto dma_b = [&](int k0, int buf) {
+        constexpr int GPW = BN / 32;   // row groups per wave
+#pragma unroll
+        for (int u = 0; u < GPW; ++u) {
+            const int grp = wave * GPW + u;
+            int row = grp * 8 + (lane >> 3); row = row < nlast ? row : nlast;
+            const float* src = Bt + (size_t)row * g.ldb + k0 + 4 * ((lane & 7) ^ (lane >> 3));
+            __builtin_amdgcn_global_load_lds((gemm_gptr_t)src, (gemm_lds_ptr_t)(Bs + buf * (BN * LDR) + grp * 256), 16, 0, 0);
+        }
     };
     // LN + GELU of one staged element, same operation order as the stand-alone kernel: ((a - mean) * rstd) * g + b, then GELU
     auto ln_elem = [&](float a, int it, float gq, float bq) { return gelu_short((a - ln_mean[it]) * ln_rstd[it] * gq + bq); };
@@ -159,10 +183,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 #else
     constexpr int abl = 0;
 #endif
+    if (DMAB) dma_b(0, 0);
     if (PF) load_tile(0);
     if (LNI) ln_tile();   // first tile: nothing to hide it under
+    int bbuf = 0;
     for (int k0 = 0; k0 < g.K; k0 += BK) {
         if (!PF) load_tile(k0);
+        if (DMAB) {
+            // #1: this tile's B copy and A rows have landed (requested one tile ago); every wave has finished the previous tile
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it)
+                *reinterpret_cast<f32x4*>(da + it * 32 * LDR) = f32x4{ra[it].x, ra[it].y, ra[it].z, ra[it].w};
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // #2: the A tile is visible
+            // next tile, in flight under this tile's MFMAs.  Unconditional (the last tile re-requests itself into the idle buffer) and fenced:
+            // behind a branch the compiler merges the loaded registers with copies and waits for the loads on the spot, without the fence
+            // the scheduler sinks them below the MFMAs (profiles/r03_ab_notes.md)
+            { const int kn = k0 + BK < g.K ? k0 + BK : k0; dma_b(kn, bbuf ^ 1); load_tile(kn); }
+            __builtin_amdgcn_sched_barrier(0);
+        } else
         if (!(abl & 2) || k0 == 0) {
         __syncthreads();   // previous tile fully consumed
 #pragma unroll
@@ -190,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
         }
         __syncthreads();
         }
-        if (PF && k0 + BK < g.K && !(abl & 1)) load_tile(k0 + BK);
+        if (!DMAB && PF && k0 + BK < g.K && !(abl & 1)) load_tile(k0 + BK);
         // LNI: the tile prefetched before this loop has landed by now (>= 64 MFMAs = 4096 cycles after its loads were issued):
         // its LayerNorm + GELU -- VALU work, 2 of the 16 elements of this thread per k-step -- runs in the shadow of the
         // MFMAs of the remaining k-steps instead of on the staging path in front of the barrier
@@ -210,13 +249,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
             // fragment back into its own registers as soon as its last MFMA of this group has been issued (+8 VGPRs, no LDS
             // round trip exposed at the group boundaries)
             const int iswz = i & 7;
+            const float* const bpt = DMAB ? bp + bbuf * (BN * LDR) : bp;   // this tile's B buffer
             f32x4 a4[MB], b4[NB];
             {
                 const int slot = ((h << 2) ^ iswz) << 2;
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) a4[mb] = *reinterpret_cast<const f32x4*>(ap + mb * 32 * LDR + slot);
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) b4[nb] = *reinterpret_cast<const f32x4*>(bp + nb * 32 * LDR + slot);
+                for (int nb = 0; nb < NB; ++nb) b4[nb] = *reinterpret_cast<const f32x4*>(bpt + nb * 32 * LDR + slot);
             }
 #pragma unroll
             for (int gq4 = 0; gq4 < 4; ++gq4) {
@@ -234,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
                         for (int mb = 0; mb < MB; ++mb)
                             acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[mb][cq], b4[nb][cq], acc[mb][nb], 0, 0, 0);
-                    if (gq4 < 3) { b4[nb] = *reinterpret_cast<const f32x4*>(bp + nb * 32 * LDR + nslot); __builtin_amdgcn_sched_barrier(0); }
+                    if (gq4 < 3) { b4[nb] = *reinterpret_cast<const f32x4*>(bpt + nb * 32 * LDR + nslot); __builtin_amdgcn_sched_barrier(0); }
                     RFE_LN_SHADOW(gq4 * 4 + nb)
                 }
                 if (gq4 < 3) {
@@ -258,6 +298,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
             }
         }
 #undef RFE_LN_SHADOW
+        if (DMAB) bbuf ^= 1;
     }
 
     {   // bias (+alpha, +ReLU, +residual) epilogue: 128-B coalesced accesses straight from the D layout
@@ -372,8 +413,19 @@ int launch_gemm_nt(hipStream_t s, const GemmArgs& g_in) {
     static const bool kp_on = tune_int("RFE_GEMM_KP", 1) != 0;   // tuning switch: 0 = padded layout / k-ascending order everywhere
     const bool kp = kp_on && g.kperm != 0;
     static const bool pft = tune_int("RFE_GEMM_PF", 1) != 0;   // register prefetch of the next K tile also on the 128-row tiles (+1 % on ffn1 / ffn2, profiles/r02_ab_notes.md); RFE_GEMM_PF=0 (tuning build) disables
+    static const bool dmab = tune_int("RFE_GEMM_DMA", 0) != 0;   // tuning switch, OFF in the product: B tile by LDS-DMA on the k-permuted throughput tile (ffn.0 269.5 -> 266.1 us, qkv 218.6 -> 216.3, cross-qkv unchanged: within 1.3 %, not worth a second code path under the headline -- profiles/r03_ab_notes.md)
+    constexpr int kDmaLds = (128 + 2 * 256) * 32 * 4;            // 80 KB
 #define RFE_GEMM_GO(MB_, NB_, GRID)                                                                  \
     do {                                                                                             \
+        if (kp && MB_ == 2 && NB_ == 4 && pft && !lna && dmab && batch == 1 && !g.m_valid) {         \
+            if (res) {                                                                               \
+                static const hipError_t a_ = hipFuncSetAttribute((const void*)gemm_nt_kernel<2, 4, true, true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLds); (void)a_; \
+                hipLaunchKernelGGL((gemm_nt_kernel<2, 4, true, true, false, true, true>), GRID, dim3(256), kDmaLds, s, g); \
+            } else {                                                                                 \
+                static const hipError_t a_ = hipFuncSetAttribute((const void*)gemm_nt_kernel<2, 4, false, true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLds); (void)a_; \
+                hipLaunchKernelGGL((gemm_nt_kernel<2, 4, false, true, false, true, true>), GRID, dim3(256), kDmaLds, s, g); \
+            }                                                                                        \
+        } else                                                                                       \
         if (kp && MB_ == 2 && pft && !lna) {                                                         \
             if (res) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, true, MB_ == 2, false, MB_ == 2>), GRID, dim3(256), 0, s, g); \
             else hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, false, MB_ == 2, false, MB_ == 2>), GRID, dim3(256), 0, s, g);         \
