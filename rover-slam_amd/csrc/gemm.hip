@@ -419,10 +419,10 @@ int launch_gemm_nt(hipStream_t s, const GemmArgs& g_in) {
     do {                                                                                             \
         if (kp && MB_ == 2 && NB_ == 4 && pft && !lna && dmab && batch == 1 && !g.m_valid) {         \
             if (res) {                                                                               \
-                static const hipError_t a_ = hipFuncSetAttribute((const void*)gemm_nt_kernel<2, 4, true, true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLds); (void)a_; \
+                static bool ls_[64]; ensure_dynamic_lds((const void*)gemm_nt_kernel<2, 4, true, true, false, true, true>, kDmaLds, ls_); \
                 hipLaunchKernelGGL((gemm_nt_kernel<2, 4, true, true, false, true, true>), GRID, dim3(256), kDmaLds, s, g); \
             } else {                                                                                 \
-                static const hipError_t a_ = hipFuncSetAttribute((const void*)gemm_nt_kernel<2, 4, false, true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLds); (void)a_; \
+                static bool ls_[64]; ensure_dynamic_lds((const void*)gemm_nt_kernel<2, 4, false, true, false, true, true>, kDmaLds, ls_); \
                 hipLaunchKernelGGL((gemm_nt_kernel<2, 4, false, true, false, true, true>), GRID, dim3(256), kDmaLds, s, g); \
             }                                                                                        \
         } else                                                                                       \

@@ -311,9 +311,8 @@ int launch_gemm_h2(hipStream_t s, const GemmArgs& g) {
 #define RFE_H2_LAUNCH(RES_, LNA_)                                                                                                     \
     do {                                                                                                                              \
         if (dma) {                                                                                                                    \
-            static const hipError_t attr = hipFuncSetAttribute((const void*)gemm_h2_kernel<RES_, LNA_, true>,                         \
-                                                               hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLds);                  \
-            (void)attr;                                                                                                               \
+            static bool lds_set[64];                                                                                                  \
+            ensure_dynamic_lds((const void*)gemm_h2_kernel<RES_, LNA_, true>, kDmaLds, lds_set);                                      \
             hipLaunchKernelGGL((gemm_h2_kernel<RES_, LNA_, true>), grid, dim3(256), kDmaLds, s, g);                                   \
         } else {                                                                                                                      \
             hipLaunchKernelGGL((gemm_h2_kernel<RES_, LNA_, false>), grid, dim3(256), 0, s, g);                                        \
@@ -321,7 +320,7 @@ int launch_gemm_h2(hipStream_t s, const GemmArgs& g) {
     } while (0)
 #ifdef RFE_TUNING
     if (!lna && !res) switch (tune_int("RFE_DBG_H2_ABL", 0)) {
-#define RFE_H2_ABL(n) case n: { static const hipError_t a_ = hipFuncSetAttribute((const void*)gemm_h2_kernel<false, false, true, n>, hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLds); (void)a_; \
+#define RFE_H2_ABL(n) case n: { static bool ls_[64]; ensure_dynamic_lds((const void*)gemm_h2_kernel<false, false, true, n>, kDmaLds, ls_); \
                                 hipLaunchKernelGGL((gemm_h2_kernel<false, false, true, n>), grid, dim3(256), kDmaLds, s, g); return 0; }
         RFE_H2_ABL(1) RFE_H2_ABL(2) RFE_H2_ABL(3) RFE_H2_ABL(4) RFE_H2_ABL(7) RFE_H2_ABL(8) RFE_H2_ABL(15)
 #undef RFE_H2_ABL

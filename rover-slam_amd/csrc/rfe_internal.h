@@ -165,6 +165,16 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
 void launch_conv1ab_fused(hipStream_t s, const uint8_t* img, int stride, int B, int H, int W, const float* w1a,
                           const float* b1a, const float* wp, const float* bias, float* out);
 // gemm.hip
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the CURRENT device's copy of a kernel: set it once per (kernel, device) -- pools run
+// one ctx per device.  `done` is the caller's per-kernel flag array (static bool [64]); races only repeat the idempotent call.
+inline void ensure_dynamic_lds(const void* kernel, int bytes, bool* done) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !done[dev]) {
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (dev >= 0 && dev < 64) done[dev] = true;
+    }
+}
 int launch_gemm_h2(hipStream_t s, const GemmArgs& g);   // gemm_h2.hip: split GEMM on the f16 matrix pipe (GemmArgs::Bh / Bl), called by launch_gemm_nt
 void launch_split_f16(hipStream_t s, const float* x, uint16_t* hi, uint16_t* lo, size_t n);
 int launch_gemm_nt(hipStream_t s, const GemmArgs& g);   // returns the number of partial-statistics pairs per row it wrote (0 without stats_out)
