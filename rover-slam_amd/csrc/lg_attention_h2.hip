@@ -6,8 +6,9 @@
 // 32 x 32 x 16 block: 24 matrix instructions of 32 cycles per 32 keys x 32 queries where the fp32 kernel issues 64 of 64 cycles.
 // The reference runs this inside Session::Run(lightglue_sim.onnx), src/Matchers/lightglue_onnx.cpp:210-214.
 //
-// Workgroup = 4 waves = 256 queries of one head, wave = 64 queries (two 32-query blocks b: the K and V^T fragments read from LDS feed
-// both -- at the f16 rate a 32-query wave would need 85 B/clk of LDS reads per CU).  64-key tiles, double-buffered in LDS (64 KB, two
+// Workgroup = 4 waves = 256 queries of one head, wave = 64 queries (NQB = 2: two 32-query blocks b share every K / V^T fragment read and
+// every staged tile serves twice the queries; the 128-query / 32-query-wave shape of the fp32 kernel -- NQB = 1, one tile buffer, three
+// workgroups per CU -- measured 7 % slower, profiles/r03_ab_notes.md).  64-key tiles, double-buffered in LDS (64 KB, two
 // workgroups per CU), ONE barrier per tile: tile t+1 is fetched into registers before the products of tile t and written (split into
 // planes) after them.  Per tile and 32-key sub-block:
 //   S^T = K . Q^T      A = K rows (hi / lo planes, [key][64 dims], 128-byte rows of eight 16-byte slots, slot c at c ^ ((key >> 1) & 7):
@@ -20,9 +21,11 @@
 //   O^T += V^T . P^T   A = V^T (hi / lo planes, [dim][64 keys] with the keys of every 16-key group stored in that swapped order, built
 //                      by a 4 x 4 register transpose while staging: thread = 4 keys x 4 dims, one ds_write_b64 per dim and plane).
 //                      Row d sits at physical row (d & ~1) | ((d ^ (d >> 4)) & 1), slot c at c ^ (((d & 15) ^ (d >> 4)) >> 1): both the
-//                      fragment reads (16 consecutive d) and the transposing writes (d = 4 dq + c over 16 dq) are bank-conflict free.
+//                      fragment reads (16 consecutive d) are bank-conflict free (the transposing 8-byte writes are not quite -- stores
+                      are served 16 lanes / 32 banks at a time: 14 % of the LDS cycles, which are 14 % of the kernel's).
 // The deferred-rescale threshold is 2^11 (fp32 kernel: 2^16): P must stay below fp16's 65504.  Values below fp16's normal range
 // (|x| < 6.1e-5: small P, low planes) are carried as fp16 subnormals -- absolute error <= 2^-25 per element, against a row sum >= 1.
+// Operands past fp16's range saturate instead of overflowing (MODE.FP16_OVFL, h2_split.h): finite results outside the option's domain.
 // Rotary (self blocks): applied to q and k with the same three fp32 operations as lg_attention_kernel, before the split.
 #include "rfe_internal.h"
 #include "h2_split.h"
