@@ -20,8 +20,8 @@
 //                      16 s + 8 (e >> 2) + 4 h + (e & 3): key bits 2 and 3 swapped;
 //   O^T += V^T . P^T   A = V^T (hi / lo planes, [dim][64 keys] with the keys of every 16-key group stored in that swapped order, built
 //                      by a 4 x 4 register transpose while staging: thread = 4 keys x 4 dims, one ds_write_b64 per dim and plane).
-//                      Row d sits at physical row (d & ~1) | ((d ^ (d >> 4)) & 1), slot c at c ^ (((d & 15) ^ (d >> 4)) >> 1): both the
-////                      fragment reads (16 consecutive d) are bank-conflict free (the transposing 8-byte writes are not quite -- stores
+//                      Row d sits at physical row (d & ~1) | ((d ^ (d >> 4)) & 1), slot c at c ^ (((d & 15) ^ (d >> 4)) >> 1): the
+//                      fragment reads (16 consecutive d) are bank-conflict free (the transposing 8-byte writes are not quite -- stores
 //                      are served 16 lanes / 32 banks at a time: 14 % of the LDS cycles, which are 14 % of the kernel's).
 // The deferred-rescale threshold is 2^11 (fp32 kernel: 2^16): P must stay below fp16's 65504.  Values below fp16's normal range
 // (|x| < 6.1e-5: small P, low planes) are carried as fp16 subnormals -- absolute error <= 2^-25 per element, against a row sum >= 1.
