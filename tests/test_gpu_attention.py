@@ -62,13 +62,14 @@ def _run(ctx, capi, x, offs, ld, nseq, L, lens, kvmap, rope, fp16x2):
     return out
 
 
-@pytest.mark.parametrize("kind", ["self_rope", "cross"])
+@pytest.mark.parametrize("kind", ["self_rope", "cross", "self_rope_L1000", "cross_L1000"])
 def test_attention_throughput_shape_vs_float64(ctx, kind):
     from rover_slam_amd import capi
-    rng = np.random.default_rng(5 if kind == "cross" else 6)
-    nseq, L = 32, 1024
+    rng = np.random.default_rng({"cross": 5, "self_rope": 6, "cross_L1000": 7, "self_rope_L1000": 8}[kind])
+    nseq, L = (34, 1000) if kind.endswith("L1000") else (32, 1024)   # L = 1000: a padded length that is a multiple of 4 only (not of the 64-key tile / 256-query block)
+    kind = kind.replace("_L1000", "")
     lens = np.full(nseq, L, np.int32)
-    lens[[1, 6, 7, 20]] = [650, 1001, 257, 32]          # ragged: partial last tiles, a sequence shorter than one query block
+    lens[[1, 6, 7, 20]] = [650, min(1001, L - 3), 257, 32]          # ragged: partial last tiles, a sequence shorter than one query block
     if kind == "self_rope":
         ld, offs, kvmap = 768, (0, 256, 512), None       # [q | k | v] rows as the self block's projection writes them
         rope = np.empty((nseq * L, 32, 2), np.float32)
