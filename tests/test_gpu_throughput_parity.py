@@ -231,3 +231,40 @@ def test_lightglue_batch16_fp16x2_vs_oracle(ctx, oracle):
     print(f"batch16 fp16x2: {total} matches over {P} pairs, max |score dev| vs oracle {worst:.2e}")
     for b in (dx0, dx1, dsc):
         b.free()
+
+
+def test_ffn_block_ragged_rows_fp32_and_fp16x2_vs_float64(ctx):
+    """One FFN block (ffn.0 -> LayerNorm -> GELU -> ffn.3 + residual) on 34 077 token rows -- not a multiple of the 128-row tiles -- through the
+    forward's own code (rfe_k_lightglue_ffn: throughput tiles, fused LayerNorm partials) with the fp32 kernels and with RFE_OPT_LG_FP16X2 (split
+    GEMMs: weight planes by LDS-DMA, clamped edge rows): both against a float64 evaluation on sampled rows including the last ones."""
+    from rover_slam_amd import capi
+    from scipy.special import erf
+    w = Wt.make_lightglue(seed=11)
+    man, _ = Wt.lg_manifest()
+    t = {name: (off, shape) for name, off, shape in man}
+    g = lambda name: w[t[name][0]:t[name][0] + int(np.prod(t[name][1]))].reshape(t[name][1]).astype(np.float64)
+    rows = 34077
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((rows, 256)).astype(np.float32)
+    s = rng.standard_normal((rows, 256)).astype(np.float32)
+    dx, dsec, dout = ctx.alloc(x.nbytes).upload(x), ctx.alloc(s.nbytes).upload(s), ctx.alloc(x.nbytes)
+    sel = np.concatenate([rng.choice(rows - 200, 300, replace=False), np.arange(rows - 200, rows)])
+    p = "layers.3.cross."
+    h = np.concatenate([x[sel], s[sel]], 1).astype(np.float64) @ g(p + "W1").T + g(p + "b1")
+    mu, var = h.mean(1, keepdims=True), h.var(1, keepdims=True)
+    hn = (h - mu) / np.sqrt(var + 1e-5) * g(p + "ln_g") + g(p + "ln_b")
+    ref = x[sel] + (0.5 * hn * (1 + erf(hn / np.sqrt(2.0)))) @ g(p + "W2").T + g(p + "b2")
+    dev = {}
+    for opt in (0, 1):
+        ctx.set_option(capi.OPT_LG_FP16X2, opt)
+        try:
+            ctx._chk(capi.lib.rfe_k_lightglue_ffn(ctx.h, 3, 1, dx.ptr, dsec.ptr, rows, dout.ptr))
+        finally:
+            ctx.set_option(capi.OPT_LG_FP16X2, 0)
+        out = dout.download((rows, 256), np.float32)
+        assert np.isfinite(out).all()
+        dev[opt] = float(np.abs(out[sel] - ref).max())
+    print(f"FFN block, 34 077 rows: max |out - float64|  fp32 kernels {dev[0]:.2e}   fp16x2 split kernels {dev[1]:.2e}  (|out| up to {np.abs(ref).max():.1f})")
+    assert dev[0] < 1e-4 and dev[1] < 1e-4, dev
+    for b in (dx, dsec, dout):
+        b.free()
