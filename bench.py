@@ -211,6 +211,8 @@ def cpu_baseline(frames, wsp, wlg, gpu=None):
     prev, nf = None, 0
     sp_ok, lg_ok, lg_identical = True, True, True
     ms_dev, n_matches, one_sided = 0.0, 0, 0
+    alt = gpu.get("alt") if gpu is not None else None      # match lists of the same pairs from variants.fp16x2 (RFE_OPT_LG_FP16X2 on): same oracle, same rule
+    alt_stat = {"ok": True, "identical": True, "dev": 0.0, "matches": 0, "one_sided": 0}
     from tolerances import LG_SCORE_TOL, lists_agree_borderline
 
     def check_pair(idx, lg):
@@ -222,6 +224,12 @@ def cpu_baseline(frames, wsp, wlg, gpu=None):
         lg_ok &= bool(ok and dev < LG_SCORE_TOL)
         lg_identical &= bool(only == 0 and Sg == lg["S"])
         ms_dev, n_matches, one_sided = max(ms_dev, float(dev)), n_matches + Sg, one_sided + only
+        if alt is not None:
+            Sa = int(alt["S"][idx])
+            ok2, dev2, only2 = lists_agree_borderline(alt["pairs"][idx, :Sa], alt["ms"][idx, :Sa], lg["pairs"], lg["ms"], lg["scores"], KMAX)
+            alt_stat["ok"] &= bool(ok2 and dev2 < LG_SCORE_TOL)
+            alt_stat["identical"] &= bool(only2 == 0 and Sa == lg["S"])
+            alt_stat["dev"], alt_stat["matches"], alt_stat["one_sided"] = max(alt_stat["dev"], float(dev2)), alt_stat["matches"] + Sa, alt_stat["one_sided"] + only2
 
     while nf < len(frames) and (nf < 4 or time.perf_counter() - t0 < 12.0):
         cur = O.superpoint(wsp, frames[nf], kmax=KMAX)
@@ -256,6 +264,11 @@ def cpu_baseline(frames, wsp, wlg, gpu=None):
                             "on a row / column whose two best probabilities are closer than 2 tol; common scores within tol",
                     "tolerance_note": "stated fp32 tolerance of LightGlue match scores at K = 1024 (tests/tolerances.py, profiles/r02_lg_tolerance.md: "
                                       "any two fp32 evaluations of the graph differ by 1-3e-4, oracle vs float64 2.6e-4)"}
+        if alt is not None:
+            verified["fp16x2_variant"] = {"ok": alt_stat["ok"], "match_lists_identical": alt_stat["identical"], "matches_compared": alt_stat["matches"],
+                                          "one_sided_borderline_matches": alt_stat["one_sided"], "match_score_max_dev": alt_stat["dev"],
+                                          "note": "the match lists variants.fp16x2 produced for the same pairs, against the same oracle results under the same rule "
+                                                  "(SuperPoint is not affected by the option)"}
         if not verified["ok"]:
             print(f"bench.py: GPU results of the timed loop differ from the oracle: {verified}", file=sys.stderr)
     return {"value": round((nf - 1) / dt, 4), "unit": "frames/s", "cores": O.threads(), "cpu_model": cpu_model(), "kind": "port",
@@ -640,6 +653,7 @@ def main():
     # ---- variants ("also report K in {256, 512}" and "a second weight set with dustbin bias to exercise K < Kmax and
     # variable-K batching"): the same 33-frame / 32-pair step at other keypoint budgets, short runs, never the headline
     variants = None
+    fp16x2_out = None
     if world == 1 and not args.no_variants and args.workload == "c4" and not args.lg_fp16x2:
         variants = {}
 
@@ -691,6 +705,7 @@ def main():
             devh = max([float(np.abs(mh[q, :S32[q]] - m32[q, :S32[q]]).max()) for q in range(B - 1) if S32[q] > 0 and Sh[q] == S32[q]] or [0.0]) if same else None
             variants["fp16x2"].update({"match_lists_identical_to_fp32_path": same, "match_score_max_dev_vs_fp32_path": devh,
                                                "matches_total": int(S32.sum())})
+            fp16x2_out = {"S": Sh.copy(), "pairs": ph.copy(), "ms": mh.copy()}
         finally:
             ctx.set_option(capi.OPT_LG_FP16X2, 0)
         step(); fence()      # ... and of the fp32 path
@@ -845,7 +860,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             gpu = {k: v.cpu().numpy() for k, v in (("n", n), ("kxy", kxy), ("score", score), ("desc", desc), ("S", S), ("pairs", pairs), ("ms", ms))}
             gpu["fold"] = fold
+            if fp16x2_out is not None:
+                gpu["alt"] = fp16x2_out
             out["cpu_baseline"] = cpu_baseline(frames_np, wsp, wlg, gpu)
+            vf = (out["cpu_baseline"].get("verified_against_gpu") or {}).pop("fp16x2_variant", None)
+            if vf is not None and variants is not None and "fp16x2" in variants:
+                variants["fp16x2"]["verified_against_oracle"] = vf
             out["cpu_baseline_torch"] = torch_cpu_baseline(frames_np, wsp, wlg)
             ref = ort_reference_baseline(frames_np)          # only where onnxruntime + the real blobs exist (not in this image)
             if ref is not None:
