@@ -12,6 +12,7 @@ max |score difference| over common matches, match lists identical in every case 
   HF transformers (fp32, torch CPU) vs float64             1.2e-4 (the two full-size fixtures)
 Round 3 (profiles/r03_lg_tolerance.md, final kernels; every case also inside a 16-pair call = the THROUGHPUT tiling the benchmark times):
   HIP single pair vs oracle / vs float64                   2.8e-4 / 2.3e-4        HIP 16-pair batch vs oracle / vs float64   3.2e-4 / 1.8e-4
+  randomised sweep, 29 weight seeds, 1216 ragged pairs inside 16-20-pair calls (profiles/r03_fuzz_fp16x2.md): HIP vs oracle <= 3.5e-4 (fp32) / 4.0e-4 (RFE_OPT_LG_FP16X2)
 i.e. any two fp32 evaluation orders of this graph differ by 1-3e-4 (the case with the largest HIP-vs-oracle figure is the
 one where the ORACLE sits 2.6e-4 from float64 and the HIP path 7e-5): 1e-4 is below the noise floor of fp32 itself at this
 size, and the fold does not change the picture.  Final token states agree to 1e-5 (bar 1e-4).
