@@ -36,14 +36,16 @@ public:
     long long matcher_timer = 0;
     float lastmatch = 0;
     std::vector<float> scales = {1.0f, 1.0f};
-    int max_keypoints = 1024;                       // export-time max_num_keypoints of the reference graph
+    // The reference takes K from the shape of the graph's `keypoints` output (superpoint_onnx.cc:169-181): max_num_keypoints and the
+    // detection threshold are constants of superpoint.onnx.  Here they come from the weight file's RFEW v2 header (written by
+    // rover-slam_amd/onnx_weights.py from the graph it converts) through rfe_get_hparams, as do the NMS radius and the border inside
+    // the library; a version-1 file gives the published defaults below.
+    int max_keypoints = 1024;
     float detection_threshold = 0.0005f;
     std::vector<std::vector<rfe::Tensor>> extractor_outputtensors;
     std::pair<std::vector<cv::Point2f>, std::vector<cv::Point2f>> keypoints_result;
 
-    explicit SuperPointOnnxRunner(unsigned int threads = 1) : num_threads(threads) {
-        if (const char* e = std::getenv("RFE_MAX_KEYPOINTS")) max_keypoints = std::atoi(e);
-    }
+    explicit SuperPointOnnxRunner(unsigned int threads = 1) : num_threads(threads) {}
     ~SuperPointOnnxRunner() { if (ExtractorSession) rfe_destroy(ExtractorSession); }
     SuperPointOnnxRunner(const SuperPointOnnxRunner&) = delete;
     SuperPointOnnxRunner& operator=(const SuperPointOnnxRunner&) = delete;
@@ -65,6 +67,8 @@ public:
             std::cerr << "[ERROR] rover_fe environment created failed : " << rfe_last_error(ExtractorSession) << '\n';
             return EXIT_FAILURE;
         }
+        rfe_hparams hp;
+        if (rfe_get_hparams(ExtractorSession, &hp) == RFE_OK) { max_keypoints = hp.sp_max_keypoints; detection_threshold = hp.sp_detection_threshold; }
         return EXIT_SUCCESS;
     }
 
@@ -79,8 +83,9 @@ public:
         extractor_outputtensors.clear();
         if (!ExtractorSession) { std::cerr << "[ERROR] Extractor inference failed : no session" << std::endl; return EXIT_FAILURE; }
         const int K = max_keypoints;
-        std::vector<int32_t> kxy((size_t)K * 2);
-        std::vector<float> sc(K), desc((size_t)K * 256);
+        std::vector<int32_t>& kxy = stage_kxy_;        // grow-only staging owned by the runner: nothing K-sized is allocated per call
+        std::vector<float>&sc = stage_score_, &desc = stage_desc_;
+        if (kxy.size() < (size_t)K * 2) { kxy.resize((size_t)K * 2); sc.resize(K); desc.resize((size_t)K * 256); }
         int32_t n = 0;
         auto t0 = std::chrono::high_resolution_clock::now();
         int rc = rfe_extract_u8(ExtractorSession, img, H, W, stride, 1, K, detection_threshold, &n, kxy.data(), sc.data(), desc.data());
@@ -151,4 +156,8 @@ public:
     void SetMatchThresh(float thresh) { matchThresh = thresh; }
     double GetTimer(std::string name) { return name == "extractor" ? (double)extractor_timer : (double)matcher_timer; }
     std::pair<std::vector<cv::Point2f>, std::vector<cv::Point2f>> GetKeypointsResult() { return keypoints_result; }
+
+private:
+    std::vector<int32_t> stage_kxy_;
+    std::vector<float> stage_score_, stage_desc_;
 };

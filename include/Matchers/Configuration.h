@@ -4,7 +4,9 @@
 // Differences: the two paths name RFEW weight containers (rover-slam_amd/weights.py), not .onnx files --
 // when they do not end in ".rfew" the shims fall back to $RFE_SP_WEIGHTS / $RFE_LG_WEIGHTS and then to
 // onnxmodel/superpoint.rfew / onnxmodel/lightglue_sim.rfew; `device` is accepted and ignored (the only
-// backend is HIP on gfx950; the reference passes "cuda", SPextractor.cc:92); two fields are additions.
+// backend is HIP on gfx950; the reference passes "cuda", SPextractor.cc:92).  The keypoint budget, detection threshold, NMS radius,
+// border and match filter are NOT configuration here, just as they are not in the reference: they are constants of the model files and
+// travel in the RFEW v2 header (rfe_hparams, include/rover_fe.h).
 #pragma once
 #include <string>
 
@@ -17,7 +19,4 @@ struct Configuration {
     bool isEndtoEnd = true, grayScale = false, viz = false;
     unsigned int image_size = 512;
     float threshold = 0.0f;
-    // additions
-    int max_keypoints = 0;                     // 0 = runner default (1024 or $RFE_MAX_KEYPOINTS)
-    float detection_threshold = 0.0005f;       // SuperPoint score threshold of the LightGlue-ONNX export
 };

@@ -27,7 +27,8 @@ public:
     rfe_ctx* MatcherSession = nullptr;             // reference: Ort::Session*
     std::vector<std::vector<int64_t>> MatcherInputNodeShapes = {{1, -1, 2}, {1, -1, 2}, {1, -1, 256}, {1, -1, 256}};
     float matchThresh = 0.0f;
-    float filter_threshold = 0.1f;                 // in-graph filter of the fused LightGlue export
+    float filter_threshold = 0.1f;                 // in-graph filter of the fused LightGlue export: a constant of lightglue_sim.onnx, read from
+                                                   // the weight file's RFEW v2 header at InitOrtEnv (rfe_get_hparams); 0.1 = published default
     long long extractor_timer = 0;
     long long matcher_timer = 0;
     std::vector<float> scales = {1.0f, 1.0f};
@@ -56,6 +57,8 @@ public:
             std::cerr << "[ERROR] rover_fe environment created failed : " << rfe_last_error(MatcherSession) << '\n';
             return EXIT_FAILURE;
         }
+        rfe_hparams hp;
+        if (rfe_get_hparams(MatcherSession, &hp) == RFE_OK) filter_threshold = hp.lg_filter_threshold;
         return EXIT_SUCCESS;
     }
 

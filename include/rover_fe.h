@@ -73,6 +73,35 @@ int64_t rfe_weight_count(int kind);
  * equal ids = shared copy. */
 uint64_t rfe_weights_id(rfe_ctx* ctx, int kind);
 
+/* ---- graph hyper-parameters (RFEW version 2; per ctx) ----
+ * The reference's two model files carry constants that never appear in its C++: the extractor takes K from the SHAPE of the
+ * `keypoints` output (src/Extractors/superpoint_onnx.cc:169-181) because max_num_keypoints, the detection threshold, the NMS
+ * radius and the border width are baked into onnxmodel/superpoint.onnx at export time (src/Extractors/SPextractor.cc:92-94),
+ * and the matcher reads whatever matches0 / mscores0 hold (src/Matchers/lightglue_onnx.cpp:404-409) because depth, heads and the
+ * in-graph filter threshold are baked into onnxmodel/lightglue_sim.onnx (lightglue_onnx.cpp:38).  rover-slam_amd/onnx_weights.py
+ * reads them from the graphs and writes them into the RFEW v2 header; rfe_load_weights applies them to the ctx.  Version-1 files
+ * and rfe_set_weights (bare blobs) leave the defaults below.
+ *   sp_max_keypoints / sp_detection_threshold / lg_filter_threshold are what a drop-in caller passes as Kmax / thr / filter_thr
+ *     (the C++ shims do exactly that); the entry points themselves keep taking them as arguments.
+ *   sp_nms_radius (1..8) and sp_remove_borders (0..64) act inside rfe_extract_* (simple_nms window 2r+1, border set to -1).
+ *   sp_topk_always: 0 = the published top_k_keypoints (score-descending order only when more than Kmax candidates pass, row-major
+ *     otherwise); 1 = exports that run torch.topk(scores, min(k, n)) unconditionally (TopK behind a Min in the graph): keypoints
+ *     always ordered by (score descending, pixel index ascending).
+ *   lg_layers / lg_heads describe the file; the kernels are built for 9 layers of 4 heads x 64 and rfe_set_hparams /
+ *     rfe_load_weights refuse anything else (RFE_ERR_INVALID / RFE_ERR_IO). */
+typedef struct rfe_hparams {
+    int32_t sp_max_keypoints;       /* default 1024 */
+    float sp_detection_threshold;   /* default 0.0005 */
+    int32_t sp_nms_radius;          /* default 4 */
+    int32_t sp_remove_borders;      /* default 4 */
+    int32_t sp_topk_always;         /* default 0 */
+    int32_t lg_layers;              /* 9 */
+    int32_t lg_heads;               /* 4 */
+    float lg_filter_threshold;      /* default 0.1 */
+} rfe_hparams;
+int rfe_get_hparams(rfe_ctx* ctx, rfe_hparams* out);
+int rfe_set_hparams(rfe_ctx* ctx, const rfe_hparams* in);
+
 /* ---- options (per ctx; the library never reads the environment) ----
  * RFE_OPT_LG_FOLD_WO (default 1): every LightGlue attention output projection (Wo, bo) is multiplied into the message
  *   half of the following ffn.0 Linear at load time (W1 [x | ctx Wo^T + bo] + b1 = [W1a | W1b Wo] [x | ctx] + (b1 + W1b bo),
@@ -258,6 +287,7 @@ int rfe_pool_has_rccl(rfe_pool* pool);           /* 1 = RCCL communicators are u
 int rfe_pool_set_weights(rfe_pool* pool, int kind, const float* blob, int64_t count);
 int rfe_pool_load_weights(rfe_pool* pool, const char* sp_path, const char* lg_path);
 int rfe_pool_set_option(rfe_pool* pool, int option, int value);
+int rfe_pool_set_hparams(rfe_pool* pool, const rfe_hparams* in);   /* every member; rfe_pool_load_weights applies a v2 file's values by itself */
 /* the sharding rule itself (pure function, no device): member `member` of n extracts frames [first_frame, first_frame + frames)
  * of an F-frame stream and owns `pairs` consecutive pairs starting at first_frame (frames = pairs + 1; 0 / 0 = idle member) */
 int rfe_pool_shard(int F, int n, int member, int* first_frame, int* frames, int* pairs);

@@ -68,6 +68,9 @@ def lib():
         L.rfo_superpoint.restype = C.c_int
         L.rfo_superpoint.argtypes = [fp, u8p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
                                      ip, fp, fp, fp, fp, fp, fp]
+        L.rfo_superpoint_ex.restype = C.c_int
+        L.rfo_superpoint_ex.argtypes = [fp, u8p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
+                                        ip, fp, fp, fp, fp, fp, fp]
         L.rfo_lightglue.restype = C.c_int
         L.rfo_lightglue.argtypes = [fp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_float, ip, fp, fp, fp, fp]
         L.rfo_normalize_keypoints.argtypes = [fp, C.c_int, C.c_int, C.c_int, fp]
@@ -162,7 +165,7 @@ def l2norm256(x):
     return out
 
 
-def superpoint(weights, img_u8, kmax=1024, thr=0.0005, nms_radius=4, border=4, debug=False):
+def superpoint(weights, img_u8, kmax=1024, thr=0.0005, nms_radius=4, border=4, debug=False, topk_always=False):
     """One frame.  Returns dict(n, kxy[Kmax,2] i32, score[Kmax], desc[Kmax,256] (+ debug taps))."""
     w, wp = _f(weights)
     assert w.size == sp_weight_count()
@@ -177,7 +180,7 @@ def superpoint(weights, img_u8, kmax=1024, thr=0.0005, nms_radius=4, border=4, d
         dbg = dict(scoremap=np.empty((Hs, Ws), np.float32), nms=np.empty((Hs, Ws), np.float32),
                    descmap=np.empty((H // 8, W // 8, 256), np.float32),
                    feat=np.empty((H // 8, W // 8, 128), np.float32))
-    n = lib().rfo_superpoint(wp, img.ctypes.data_as(C.POINTER(C.c_uint8)), H, W, kmax, thr, nms_radius, border,
+    n = lib().rfo_superpoint_ex(wp, img.ctypes.data_as(C.POINTER(C.c_uint8)), H, W, kmax, thr, nms_radius, border, int(topk_always),
                              kxy.ctypes.data_as(C.POINTER(C.c_int32)), _opt(score), _opt(desc),
                              _opt(dbg.get("scoremap")), _opt(dbg.get("nms")), _opt(dbg.get("descmap")),
                              _opt(dbg.get("feat")))

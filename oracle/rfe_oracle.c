@@ -253,6 +253,12 @@ static int cand_cmp(const void* a, const void* b) {
 int rfo_superpoint(const float* wts, const uint8_t* img, int H, int W, int Kmax, float thr,
                    int nms_radius, int border, int32_t* kxy, float* score, float* desc,
                    float* dbg_scoremap, float* dbg_nms, float* dbg_descmap, float* dbg_feat) {
+    return rfo_superpoint_ex(wts, img, H, W, Kmax, thr, nms_radius, border, 0, kxy, score, desc, dbg_scoremap, dbg_nms, dbg_descmap, dbg_feat);
+}
+
+int rfo_superpoint_ex(const float* wts, const uint8_t* img, int H, int W, int Kmax, float thr,
+                      int nms_radius, int border, int topk_always, int32_t* kxy, float* score, float* desc,
+                      float* dbg_scoremap, float* dbg_nms, float* dbg_descmap, float* dbg_feat) {
     /* Any H, W >= 8, like the ONNX graph (dynamic axes): the three 2x2/2 max-pools floor, so the feature grid is Hc x Wc =
      * floor(H/8) x floor(W/8) and everything after the heads lives on the Hs x Ws = 8Hc x 8Wc score map (= the image when H, W
      * are multiples of 8; e.g. KITTI 1241 x 376 -> 155 x 47 cells, score map 1240 x 376). */
@@ -302,7 +308,7 @@ int rfo_superpoint(const float* wts, const uint8_t* img, int H, int W, int Kmax,
     for (size_t i = 0; i < n0; ++i)
         if (nmap[i] > thr) { cand[nc].s = nmap[i]; cand[nc].idx = (int32_t)i; ++nc; }
     int n = nc;
-    if (nc > Kmax) { qsort(cand, nc, sizeof(cand_t), cand_cmp); n = Kmax; }
+    if (nc > Kmax || topk_always) { qsort(cand, nc, sizeof(cand_t), cand_cmp); n = nc < Kmax ? nc : Kmax; }
     for (int k = 0; k < Kmax; ++k) {
         if (k < n) {
             int x = cand[k].idx % W, y = cand[k].idx / W;

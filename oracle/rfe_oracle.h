@@ -58,6 +58,13 @@ int rfo_superpoint(const float* weights, const uint8_t* img, int H, int W, int K
                    float* dbg_scoremap /*[H,W] pre-NMS*/, float* dbg_nms /*[H,W] post-NMS,border*/,
                    float* dbg_descmap /*[Hc,Wc,256] normalised*/, float* dbg_feat /*[Hc,Wc,128] conv4b*/);
 
+/* The same with the selection rule of exports that apply top-k unconditionally (torch.topk(scores, min(k, n)): the TopK node sits
+ * behind a Min in the graph): topk_always != 0 orders the keypoints by (score descending, pixel index ascending) also when no more
+ * than Kmax candidates pass the threshold; 0 = the published top_k_keypoints (row-major order in that case) = rfo_superpoint. */
+int rfo_superpoint_ex(const float* weights, const uint8_t* img, int H, int W, int Kmax, float thr,
+                      int nms_radius, int border, int topk_always, int32_t* kxy, float* score, float* desc,
+                      float* dbg_scoremap, float* dbg_nms, float* dbg_descmap, float* dbg_feat);
+
 /* ---- LightGlue end to end (one pair) ----
  * k0n/k1n: normalised keypoints [M,2]/[N,2]; d0/d1: [M,256]/[N,256].
  * pairs: [min(M,N),2] (i,j) ascending i; ms: scores.  Returns S.

@@ -16,13 +16,13 @@ OPT_LG_FP16X2 = 2   # LightGlue Linears + attention of batched calls as split pr
 
 EXPORTS = [
     "rfe_init", "rfe_destroy", "rfe_last_error", "rfe_version", "rfe_load_weights", "rfe_set_weights",
-    "rfe_weight_count", "rfe_weights_id", "rfe_set_option", "rfe_get_option", "rfe_set_stream", "rfe_synchronize", "rfe_malloc", "rfe_free", "rfe_memcpy_h2d",
+    "rfe_weight_count", "rfe_weights_id", "rfe_get_hparams", "rfe_set_hparams", "rfe_set_option", "rfe_get_option", "rfe_set_stream", "rfe_synchronize", "rfe_malloc", "rfe_free", "rfe_memcpy_h2d",
     "rfe_memcpy_d2h", "rfe_extract_u8", "rfe_extract_u8_dev", "rfe_extract_u8_bin", "rfe_extract_u8_bin_dev", "rfe_match", "rfe_match_dev", "rfe_match_fused",
     "rfe_extract_match_stream_dev", "rfe_stereo_match", "rfe_stereo_match_dev", "rfe_stereo_frame_dev", "rfe_l2_distance_matrix", "rfe_binarize_descriptors",
     "rfe_search_candidates", "rfe_distinctive_descriptors",
     "rfe_l2_distance_matrix_dev", "rfe_binarize_descriptors_dev", "rfe_search_candidates_dev", "rfe_distinctive_descriptors_dev",
     "rfe_pool_create", "rfe_pool_destroy", "rfe_pool_last_error", "rfe_pool_size", "rfe_pool_ctx", "rfe_pool_has_rccl", "rfe_pool_set_weights",
-    "rfe_pool_load_weights", "rfe_pool_set_option", "rfe_pool_shard", "rfe_pool_extract_match_stream",
+    "rfe_pool_load_weights", "rfe_pool_set_option", "rfe_pool_set_hparams", "rfe_pool_shard", "rfe_pool_extract_match_stream",
     "rfe_profile_enable", "rfe_profile_filter", "rfe_profile_reset", "rfe_profile_read",
     "rfe_k_conv3x3", "rfe_k_linear", "rfe_k_scoremap", "rfe_k_lightglue_taps", "rfe_k_set_lightglue_tap", "rfe_k_lightglue_ffn", "rfe_k_attention",
 ]
@@ -46,6 +46,20 @@ lib.rfe_weight_count.argtypes = [C.c_int]
 lib.rfe_weight_count.restype = C.c_int64
 lib.rfe_weights_id.restype = C.c_uint64
 lib.rfe_weights_id.argtypes = [C.c_void_p, C.c_int]
+
+
+class HParams(C.Structure):
+    """include/rover_fe.h: rfe_hparams -- the constants baked into the reference's two .onnx graphs (RFEW v2 header)."""
+    _fields_ = [("sp_max_keypoints", C.c_int32), ("sp_detection_threshold", C.c_float), ("sp_nms_radius", C.c_int32),
+                ("sp_remove_borders", C.c_int32), ("sp_topk_always", C.c_int32), ("lg_layers", C.c_int32), ("lg_heads", C.c_int32), ("lg_filter_threshold", C.c_float)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+lib.rfe_get_hparams.argtypes = [C.c_void_p, C.POINTER(HParams)]
+lib.rfe_set_hparams.argtypes = [C.c_void_p, C.POINTER(HParams)]
+lib.rfe_pool_set_hparams.argtypes = [C.c_void_p, C.POINTER(HParams)]
 lib.rfe_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
 lib.rfe_get_option.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
 lib.rfe_set_stream.argtypes = [C.c_void_p, C.c_void_p]
@@ -291,6 +305,21 @@ class Context:
 
     def load_weights(self, sp_path=None, lg_path=None):
         self._chk(lib.rfe_load_weights(self.h, sp_path.encode() if sp_path else None, lg_path.encode() if lg_path else None))
+
+    def get_hparams(self):
+        h = HParams()
+        self._chk(lib.rfe_get_hparams(self.h, C.byref(h)))
+        return h.as_dict()
+
+    def set_hparams(self, **kw):
+        """Change some of the graph hyper-parameters (keys of rfe_hparams); the others keep their current values."""
+        h = HParams()
+        self._chk(lib.rfe_get_hparams(self.h, C.byref(h)))
+        for k, v in kw.items():
+            if not hasattr(h, k):
+                raise KeyError(k)
+            setattr(h, k, v)
+        self._chk(lib.rfe_set_hparams(self.h, C.byref(h)))
 
     def set_option(self, option, value):
         self._chk(lib.rfe_set_option(self.h, option, int(value)))

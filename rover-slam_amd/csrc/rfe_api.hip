@@ -399,6 +399,25 @@ extern "C" uint64_t rfe_weights_id(rfe_ctx* c, int kind) {
     return (uint64_t)(uintptr_t)p;
 }
 
+// RFEW container (rover-slam_amd/weights.py).  Both versions: "RFEW" | u32 version | u32 kind | u64 float count.
+//   version 1: the floats follow.
+//   version 2: u32 hp_bytes | hp_bytes of graph hyper-parameters | the floats.  Hyper-parameter block (little endian):
+//     kind 1 (SuperPoint): i32 max_keypoints, f32 detection_threshold, i32 nms_radius, i32 remove_borders, i32 topk_always   (20 bytes)
+//     kind 2 (LightGlue):  i32 layers, i32 heads, f32 filter_threshold                                     (12 bytes)
+//   A longer block (a later writer) is accepted, its known prefix used.
+static int check_hparams(rfe_ctx* c, const rfe_hparams& h, const char* who) {
+    if (h.sp_max_keypoints < 1 || h.sp_max_keypoints > 4096) return fail(c, RFE_ERR_INVALID, std::string(who) + ": sp_max_keypoints must be in 1..4096");
+    if (!(h.sp_detection_threshold >= 0.f) || !(h.sp_detection_threshold < 1.f)) return fail(c, RFE_ERR_INVALID, std::string(who) + ": sp_detection_threshold must be in [0, 1)");
+    if (h.sp_nms_radius < 1 || h.sp_nms_radius > NMS_MAX_RADIUS) return fail(c, RFE_ERR_INVALID, std::string(who) + ": sp_nms_radius must be in 1.." + std::to_string(NMS_MAX_RADIUS));
+    if (h.sp_remove_borders < 0 || h.sp_remove_borders > 64) return fail(c, RFE_ERR_INVALID, std::string(who) + ": sp_remove_borders must be in 0..64");
+    if (h.sp_topk_always != 0 && h.sp_topk_always != 1) return fail(c, RFE_ERR_INVALID, std::string(who) + ": sp_topk_always must be 0 or 1");
+    if (h.lg_layers != LG_LAYERS || h.lg_heads != 4)
+        return fail(c, RFE_ERR_INVALID, std::string(who) + ": the LightGlue kernels are built for 9 layers of 4 heads x 64, the file / caller says " +
+                                        std::to_string(h.lg_layers) + " layers of " + std::to_string(h.lg_heads) + " heads");
+    if (!(h.lg_filter_threshold >= 0.f) || !(h.lg_filter_threshold < 1.f)) return fail(c, RFE_ERR_INVALID, std::string(who) + ": lg_filter_threshold must be in [0, 1)");
+    return RFE_OK;
+}
+
 static int load_rfew(rfe_ctx* c, const char* path, int want_kind) {
     FILE* f = fopen(path, "rb");
     if (!f) return fail(c, RFE_ERR_IO, std::string("cannot open weight file ") + path);
@@ -406,12 +425,42 @@ static int load_rfew(rfe_ctx* c, const char* path, int want_kind) {
     if (fread(head, 1, 20, f) != 20 || memcmp(head, "RFEW", 4) != 0) { fclose(f); return fail(c, RFE_ERR_IO, std::string("not an RFEW file: ") + path); }
     uint32_t ver, kind; uint64_t cnt;
     memcpy(&ver, head + 4, 4); memcpy(&kind, head + 8, 4); memcpy(&cnt, head + 12, 8);
-    if (ver != 1 || (int)kind != want_kind || (int64_t)cnt != rfe_weight_count(want_kind)) { fclose(f); return fail(c, RFE_ERR_IO, std::string("RFEW header mismatch in ") + path); }
+    if ((ver != 1 && ver != 2) || (int)kind != want_kind || (int64_t)cnt != rfe_weight_count(want_kind)) { fclose(f); return fail(c, RFE_ERR_IO, std::string("RFEW header mismatch in ") + path); }
+    rfe_hparams hp = c->hp;
+    if (ver == 2) {
+        uint32_t hb = 0;
+        unsigned char blk[256];
+        const uint32_t need = want_kind == RFE_KIND_SUPERPOINT ? 20u : 12u;
+        if (fread(&hb, 4, 1, f) != 1 || hb < need || hb > sizeof(blk) || fread(blk, 1, hb, f) != hb) { fclose(f); return fail(c, RFE_ERR_IO, std::string("RFEW v2 hyper-parameter block damaged in ") + path); }
+        if (want_kind == RFE_KIND_SUPERPOINT) {
+            memcpy(&hp.sp_max_keypoints, blk, 4); memcpy(&hp.sp_detection_threshold, blk + 4, 4);
+            memcpy(&hp.sp_nms_radius, blk + 8, 4); memcpy(&hp.sp_remove_borders, blk + 12, 4); memcpy(&hp.sp_topk_always, blk + 16, 4);
+        } else {
+            memcpy(&hp.lg_layers, blk, 4); memcpy(&hp.lg_heads, blk + 4, 4); memcpy(&hp.lg_filter_threshold, blk + 8, 4);
+        }
+        const int rc = check_hparams(c, hp, path);
+        if (rc) { fclose(f); c->err = "RFEW v2 hyper-parameters refused: " + c->err; return RFE_ERR_IO; }
+    }
     std::vector<float> blob(cnt);
     size_t got = fread(blob.data(), sizeof(float), cnt, f);
     fclose(f);
     if (got != cnt) return fail(c, RFE_ERR_IO, std::string("short read on ") + path);
-    return rfe_set_weights(c, want_kind, blob.data(), (int64_t)cnt);
+    const int rc = rfe_set_weights(c, want_kind, blob.data(), (int64_t)cnt);
+    if (rc == RFE_OK) c->hp = hp;     // the file's hyper-parameters travel with its weights
+    return rc;
+}
+
+extern "C" int rfe_get_hparams(rfe_ctx* c, rfe_hparams* out) {
+    if (!c || !out) return RFE_ERR_INVALID;
+    *out = c->hp;
+    return RFE_OK;
+}
+extern "C" int rfe_set_hparams(rfe_ctx* c, const rfe_hparams* in) {
+    if (!c || !in) return RFE_ERR_INVALID;
+    const int rc = check_hparams(c, *in, "rfe_set_hparams");
+    if (rc) return rc;
+    c->hp = *in;
+    return RFE_OK;
 }
 
 extern "C" int rfe_load_weights(rfe_ctx* c, const char* sp_path, const char* lg_path) {
@@ -542,7 +591,7 @@ int sp_forward_maps(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, in
     { ProfScope p(c, "convPb"); launch_gemm_nt(s, gemm_plain(b.pa, 256, w.packed[L_PB], 256, w.bias[L_PB], b.logits, 65, cells, 65, 256)); }
     { ProfScope p(c, "sp_post");
       launch_softmax65_d2s(s, b.logits, 65, B, Hc, Wc, b.smap);
-      launch_nms(s, b.smap, B, 8 * Hc, 8 * Wc, 4, b.ss, b.mask, b.supp, b.nmap); }
+      launch_nms(s, b.smap, B, 8 * Hc, 8 * Wc, c->hp.sp_nms_radius, c->hp.sp_remove_borders, b.ss, b.mask, b.supp, b.nmap); }
     if (fork && join) RFE_HIP(c, hipStreamWaitEvent(s, c->ev_join, 0));
     forked = fork && !join;
     RFE_HIP(c, hipGetLastError());
@@ -557,7 +606,7 @@ int sp_forward(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, int B, 
     if (rc) return rc;
     const int Hc = H / 2 / 2 / 2, Wc = W / 2 / 2 / 2, Hs = 8 * Hc, Ws = 8 * Wc;   // score-map frame, see sp_forward_maps
     { ProfScope p(c, "sp_select");
-      launch_select(c->stream, b.nmap, B, Hs, Ws, Kmax, thr, b.cand_score, b.cand_idx, n, kxy, score, (int32_t*)b.ss /*NMS scratch, free by now*/);
+      launch_select(c->stream, b.nmap, B, Hs, Ws, Kmax, thr, b.cand_score, b.cand_idx, n, kxy, score, (int32_t*)b.ss /*NMS scratch, free by now*/, c->hp.sp_topk_always != 0);
       if (forked) RFE_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));   // descriptor map ready
       launch_desc_sample(c->stream, b.dmap, B, Hc, Wc, Hs, Ws, n, kxy, Kmax, desc, desc_bin); }
     RFE_HIP(c, hipGetLastError());

@@ -110,6 +110,7 @@ struct rfe_ctx {
     bool has_sp = false, has_lg = false;
     bool opt_lg_fold = true;             // RFE_OPT_LG_FOLD_WO
     bool opt_lg_fp16x2 = false;          // RFE_OPT_LG_FP16X2
+    rfe_hparams hp = {1024, 0.0005f, 4, 4, 0, rfe::LG_LAYERS, 4, 0.1f};   // graph hyper-parameters (RFEW v2 header / rfe_set_hparams)
     rfe::SpWeightsDev sp;                // views into *sp_hold / *lg_hold
     rfe::LgWeightsDev lg;
     std::shared_ptr<void> sp_hold, lg_hold;   // device copies, shared by every ctx of the process that loaded the same blob on the same device
@@ -180,11 +181,12 @@ void launch_split_f16(hipStream_t s, const float* x, uint16_t* hi, uint16_t* lo,
 int launch_gemm_nt(hipStream_t s, const GemmArgs& g);   // returns the number of partial-statistics pairs per row it wrote (0 without stats_out)
 // sp_post.hip
 void launch_softmax65_d2s(hipStream_t s, const float* logits, int ld, int B, int Hc, int Wc, float* score);
-void launch_nms(hipStream_t s, const float* score, int B, int H, int W, int border, float* tmp_ss,
+constexpr int NMS_MAX_RADIUS = 8;
+void launch_nms(hipStream_t s, const float* score, int B, int H, int W, int radius /*1..NMS_MAX_RADIUS*/, int border, float* tmp_ss,
                 uint8_t* tmp_mask, uint8_t* tmp_supp, float* out);
 void launch_select(hipStream_t s, const float* nms, int B, int H, int W, int Kmax, float thr,
                    float* cand_score, int32_t* cand_idx, int32_t* n_out, int32_t* kxy, float* score,
-                   int32_t* chunk_cnt /*B * ceil(H*W/4096) ints of scratch*/);
+                   int32_t* chunk_cnt /*B * ceil(H*W/4096) ints of scratch*/, bool topk_always = false /*rfe_hparams::sp_topk_always*/);
 void launch_descmap_norm(hipStream_t s, float* dmap, int64_t cells);
 void launch_desc_sample(hipStream_t s, const float* dmap, int B, int Hc, int Wc, int H, int W,
                         const int32_t* n, const int32_t* kxy, int Kmax, float* desc, uint8_t* desc_bin /*optional u8 [B,Kmax,256] = desc > 0*/);

@@ -285,6 +285,15 @@ extern "C" int rfe_pool_set_option(rfe_pool* p, int option, int value) {
     return RFE_OK;
 }
 
+extern "C" int rfe_pool_set_hparams(rfe_pool* p, const rfe_hparams* in) {
+    if (!p) return RFE_ERR_INVALID;
+    for (size_t r = 0; r < p->m.size(); ++r) {
+        const int rc = rfe_set_hparams(p->m[r].ctx, in);
+        if (rc) return pfail(p, rc, "member " + std::to_string(r) + ": " + rfe_last_error(p->m[r].ctx));
+    }
+    return RFE_OK;
+}
+
 extern "C" int rfe_pool_extract_match_stream(rfe_pool* p, const uint8_t* img, int H, int W, int stride, int F, int Kmax, float thr,
                                              float filter_thr, int transport, int32_t* n, int32_t* kxy, float* score, float* desc,
                                              int32_t* S, int32_t* pairs, float* ms) {

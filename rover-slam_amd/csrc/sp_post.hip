@@ -1,4 +1,4 @@
-// sp_post.hip -- the non-GEMM tail of SuperPoint: softmax(65)+depth-to-space, simple_nms(r=4),
+// sp_post.hip -- the non-GEMM tail of SuperPoint: softmax(65)+depth-to-space, simple_nms(r),
 // border/threshold/top-k selection, descriptor-map L2 normalisation and bilinear descriptor sampling.
 // In the reference all of this is inside superpoint.onnx (Ort::Session::Run,
 // src/Extractors/superpoint_onnx.cc:133-136); outputs follow the tensor contract read by
@@ -59,57 +59,72 @@ void launch_softmax65_d2s(hipStream_t s, const float* logits, int ld, int B, int
     hipLaunchKernelGGL(softmax65_d2s_kernel, dim3((total + 255) / 256), dim3(256), 0, s, logits, ld, total, Hc, Wc, score);
 }
 
-// ---------------------------------------------------------------- simple_nms (radius 4)
+// ---------------------------------------------------------------- simple_nms
 // published recurrence (SuperPoint / LightGlue):  max_mask = s == mp(s);
 //   2x { supp = mp(max_mask) > 0; ss = supp ? 0 : s; new = ss == mp(ss); max_mask |= new & ~supp }
-//   out = max_mask ? s : 0   then the 4-px border is set to -1.
-constexpr int NR = 4, NTH = 32, NTW = 64, NIH = NTH + 2 * NR, NIW = NTW + 2 * NR;
+//   out = max_mask ? s : 0   then the `border`-px frame is set to -1.
+// mp = max_pool2d(2 r + 1, stride 1, padding r).  The radius and the border are hyper-parameters of the reference's graph
+// (rfe_hparams: baked into superpoint.onnx at export time): CR = 4 is the compile-time instance of the published default,
+// CR = 0 takes the radius at run time (1..NMS_MAX_RADIUS, LDS tiles sized for the maximum).
+constexpr int NTH = 32, NTW = 64;
 
-template <typename LoadFn>
-__device__ __forceinline__ void tile_maxpool9(LoadFn load, int y0, int x0, int H, int W, float* t0, float* t1) {
+template <int CR, typename LoadFn>
+__device__ __forceinline__ void tile_maxpool(LoadFn load, int y0, int x0, int H, int W, int r, float* t0, float* t1) {
+    const int R = CR ? CR : r, NIH = NTH + 2 * R, NIW = NTW + 2 * R;
     for (int idx = threadIdx.x; idx < NIH * NIW; idx += 256) {
         const int py = idx / NIW, px = idx % NIW;
-        const int gy = y0 - NR + py, gx = x0 - NR + px;
+        const int gy = y0 - R + py, gx = x0 - R + px;
         t0[idx] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? load(gy, gx) : -INFINITY;
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < NIH * NTW; idx += 256) {
         const int py = idx / NTW, px = idx % NTW;
-        const float* r = t0 + py * NIW + px;
-        float m = r[0];
+        const float* rp = t0 + py * NIW + px;
+        float m = rp[0];
+        if (CR) {
 #pragma unroll
-        for (int d = 1; d <= 2 * NR; ++d) m = fmaxf(m, r[d]);
+            for (int d = 1; d <= 2 * CR; ++d) m = fmaxf(m, rp[d]);
+        } else {
+            for (int d = 1; d <= 2 * R; ++d) m = fmaxf(m, rp[d]);
+        }
         t1[idx] = m;
     }
     __syncthreads();
 }
-__device__ __forceinline__ float tile_colmax(const float* t1, int py, int px) {
+template <int CR>
+__device__ __forceinline__ float tile_colmax(const float* t1, int py, int px, int r) {
     const float* c = t1 + py * NTW + px;
     float m = c[0];
+    if (CR) {
 #pragma unroll
-    for (int d = 1; d <= 2 * NR; ++d) m = fmaxf(m, c[d * NTW]);
+        for (int d = 1; d <= 2 * CR; ++d) m = fmaxf(m, c[d * NTW]);
+    } else {
+        for (int d = 1; d <= 2 * r; ++d) m = fmaxf(m, c[d * NTW]);
+    }
     return m;
 }
 
 // MODE 0: mask = (s == mp(s))
 // MODE 1: supp = mp(mask) > 0 ; ss = supp ? 0 : s
 // MODE 2: mask |= (ss == mp(ss)) & ~supp ; FINAL: out = mask ? s : 0, border -> -1
-template <int MODE, bool FINAL>
+template <int MODE, bool FINAL, int CR>
 __global__ __launch_bounds__(256) void nms_pass_kernel(const float* __restrict__ s, float* __restrict__ ss,
                                                        uint8_t* __restrict__ mask, uint8_t* __restrict__ supp,
-                                                       float* __restrict__ out, int H, int W, int border) {
-    __shared__ float t0[NIH * NIW];
-    __shared__ float t1[NIH * NTW];
+                                                       float* __restrict__ out, int H, int W, int r, int border) {
+    constexpr int RM = CR ? CR : NMS_MAX_RADIUS;
+    __shared__ float t0[(NTH + 2 * RM) * (NTW + 2 * RM)];
+    __shared__ float t1[(NTH + 2 * RM) * NTW];
+    const int R = CR ? CR : r, NIW = NTW + 2 * R;
     const size_t fo = (size_t)blockIdx.z * H * W;
     const int y0 = blockIdx.y * NTH, x0 = blockIdx.x * NTW;
-    if (MODE == 0) tile_maxpool9([&](int y, int x) { return s[fo + (size_t)y * W + x]; }, y0, x0, H, W, t0, t1);
-    if (MODE == 1) tile_maxpool9([&](int y, int x) { return mask[fo + (size_t)y * W + x] ? 1.f : 0.f; }, y0, x0, H, W, t0, t1);
-    if (MODE == 2) tile_maxpool9([&](int y, int x) { return ss[fo + (size_t)y * W + x]; }, y0, x0, H, W, t0, t1);
+    if (MODE == 0) tile_maxpool<CR>([&](int y, int x) { return s[fo + (size_t)y * W + x]; }, y0, x0, H, W, r, t0, t1);
+    if (MODE == 1) tile_maxpool<CR>([&](int y, int x) { return mask[fo + (size_t)y * W + x] ? 1.f : 0.f; }, y0, x0, H, W, r, t0, t1);
+    if (MODE == 2) tile_maxpool<CR>([&](int y, int x) { return ss[fo + (size_t)y * W + x]; }, y0, x0, H, W, r, t0, t1);
     for (int idx = threadIdx.x; idx < NTH * NTW; idx += 256) {
         const int py = idx / NTW, px = idx % NTW;
         const int y = y0 + py, x = x0 + px;
         if (y >= H || x >= W) continue;
-        const float m = tile_colmax(t1, py, px);
+        const float m = tile_colmax<CR>(t1, py, px, r);
         const size_t o = fo + (size_t)y * W + x;
         if (MODE == 0) {
             mask[o] = (s[o] == m) ? 1 : 0;
@@ -118,7 +133,7 @@ __global__ __launch_bounds__(256) void nms_pass_kernel(const float* __restrict__
             supp[o] = sp ? 1 : 0;
             ss[o] = sp ? 0.f : s[o];
         } else {
-            const float c = t0[(py + NR) * NIW + px + NR];  // ss at this pixel
+            const float c = t0[(py + R) * NIW + px + R];  // ss at this pixel
             bool mk = mask[o] != 0;
             if (c == m && !supp[o]) mk = true;
             if (FINAL) {
@@ -132,14 +147,21 @@ __global__ __launch_bounds__(256) void nms_pass_kernel(const float* __restrict__
     }
 }
 
-void launch_nms(hipStream_t st, const float* score, int B, int H, int W, int border, float* tmp_ss,
-                uint8_t* tmp_mask, uint8_t* tmp_supp, float* out) {
+template <int CR>
+static void launch_nms_r(hipStream_t st, const float* score, int B, int H, int W, int r, int border, float* tmp_ss,
+                         uint8_t* tmp_mask, uint8_t* tmp_supp, float* out) {
     dim3 grid((W + NTW - 1) / NTW, (H + NTH - 1) / NTH, B), blk(256);
-    hipLaunchKernelGGL((nms_pass_kernel<0, false>), grid, blk, 0, st, score, tmp_ss, tmp_mask, tmp_supp, out, H, W, border);
-    hipLaunchKernelGGL((nms_pass_kernel<1, false>), grid, blk, 0, st, score, tmp_ss, tmp_mask, tmp_supp, out, H, W, border);
-    hipLaunchKernelGGL((nms_pass_kernel<2, false>), grid, blk, 0, st, score, tmp_ss, tmp_mask, tmp_supp, out, H, W, border);
-    hipLaunchKernelGGL((nms_pass_kernel<1, false>), grid, blk, 0, st, score, tmp_ss, tmp_mask, tmp_supp, out, H, W, border);
-    hipLaunchKernelGGL((nms_pass_kernel<2, true>), grid, blk, 0, st, score, tmp_ss, tmp_mask, tmp_supp, out, H, W, border);
+    hipLaunchKernelGGL((nms_pass_kernel<0, false, CR>), grid, blk, 0, st, score, tmp_ss, tmp_mask, tmp_supp, out, H, W, r, border);
+    hipLaunchKernelGGL((nms_pass_kernel<1, false, CR>), grid, blk, 0, st, score, tmp_ss, tmp_mask, tmp_supp, out, H, W, r, border);
+    hipLaunchKernelGGL((nms_pass_kernel<2, false, CR>), grid, blk, 0, st, score, tmp_ss, tmp_mask, tmp_supp, out, H, W, r, border);
+    hipLaunchKernelGGL((nms_pass_kernel<1, false, CR>), grid, blk, 0, st, score, tmp_ss, tmp_mask, tmp_supp, out, H, W, r, border);
+    hipLaunchKernelGGL((nms_pass_kernel<2, true, CR>), grid, blk, 0, st, score, tmp_ss, tmp_mask, tmp_supp, out, H, W, r, border);
+}
+
+void launch_nms(hipStream_t st, const float* score, int B, int H, int W, int radius, int border, float* tmp_ss,
+                uint8_t* tmp_mask, uint8_t* tmp_supp, float* out) {
+    if (radius == 4) launch_nms_r<4>(st, score, B, H, W, radius, border, tmp_ss, tmp_mask, tmp_supp, out);
+    else launch_nms_r<0>(st, score, B, H, W, radius, border, tmp_ss, tmp_mask, tmp_supp, out);
 }
 
 // ---------------------------------------------------------------- threshold + top-k selection
@@ -252,7 +274,7 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(const float* __restrict__
                                                        int P2, float thr, float* __restrict__ cand_score,
                                                        int32_t* __restrict__ cand_idx, int32_t* __restrict__ n_out,
                                                        int32_t* __restrict__ kxy, float* __restrict__ score,
-                                                       const int32_t* __restrict__ chunk_cnt, int nch) {
+                                                       const int32_t* __restrict__ chunk_cnt, int nch, int topk_always) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);  // [P2]
     __shared__ int wave_tot[SEL_T / 64];
@@ -271,7 +293,7 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(const float* __restrict__
 
     int32_t* okxy = kxy + (size_t)b * Kmax * 2;
     float* osc = score + (size_t)b * Kmax;
-    if (count <= Kmax) {
+    if (count <= Kmax && !topk_always) {     // published top_k_keypoints: nothing to cut -> row-major order
         if (tid == 0) n_out[b] = count;
         for (int k = tid; k < Kmax; k += SEL_T) {
             if (k < count) {
@@ -283,6 +305,14 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(const float* __restrict__
         }
         return;
     }
+    const int nsel = count < Kmax ? count : Kmax;
+    if (count <= Kmax) {
+        // topk_always (TopK behind Min(k, n) in the graph): every candidate is kept, ordered like the cut set below
+        for (int k = tid; k < P2; k += SEL_T)
+            keys[k] = k < count ? (((unsigned long long)__float_as_uint(cs[k]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)ci[k])) : 0ull;
+        for (int k = nsel + tid; k < Kmax; k += SEL_T) { okxy[2 * k] = 0; okxy[2 * k + 1] = 0; osc[k] = 0.f; }
+        __syncthreads();
+    } else {
     // ---- radix select: Kmax-th largest score (scores are positive floats: bit pattern is monotonic)
     if (tid == 0) { sh_prefix = 0u; sh_remaining = Kmax; }
     __syncthreads();
@@ -328,13 +358,14 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(const float* __restrict__
         eq_seen += tot_eq; sel_seen += tot_sel;
     }
     __syncthreads();
+    }
     // ---- rank sort, descending: keys are distinct (the pixel index is part of the key), so the number of larger keys
-    // is the output position.  Kmax broadcast LDS reads per key instead of the 55 barrier-separated bitonic stages.
-    if (tid == 0) n_out[b] = Kmax;
-    for (int t = tid; t < Kmax; t += SEL_T) {
+    // is the output position.  nsel broadcast LDS reads per key instead of the 55 barrier-separated bitonic stages.
+    if (tid == 0) n_out[b] = nsel;
+    for (int t = tid; t < nsel; t += SEL_T) {
         const unsigned long long key = keys[t];
         int rank = 0;
-        for (int j = 0; j < Kmax; ++j) rank += keys[j] > key ? 1 : 0;
+        for (int j = 0; j < nsel; ++j) rank += keys[j] > key ? 1 : 0;
         const int idx = (int)(0xFFFFFFFFu - (unsigned int)(key & 0xFFFFFFFFull));
         okxy[2 * rank] = idx % W; okxy[2 * rank + 1] = idx / W;
         osc[rank] = __uint_as_float((unsigned int)(key >> 32));
@@ -342,14 +373,14 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(const float* __restrict__
 }
 
 void launch_select(hipStream_t s, const float* nms, int B, int H, int W, int Kmax, float thr, float* cand_score,
-                   int32_t* cand_idx, int32_t* n_out, int32_t* kxy, float* score, int32_t* chunk_cnt) {
+                   int32_t* cand_idx, int32_t* n_out, int32_t* kxy, float* score, int32_t* chunk_cnt, bool topk_always) {
     int P2 = 1;
     while (P2 < Kmax) P2 <<= 1;
     const int HW = H * W, nch = (HW + SEL_CHUNK - 1) / SEL_CHUNK;   // chunk_cnt: B * nch ints of scratch
     hipLaunchKernelGGL(select_count_kernel, dim3(nch, B), dim3(256), 0, s, nms, HW, nch, thr, chunk_cnt);
     hipLaunchKernelGGL(select_compact_kernel, dim3(nch, B), dim3(256), 0, s, nms, HW, nch, thr, chunk_cnt, cand_score, cand_idx);
     hipLaunchKernelGGL(select_kernel, dim3(B), dim3(SEL_T), (size_t)P2 * 8, s, nms, H, W, Kmax, P2, thr,
-                       cand_score, cand_idx, n_out, kxy, score, chunk_cnt, nch);
+                       cand_score, cand_idx, n_out, kxy, score, chunk_cnt, nch, topk_always ? 1 : 0);
 }
 
 // ---------------------------------------------------------------- 256-d L2 normalisation

@@ -15,7 +15,10 @@ the first disagreement is reported with its position, the expected and the found
 `tests/test_onnx_weights.py` exercises reader and both mappings on ONNX files written by the test itself; when a real
 file deviates, `convert_*` raises and lists what it could not place.
 
-Only a protobuf *wire-format* reader is implemented (ModelProto.graph.{initializer,node}); external-data
+Besides the weights, the graph's baked-in hyper-parameters (max_num_keypoints, detection threshold, NMS radius, border; LightGlue
+depth, heads, filter threshold) are read from its nodes and written into the RFEW v2 header (`read_*_hparams`, `convert`, `main`).
+
+Only a protobuf *wire-format* reader is implemented (ModelProto.graph.{initializer,node} with node attributes); external-data
 tensors are not supported.
 """
 import struct
@@ -84,9 +87,9 @@ def _tensor(buf):
                 j, vv = 0, bytes(v)
                 while j < len(vv):
                     d, j = _varint(vv, j)
-                    int64s.append(d)
+                    int64s.append(d - (1 << 64) if d >= (1 << 63) else d)
             else:
-                int64s.append(v)
+                int64s.append(v - (1 << 64) if v >= (1 << 63) else v)
         elif fn == 13:
             raise ValueError(f"tensor {name!r}: external data is not supported")
     if dtype not in _DT:
@@ -102,8 +105,42 @@ def _tensor(buf):
     return name, arr.reshape(dims) if dims else arr
 
 
+def _attribute(buf):
+    """AttributeProto -> (name, value): i (int), f (float), s (str), t (ndarray), ints / floats (list).  Graph-valued attributes
+    (If / Loop bodies) come back as the marker string "<graph>": their presence is what matters here, not their content."""
+    name, val, ints, floats = "", None, [], []
+    for fn, wt, v in _fields(buf):
+        if fn == 1:
+            name = bytes(v).decode()
+        elif fn == 2 and wt == 5:
+            val = struct.unpack("<f", v)[0]
+        elif fn == 3 and wt == 0:
+            val = v - (1 << 64) if v >= (1 << 63) else v
+        elif fn == 4 and wt == 2:
+            val = bytes(v).decode(errors="replace")
+        elif fn == 5 and wt == 2:
+            val = _tensor(v)[1]
+        elif fn == 6 and wt == 2:
+            val = "<graph>"
+        elif fn == 7:     # floats
+            floats.extend(np.frombuffer(bytes(v), "<f4").tolist() if wt == 2 else [struct.unpack("<f", v)[0]])
+        elif fn == 8:     # ints
+            if wt == 2:
+                j, vv = 0, bytes(v)
+                while j < len(vv):
+                    d, j = _varint(vv, j)
+                    ints.append(d - (1 << 64) if d >= (1 << 63) else d)
+            else:
+                ints.append(v - (1 << 64) if v >= (1 << 63) else v)
+    if val is None and ints:
+        val = ints
+    if val is None and floats:
+        val = floats
+    return name, val
+
+
 def read_model(path):
-    """Returns (initializers: name -> ndarray, nodes: list of dict(op, inputs, outputs, name))."""
+    """Returns (initializers: name -> ndarray, nodes: list of dict(op, inputs, outputs, name, attrs))."""
     data = memoryview(open(path, "rb").read())
     inits, nodes = {}, []
     for fn, wt, v in _fields(data):
@@ -125,13 +162,8 @@ def read_model(path):
                         node["name"] = bytes(nv).decode()
                     elif nfn == 4:
                         node["op"] = bytes(nv).decode()
-                    elif nfn == 5 and nwt == 2:   # AttributeProto: integer attributes only (transB, axis ...)
-                        aname, aval = "", None
-                        for afn, awt, av in _fields(nv):
-                            if afn == 1:
-                                aname = bytes(av).decode()
-                            elif afn == 3 and awt == 0:
-                                aval = av
+                    elif nfn == 5 and nwt == 2:   # AttributeProto
+                        aname, aval = _attribute(nv)
                         if aval is not None:
                             node["attrs"][aname] = aval
                 nodes.append(node)
@@ -215,6 +247,279 @@ def _layernorms_in_order_of_use(inits, nodes, width=512):
                         seen.add(g[0])
                         out.append((inits[g[0]], inits[bb[0]]))
                         break
+    return out
+
+
+# ---------------------------------------------------------------- graph hyper-parameters
+# The reference's C++ holds NONE of these: K is the shape of the `keypoints` output (src/Extractors/superpoint_onnx.cc:169-181) and
+# matches0 / mscores0 arrive already filtered (src/Matchers/lightglue_onnx.cpp:404-409) because max_num_keypoints, the detection
+# threshold, the NMS radius, the border width, LightGlue's depth / heads / filter threshold are constants of the two graphs.  The
+# readers below recover them from the nodes a PyTorch export of the published modules produces (exercised on such exports in
+# tests/test_onnx_hparams.py; the real files are missing, .MISSING_LARGE_BLOBS:4-5).  Nothing is guessed: what cannot be read is
+# listed in `problems`, and convert / main refuse to write a weight file until the caller states the value explicitly (`assume`).
+_PASS_THROUGH = ("Cast", "Reshape", "Unsqueeze", "Squeeze", "Identity", "Flatten")
+
+
+def _graph_view(inits, nodes):
+    """constants (initializers + Constant nodes) and the producer of every tensor name"""
+    consts = dict(inits)
+    for n in nodes:
+        if n["op"] == "Constant" and n["outputs"]:
+            a = n["attrs"]
+            for key in ("value", "value_float", "value_int", "value_floats", "value_ints"):
+                if key in a and not isinstance(a[key], str):
+                    consts[n["outputs"][0]] = np.asarray(a[key])
+                    break
+    producer = {o: n for n in nodes for o in n["outputs"] if o}
+    return consts, producer
+
+
+def _const_of(name, consts, producer, depth=6):
+    """the constant a tensor name resolves to through shape-only pass-through ops, or None"""
+    while depth >= 0:
+        if name in consts:
+            return consts[name]
+        n = producer.get(name)
+        if n is None or n["op"] not in _PASS_THROUGH or not n["inputs"]:
+            return None
+        name, depth = n["inputs"][0], depth - 1
+    return None
+
+
+def _scalar(v):
+    if v is None:
+        return None
+    v = np.asarray(v)
+    return v.reshape(-1)[0].item() if v.size == 1 else None
+
+
+def _ancestors(name, producer, limit=400):
+    """nodes upstream of a tensor name (breadth first, bounded)"""
+    seen, out, todo = set(), [], [name]
+    while todo and len(out) < limit:
+        t = todo.pop(0)
+        n = producer.get(t)
+        if n is None or id(n) in seen:
+            continue
+        seen.add(id(n))
+        out.append(n)
+        todo.extend(i for i in n["inputs"] if i)
+    return out
+
+
+def read_superpoint_hparams(path):
+    """-> (hparams dict over weights.SP_HPARAMS keys, values None where unreadable; problems: list of str).
+    max_keypoints <- the k of TopK (through Min(k, n_candidates) / shape ops; a Min there means the top-k runs unconditionally:
+    topk_always = 1); detection_threshold <- the one positive constant a
+    Greater compares against (the suppression masks compare against 0); nms_radius <- kernel_shape / pads of the stride-1 MaxPools
+    (the published simple_nms has 1 + 2 x 2 of them); remove_borders <- the constant Slice bounds ([:b] / [-b:]) of the index
+    vectors the border ScatterNDs write -1 through; GridSample must be bilinear with align_corners = 1, zero padding."""
+    inits, nodes = read_model(path)
+    consts, producer = _graph_view(inits, nodes)
+    hp = {k: None for k in Wt.SP_HPARAMS}
+    problems = []
+    # ---- NMS radius
+    nms = []
+    for n in nodes:
+        if n["op"] != "MaxPool":
+            continue
+        ks, st = n["attrs"].get("kernel_shape"), n["attrs"].get("strides") or [1, 1]
+        if isinstance(ks, list) and len(ks) == 2 and list(st) == [1, 1]:
+            nms.append((tuple(ks), tuple(n["attrs"].get("pads") or [0, 0, 0, 0])))
+    if not nms:
+        problems.append("nms_radius: no stride-1 MaxPool in the graph (NMS not exported as max_pool2d?)")
+    else:
+        kinds = set(nms)
+        (kh, kw), pads = nms[0]
+        r = (kh - 1) // 2
+        if len(kinds) != 1 or kh != kw or kh % 2 == 0 or set(pads) != {r}:
+            problems.append(f"nms_radius: the stride-1 MaxPools disagree or are not (2r+1) windows padded by r: {sorted(kinds)}")
+        elif len(nms) != 5:
+            problems.append(f"nms_radius: {len(nms)} stride-1 MaxPools, the published simple_nms (2 suppression rounds) has 5 -- "
+                            "the kernels implement exactly that recurrence")
+        else:
+            hp["nms_radius"] = r
+    # ---- detection threshold
+    thr = set()
+    for n in nodes:
+        if n["op"] == "Greater" and len(n["inputs"]) == 2:
+            v = _scalar(_const_of(n["inputs"][1], consts, producer))
+            if isinstance(v, float) and 0.0 < v < 1.0:
+                thr.add(float(np.float32(v)))
+    if len(thr) == 1:
+        hp["detection_threshold"] = thr.pop()
+    else:
+        problems.append(f"detection_threshold: expected exactly one Greater(x, c) with 0 < c < 1, found constants {sorted(thr)}")
+    # ---- max_num_keypoints
+    topk = [n for n in nodes if n["op"] == "TopK"]
+    if len(topk) != 1:
+        problems.append(f"max_keypoints: {len(topk)} TopK nodes (an export without max_num_keypoints returns every candidate; "
+                        "the C ABI needs a capacity: state it with assume)")
+    else:
+        t = topk[0]
+        if t["attrs"].get("largest", 1) != 1:
+            problems.append("max_keypoints: TopK with largest = 0")
+        name, k = t["inputs"][1] if len(t["inputs"]) > 1 else "", None
+        for _ in range(8):                      # K input: constant, or Min(constant, dynamic count) behind shape ops
+            c = _scalar(_const_of(name, consts, producer))
+            if c is not None:
+                k = int(c)
+                break
+            n = producer.get(name)
+            if n is None:
+                break
+            if n["op"] == "Min":                # torch.topk(scores, min(k, n)): applied whatever the candidate count -> always sorted
+                cs = [_scalar(_const_of(i, consts, producer)) for i in n["inputs"]]
+                cs = [int(c) for c in cs if c is not None]
+                k = cs[0] if len(cs) == 1 else None
+                hp["topk_always"] = 1
+                break
+            if n["op"] in _PASS_THROUGH and n["inputs"]:
+                name = n["inputs"][0]
+            else:
+                break
+        if k is None or k < 1:
+            problems.append("max_keypoints: the K input of TopK does not resolve to a constant (or Min(constant, count))")
+        else:
+            hp["max_keypoints"] = k
+            if hp["topk_always"] is None:       # constant k (guarded by control flow upstream): the published top_k_keypoints
+                hp["topk_always"] = 0
+    # ---- border
+    pads, nscatter = set(), 0
+    for n in nodes:
+        if n["op"] != "ScatterND" or len(n["inputs"]) < 3:
+            continue
+        upd = _const_of(n["inputs"][2], consts, producer)
+        anc = _ancestors(n["inputs"][1], producer)
+        here = set()
+        for a in anc:
+            if a["op"] != "Slice" or len(a["inputs"]) < 3:
+                continue
+            src = producer.get(a["inputs"][0])
+            while src is not None and src["op"] in _PASS_THROUGH and src["inputs"]:
+                src = producer.get(src["inputs"][0])
+            if src is None or src["op"] != "Range":
+                continue                       # only slices of an index vector (arange(H) / arange(W)) describe the border
+            st, en = _scalar(_const_of(a["inputs"][1], consts, producer)), _scalar(_const_of(a["inputs"][2], consts, producer))
+            if st == 0 and en is not None and 0 < en <= 64:
+                here.add(int(en))
+            elif st is not None and -64 <= st < 0:
+                here.add(int(-st))
+        if here:
+            nscatter += 1
+            pads |= here
+            if upd is not None and np.asarray(upd).size and not np.all(np.asarray(upd) == -1):
+                problems.append("remove_borders: a border ScatterND writes something other than -1")
+    if nscatter == 0:
+        problems.append("remove_borders: no ScatterND over sliced index vectors found (border handled in another form, or not at all: "
+                        "state it with assume, 0 = no border)")
+    elif len(pads) != 1:
+        problems.append(f"remove_borders: the border slices disagree: {sorted(pads)}")
+    else:
+        hp["remove_borders"] = pads.pop()
+    # ---- descriptor sampling
+    gs = [n for n in nodes if n["op"] == "GridSample"]
+    if len(gs) != 1:
+        problems.append(f"grid_sample: {len(gs)} GridSample nodes (descriptor sampling exported in another form)")
+    else:
+        a = gs[0]["attrs"]
+        if a.get("mode", "bilinear") not in ("bilinear", "linear") or a.get("align_corners", 0) != 1 or a.get("padding_mode", "zeros") != "zeros":
+            problems.append(f"grid_sample: mode / align_corners / padding_mode = {a.get('mode', 'bilinear')} / {a.get('align_corners', 0)} / "
+                            f"{a.get('padding_mode', 'zeros')}; the kernels implement bilinear / 1 / zeros")
+    return hp, problems
+
+
+def read_lightglue_hparams(path):
+    """-> (hparams dict over weights.LG_HPARAMS keys, problems).  layers <- the `transformers.{i}.` parameter names or the number of
+    768 x 256 Linears; heads <- the head-split Reshape constants ([.., heads, 64(, 3)]); filter_threshold <- the one Greater(x, c)
+    with 0 < c < 1.  Control flow (If / Loop: early exit, point pruning) and per-layer confidence heads are reported as problems:
+    the kernels implement the fixed-depth graph."""
+    inits, nodes = read_model(path)
+    consts, producer = _graph_view(inits, nodes)
+    hp = {k: None for k in Wt.LG_HPARAMS}
+    problems = []
+    idx = {int(k.split(".")[1]) for k in inits if k.startswith("transformers.") and k.split(".")[1].isdigit()}
+    lins = _linears_in_order_of_use(inits, nodes)
+    # constant folding gives every APPLICATION of a Linear its own anonymous copy of the weight (one per image side): count contents
+    distinct = lambda shape: len({w.tobytes() for w, _, _ in lins if tuple(w.shape) == shape})
+    n_qkv = distinct((768, 256))
+    if idx:
+        hp["layers"] = max(idx) + 1
+        if n_qkv and n_qkv != hp["layers"]:
+            problems.append(f"layers: parameter names say {hp['layers']}, the graph holds {n_qkv} Wqkv (768 x 256) Linears")
+    elif n_qkv:
+        hp["layers"] = n_qkv
+    else:
+        problems.append("layers: neither `transformers.{i}.` names nor 768 x 256 Linears found")
+    heads = set()
+    for n in nodes:
+        if n["op"] != "Reshape" or len(n["inputs"]) < 2:
+            continue
+        shp = _const_of(n["inputs"][1], consts, producer)
+        if shp is None:                       # shape assembled from dynamic dims: Concat of constants and Gather(Shape) pieces
+            c = producer.get(n["inputs"][1])
+            if c is not None and c["op"] == "Concat":
+                parts = [_const_of(i, consts, producer) for i in c["inputs"]]
+                shp = np.concatenate([np.asarray(p).reshape(-1) if p is not None else np.array([-7]) for p in parts])
+        if shp is None:
+            continue
+        shp = [int(v) for v in np.asarray(shp).reshape(-1)]
+        if len(shp) >= 4 and shp[-1] == 3 and shp[-3] > 0 and shp[-2] in (64, -1):
+            heads.add(shp[-3])                 # Wqkv(x).unflatten(-1, (heads, -1, 3))
+        elif len(shp) >= 4 and shp[-1] == 64 and shp[-2] > 0:
+            heads.add(shp[-2])                 # to_qk / to_v: unflatten(-1, (heads, -1))
+    if len(heads) == 1:
+        hp["heads"] = heads.pop()
+    else:
+        problems.append(f"heads: head-split Reshape constants give {sorted(heads)}")
+    thr = set()
+    for n in nodes:
+        if n["op"] == "Greater" and len(n["inputs"]) == 2:
+            v = _scalar(_const_of(n["inputs"][1], consts, producer))
+            if isinstance(v, float) and 0.0 < v < 1.0:
+                thr.add(float(np.float32(v)))
+    if len(thr) == 1:
+        hp["filter_threshold"] = thr.pop()
+    else:
+        problems.append(f"filter_threshold: expected exactly one Greater(x, c) with 0 < c < 1, found constants {sorted(thr)}")
+    ctl = sorted({n["op"] for n in nodes if n["op"] in ("If", "Loop", "Scan")})
+    if ctl:
+        problems.append(f"control flow {ctl} in the graph (early exit / point pruning): only the fixed-depth export is implemented")
+    n_conf = distinct((1, 256))
+    if n_conf > 1:
+        problems.append(f"{n_conf} Linear(256 -> 1) heads: per-layer token-confidence heads of the early-exit graph are present "
+                        "(the fixed-depth export keeps the last matchability head only)")
+    return hp, problems
+
+
+def resolve_hparams(kind, read, problems, assume=None, path="<model>"):
+    """Merge what the graph says with what the caller states explicitly.  A value that could not be read AND is not assumed, a
+    stated value that contradicts a read one, or a structural problem (anything in `problems` not about an assumable key)
+    raises ValueError: a converted weight file never carries guessed hyper-parameters."""
+    assume = dict(assume or {})
+    keys = list(Wt.SP_HPARAMS if kind == 1 else Wt.LG_HPARAMS)
+    unknown = set(assume) - set(keys)
+    if unknown:
+        raise ValueError(f"assume: unknown hyper-parameter(s) {sorted(unknown)}; known: {keys}")
+    out, errors = {}, []
+    for k in keys:
+        if read.get(k) is not None and k in assume and float(assume[k]) != float(read[k]):
+            errors.append(f"{k}: the graph says {read[k]}, assume says {assume[k]}")
+        out[k] = read[k] if read.get(k) is not None else assume.get(k)
+    for pmsg in problems:
+        key = pmsg.split(":", 1)[0].strip()
+        if key in keys and out.get(key) is not None and read.get(key) is None:
+            continue                          # unreadable but stated by the caller
+        errors.append(pmsg)
+    if kind == 2 and not errors and (out["layers"] != Wt.LG_LAYERS or out["heads"] != 4):
+        errors.append(f"LightGlue with {out['layers']} layers of {out['heads']} heads: the kernels are built for {Wt.LG_LAYERS} layers of 4 heads x 64")
+    if kind == 1 and out.get("topk_always") is None and out.get("max_keypoints") is not None:
+        out["topk_always"] = 0
+        errors = [e for e in errors if not e.startswith("topk_always")]
+    if kind == 1 and not errors and not (1 <= out["nms_radius"] <= 8 and 0 <= out["remove_borders"] <= 64 and 1 <= out["max_keypoints"] <= 4096):
+        errors.append(f"SuperPoint hyper-parameters outside the library's range (radius 1..8, border 0..64, keypoints 1..4096): {out}")
+    if errors:
+        raise ValueError(f"{path}: graph hyper-parameters refused -- " + "; ".join(errors))
     return out
 
 
@@ -374,16 +679,42 @@ def _convert_lightglue_by_structure(path, inits, nodes, n_layers):
     return blob
 
 
+def convert(path, kind, assume=None):
+    """-> (blob, hparams): weights in the canonical layout AND the graph's hyper-parameters (resolve_hparams: refused when they cannot
+    be read and are not stated).  What `main` writes into an RFEW v2 container."""
+    if kind == 1:
+        hp = resolve_hparams(1, *read_superpoint_hparams(path), assume=assume, path=path)
+        return convert_superpoint(path), hp
+    hp = resolve_hparams(2, *read_lightglue_hparams(path), assume=assume, path=path)
+    return convert_lightglue(path), hp
+
+
+def _parse_assume(items):
+    out = {}
+    for it in items or []:
+        k, _, v = it.partition("=")
+        out[k.strip()] = float(v) if ("." in v or "e" in v.lower()) else int(v)
+    return out
+
+
 def main(argv=None):
     import argparse
-    ap = argparse.ArgumentParser(description="convert superpoint.onnx / lightglue_sim.onnx initializers to RFEW containers")
-    ap.add_argument("--superpoint"); ap.add_argument("--lightglue"); ap.add_argument("--out-dir", default=".")
-    a = ap.parse_args(argv)
     import os
-    if a.superpoint:
-        Wt.save(os.path.join(a.out_dir, "superpoint.rfew"), convert_superpoint(a.superpoint), 1)
-    if a.lightglue:
-        Wt.save(os.path.join(a.out_dir, "lightglue_sim.rfew"), convert_lightglue(a.lightglue), 2)
+    ap = argparse.ArgumentParser(description="convert superpoint.onnx / lightglue_sim.onnx to RFEW v2 containers: initializers -> canonical "
+                                             "weight blob, graph constants -> hyper-parameter header")
+    ap.add_argument("--superpoint"); ap.add_argument("--lightglue"); ap.add_argument("--out-dir", default=".")
+    ap.add_argument("--assume-sp", action="append", metavar="KEY=VALUE",
+                    help="state a SuperPoint hyper-parameter the graph does not reveal (max_keypoints, detection_threshold, nms_radius, remove_borders)")
+    ap.add_argument("--assume-lg", action="append", metavar="KEY=VALUE", help="the same for LightGlue (layers, heads, filter_threshold)")
+    a = ap.parse_args(argv)
+    for path, kind, name, assume in ((a.superpoint, 1, "superpoint.rfew", a.assume_sp), (a.lightglue, 2, "lightglue_sim.rfew", a.assume_lg)):
+        if not path:
+            continue
+        read, problems = (read_superpoint_hparams if kind == 1 else read_lightglue_hparams)(path)
+        print(f"{path}: hyper-parameters read from the graph: {read}" + (f"; unresolved: {problems}" if problems else ""))
+        blob, hp = convert(path, kind, _parse_assume(assume))
+        Wt.save(os.path.join(a.out_dir, name), blob, kind, hp)
+        print(f"  -> {os.path.join(a.out_dir, name)} (RFEW v2, {hp})")
 
 
 if __name__ == "__main__":

@@ -118,20 +118,54 @@ def make_lightglue(seed=11, proj_gain=6.0):
 
 _MAGIC = b"RFEW"
 
+# Graph hyper-parameters (include/rover_fe.h: rfe_hparams).  The reference's C++ never names them: they are constants inside its two
+# .onnx files (K is read from the output tensor's shape, src/Extractors/superpoint_onnx.cc:169-181; the match filter is applied in the
+# graph, src/Matchers/lightglue_onnx.cpp:404-409).  onnx_weights.py reads them from a graph; the RFEW v2 header carries them to
+# rfe_load_weights.  Defaults = the published LightGlue-style export settings.
+SP_HPARAMS = {"max_keypoints": 1024, "detection_threshold": 0.0005, "nms_radius": 4, "remove_borders": 4, "topk_always": 0}
+LG_HPARAMS = {"layers": LG_LAYERS, "heads": 4, "filter_threshold": 0.1}
 
-def save(path, blob, kind):
-    """kind: 1 = SuperPoint, 2 = LightGlue."""
+
+def pack_hparams(kind, hp=None):
+    d = dict(SP_HPARAMS if kind == 1 else LG_HPARAMS)
+    d.update(hp or {})
+    if kind == 1:
+        return struct.pack("<ifiii", int(d["max_keypoints"]), float(d["detection_threshold"]), int(d["nms_radius"]), int(d["remove_borders"]), int(d["topk_always"]))
+    return struct.pack("<iif", int(d["layers"]), int(d["heads"]), float(d["filter_threshold"]))
+
+
+def unpack_hparams(kind, blk):
+    if kind == 1:
+        k, t, r, b, a = struct.unpack_from("<ifiii", blk)
+        return {"max_keypoints": k, "detection_threshold": t, "nms_radius": r, "remove_borders": b, "topk_always": a}
+    l, h, t = struct.unpack_from("<iif", blk)
+    return {"layers": l, "heads": h, "filter_threshold": t}
+
+
+def save(path, blob, kind, hparams=None, version=2):
+    """kind: 1 = SuperPoint, 2 = LightGlue.  version 2 (default) carries the graph hyper-parameters (`hparams`: dict over the keys
+    of SP_HPARAMS / LG_HPARAMS, missing keys = defaults); version 1 is the bare container of earlier rounds (still loadable)."""
     blob = np.ascontiguousarray(blob, np.float32)
     with open(path, "wb") as f:
-        f.write(_MAGIC + struct.pack("<IIQ", 1, kind, blob.size))
+        f.write(_MAGIC + struct.pack("<IIQ", version, kind, blob.size))
+        if version == 2:
+            hb = pack_hparams(kind, hparams)
+            f.write(struct.pack("<I", len(hb)) + hb)
+        else:
+            assert version == 1 and not hparams, "hyper-parameters need an RFEW v2 container"
         f.write(blob.tobytes())
 
 
-def load(path):
+def load(path, with_hparams=False):
     with open(path, "rb") as f:
         head = f.read(20)
         assert head[:4] == _MAGIC, "not an RFEW file"
         ver, kind, cnt = struct.unpack("<IIQ", head[4:])
+        assert ver in (1, 2), f"unknown RFEW version {ver}"
+        hp = dict(SP_HPARAMS if kind == 1 else LG_HPARAMS)
+        if ver == 2:
+            (hb,) = struct.unpack("<I", f.read(4))
+            hp = unpack_hparams(kind, f.read(hb))
         blob = np.frombuffer(f.read(cnt * 4), np.float32).copy()
     assert blob.size == cnt
-    return blob, kind
+    return (blob, kind, hp) if with_hparams else (blob, kind)

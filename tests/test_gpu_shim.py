@@ -24,12 +24,13 @@ def test_cpp_shims_match_oracle(tmp_path, oracle, H, W):
                            "-L" + os.path.join(ROOT, "rover-slam_amd"), "-lrover_fe", "-L/opt/rocm/lib", "-lamdhip64",
                            "-Wl,-rpath," + os.path.join(ROOT, "rover-slam_amd"), "-Wl,-rpath,/opt/rocm/lib"])
     wsp, wlg = Wt.make_superpoint(seed=7), Wt.make_lightglue(seed=11)
-    Wt.save(str(tmp_path / "sp.rfew"), wsp, 1)
+    # the keypoint budget reaches the shims the way it reaches the reference: as a constant of the model file (RFEW v2 header), not as
+    # configuration (the reference reads K off the output tensor's shape, src/Extractors/superpoint_onnx.cc:169-181)
+    Wt.save(str(tmp_path / "sp.rfew"), wsp, 1, {"max_keypoints": 200})
     Wt.save(str(tmp_path / "lg.rfew"), wlg, 2)
     frames, _ = synth.make_frames(2, H, W, seed=42)
     frames.tofile(str(tmp_path / "frames.u8"))
-    env = dict(os.environ, RFE_SP_WEIGHTS=str(tmp_path / "sp.rfew"), RFE_LG_WEIGHTS=str(tmp_path / "lg.rfew"),
-               RFE_MAX_KEYPOINTS="200")
+    env = dict(os.environ, RFE_SP_WEIGHTS=str(tmp_path / "sp.rfew"), RFE_LG_WEIGHTS=str(tmp_path / "lg.rfew"))
     r = subprocess.run([exe, str(tmp_path / "frames.u8"), str(H), str(W), str(tmp_path / "out.bin")], env=env,
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr

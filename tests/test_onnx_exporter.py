@@ -25,8 +25,13 @@ from rover_slam_amd import onnx_weights as OW, weights as Wt  # noqa: E402
 def _serialise(model, args, input_names, output_names, fold, dynamic_axes=None):
     """ModelProto bytes from torch's own C++ serialiser, or skip when this torch build lacks the internals."""
     try:
+        import importlib
         from torch.onnx._internal.torchscript_exporter import utils as U
+        from torch.onnx._internal.torchscript_exporter._globals import GLOBALS
         from torch.onnx import OperatorExportTypes
+        for v in range(9, 18):      # the symbolic functions register on import: without opset >= 11 in-place slice assignment has no export
+            importlib.import_module(f"torch.onnx._internal.torchscript_exporter.symbolic_opset{v}")
+        GLOBALS.export_onnx_opset_version = 17
     except Exception as e:                                    # pragma: no cover
         pytest.skip(f"torch TorchScript ONNX exporter internals not available: {e}")
     with torch.no_grad():
@@ -190,8 +195,9 @@ class LightGluePublished(nn.Module):
     """Module tree / parameter names of the published LightGlue (input_proj = identity at 256-d SuperPoint descriptors); the fused
     export has no early exit, so only the last log_assignment head is live (the others never reach the file)."""
 
-    def __init__(self, n_layers=Wt.LG_LAYERS):
+    def __init__(self, n_layers=Wt.LG_LAYERS, filter_threshold=0.1):
         super().__init__()
+        self.filter_threshold = filter_threshold
         self.posenc = _PosEnc()
         self.transformers = nn.ModuleList([_Layer() for _ in range(n_layers)])
         self.log_assignment = nn.ModuleList([_Assign() for _ in range(n_layers)])
@@ -207,7 +213,7 @@ class LightGluePublished(nn.Module):
         idx = torch.arange(scores.shape[1])[None]
         mutual = m1.indices.gather(1, m0.indices) == idx
         ms = torch.where(mutual, m0.values.exp(), torch.zeros_like(m0.values))
-        valid = ms[0] > 0.1
+        valid = ms[0] > self.filter_threshold
         i = torch.nonzero(valid)[:, 0]
         return torch.stack([i, m0.indices[0][i]], -1), ms[0][i], d0, d1, scores
 

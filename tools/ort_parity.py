@@ -30,6 +30,8 @@ def main(argv=None):
     ap.add_argument("--frames", type=int, default=4)
     ap.add_argument("--gpu", action="store_true", help="also run librover_fe.so on cuda:0")
     ap.add_argument("--desc-tol", type=float, default=1e-4)
+    ap.add_argument("--assume-sp", action="append", metavar="KEY=VALUE", help="state a SuperPoint hyper-parameter the graph does not reveal")
+    ap.add_argument("--assume-lg", action="append", metavar="KEY=VALUE", help="the same for LightGlue")
     a = ap.parse_args(argv)
     try:
         import onnxruntime as ort
@@ -44,13 +46,22 @@ def main(argv=None):
     from oracle import oracle
     oracle.build()
     frames, _ = synth.make_frames(a.frames, 480, 640)
-    wsp = onnx_weights.convert_superpoint(a.superpoint)
+    # the graph's baked-in hyper-parameters first: a deviation below must be arithmetic, not a silently different K / radius / threshold
+    read, problems = onnx_weights.read_superpoint_hparams(a.superpoint)
+    print(f"{a.superpoint}: hyper-parameters read from the graph: {read}" + (f"; unresolved: {problems}" if problems else ""))
+    try:
+        wsp, hp = onnx_weights.convert(a.superpoint, 1, onnx_weights._parse_assume(a.assume_sp))
+    except ValueError as e:
+        print(f"ort_parity: {e}\n  (state what the graph does not reveal with --assume-sp KEY=VALUE)", file=sys.stderr)
+        return 2
     sp = ort.InferenceSession(a.superpoint, providers=["CPUExecutionProvider"])
     ctx = None
     if a.gpu:
         from rover_slam_amd import capi
         ctx = capi.Context(0)
         ctx.set_weights(capi.KIND_SUPERPOINT, wsp)
+        ctx.set_hparams(sp_max_keypoints=hp["max_keypoints"], sp_detection_threshold=hp["detection_threshold"], sp_nms_radius=hp["nms_radius"],
+                        sp_remove_borders=hp["remove_borders"], sp_topk_always=hp["topk_always"])
     bad = False
     feats = []
     for i, img in enumerate(frames):
@@ -58,10 +69,11 @@ def main(argv=None):
         k_ref, s_ref, d_ref = sp.run(["keypoints", "scores", "descriptors"], {"image": x})
         k_ref, s_ref, d_ref = k_ref[0].astype(np.int64), s_ref[0], d_ref[0]
         K = k_ref.shape[0]
-        o = oracle.superpoint(wsp, img, kmax=max(K, 1))
+        o = oracle.superpoint(wsp, img, kmax=hp["max_keypoints"], thr=hp["detection_threshold"], nms_radius=hp["nms_radius"],
+                              border=hp["remove_borders"], topk_always=bool(hp["topk_always"]))
         cands = [("oracle", o["n"], o["kxy"], o["score"], o["desc"])]
         if ctx is not None:
-            n, kxy, sc, de = ctx.extract(img[None], kmax=max(K, 1))
+            n, kxy, sc, de = ctx.extract(img[None], kmax=hp["max_keypoints"], thr=hp["detection_threshold"])
             cands.append(("hip", int(n[0]), kxy[0], sc[0], de[0]))
         for name, n, kxy, sc, de in cands:
             ref = {(int(x_), int(y_)): j for j, (x_, y_) in enumerate(k_ref)}
@@ -75,7 +87,13 @@ def main(argv=None):
             bad |= (not same) or dd > a.desc_tol
         feats.append((k_ref, d_ref))
     if a.lightglue:
-        wlg = onnx_weights.convert_lightglue(a.lightglue)
+        read, problems = onnx_weights.read_lightglue_hparams(a.lightglue)
+        print(f"{a.lightglue}: hyper-parameters read from the graph: {read}" + (f"; unresolved: {problems}" if problems else ""))
+        try:
+            wlg, hpl = onnx_weights.convert(a.lightglue, 2, onnx_weights._parse_assume(a.assume_lg))
+        except ValueError as e:
+            print(f"ort_parity: {e}\n  (state what the graph does not reveal with --assume-lg KEY=VALUE)", file=sys.stderr)
+            return 2
         lg = ort.InferenceSession(a.lightglue, providers=["CPUExecutionProvider"])
         if ctx is not None:
             ctx.set_weights(capi.KIND_LIGHTGLUE, wlg)
@@ -84,10 +102,10 @@ def main(argv=None):
             k0n = oracle.normalize_keypoints(k0.astype(np.float32), 480, 640)   # NormalizeKeypoints, transform.cpp:19-32
             k1n = oracle.normalize_keypoints(k1.astype(np.float32), 480, 640)
             m_ref, ms_ref = lg.run(["matches0", "mscores0"], {"kpts0": k0n[None], "kpts1": k1n[None], "desc0": d0[None], "desc1": d1[None]})
-            o = oracle.lightglue(wlg, k0n, k1n, d0, d1)
+            o = oracle.lightglue(wlg, k0n, k1n, d0, d1, filter_thr=hpl["filter_threshold"])
             cands = [("oracle", o["pairs"], o["ms"])]
             if ctx is not None:
-                S, pairs, ms = ctx.match(k0n[None], k1n[None], d0[None], d1[None], [len(k0n)], [len(k1n)])
+                S, pairs, ms = ctx.match(k0n[None], k1n[None], d0[None], d1[None], [len(k0n)], [len(k1n)], filter_thr=hpl["filter_threshold"])
                 cands.append(("hip", pairs[0, :S[0]], ms[0, :S[0]]))
             for name, pairs, ms in cands:
                 same = pairs.shape == m_ref.shape and np.array_equal(pairs, m_ref)
