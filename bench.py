@@ -278,13 +278,10 @@ def cpu_baseline(frames, wsp, wlg, gpu=None):
                       f"cgroup quota applied), {dt:.1f} s; {nf - 1} frames counted"}
 
 
-def bench_stereo_stream(args, ctx, capi, synth, torch, dev, rank):
-    """BASELINE configs[4] (SURVEY C5): a 752x480 stereo stream through ONE device-resident entry point per stereo frame,
-    rfe_stereo_frame_dev: both views through SuperPoint as a batch of 2 (src/Frame.cc:142-147), Frame::ComputeStereoMatches
-    (src/Frame.cc:1159-1446) and one LightGlue match of the left view against the previous left view
-    (SPmatcher.cc:1050-1080).  Nothing crosses PCIe inside the loop.  Latency figure, not the metric's workload."""
-    Hs, Ws, K = 480, 752, args.kmax
-    T = 8                                                     # distinct stereo frames, cycled
+def stereo_frames(synth, T=8):
+    """T synthetic 752x480 stereo pairs (EuRoC size): one scene, the right view shifted by a 24-px disparity, the camera moving 8 px
+    per frame.  -> (lefts, rights): lists of u8 [480,752]"""
+    Hs, Ws = 480, 752
     rng = np.random.default_rng(5)
     scene = synth.make_scene(rng, Hs, Ws + 64 + 8 * T, margin=0)
     lefts, rights = [], []
@@ -293,6 +290,17 @@ def bench_stereo_stream(args, ctx, capi, synth, torch, dev, rank):
         x0 = 8 * t
         lefts.append(np.clip(scene[:, x0:x0 + Ws] + rng.integers(0, 8, (Hs, Ws)), 0, 255).astype(np.uint8))
         rights.append(np.clip(scene[:, x0 + disp:x0 + disp + Ws] + rng.integers(0, 8, (Hs, Ws)), 0, 255).astype(np.uint8))
+    return lefts, rights
+
+
+def run_stereo_stream(ctx, capi, synth, torch, dev, kmax, steps, warmup, with_stages=True):
+    """BASELINE configs[4] (SURVEY C5): a 752x480 stereo stream through ONE device-resident entry point per stereo frame,
+    rfe_stereo_frame_dev: both views through SuperPoint as a batch of 2 (src/Frame.cc:142-147), Frame::ComputeStereoMatches
+    (src/Frame.cc:1159-1446) and one LightGlue match of the left view against the previous left view
+    (SPmatcher.cc:1050-1080).  Nothing crosses PCIe inside the loop.  Latency figure, not the metric's workload."""
+    Hs, Ws, K = 480, 752, kmax
+    T = 8                                                     # distinct stereo frames, cycled
+    lefts, rights = stereo_frames(synth, T)
     imgs = torch.from_numpy(np.stack([np.stack([l, r]) for l, r in zip(lefts, rights)])).to(dev)      # [T,2,H,W]
     st = capi.StereoStream(ctx, Hs, Ws, K, mb=0.11, mbf=0.11 * 435.0)
 
@@ -300,32 +308,159 @@ def bench_stereo_stream(args, ctx, capi, synth, torch, dev, rank):
         im = imgs[t % T]
         st.push(im[0].data_ptr(), im[1].data_ptr(), Ws)
 
-    for t in range(args.warmup + 1):
+    for t in range(warmup + 1):
         step(t)
     torch.cuda.synchronize(dev)
-    ctx.profile(True); ctx.profile_reset()
-    t0 = time.perf_counter()
-    for t in range(args.steps):
-        step(args.warmup + 1 + t)
-    torch.cuda.synchronize(dev)
-    dt_prof = time.perf_counter() - t0
-    prof = ctx.profile_read(); ctx.profile(False)
-    torch.cuda.synchronize(dev)
+    prof, dt_prof = {}, None
+    if with_stages:
+        ctx.profile(True); ctx.profile_reset()
+        t0 = time.perf_counter()
+        for t in range(steps):
+            step(warmup + 1 + t)
+        torch.cuda.synchronize(dev)
+        dt_prof = time.perf_counter() - t0
+        prof = ctx.profile_read(); ctx.profile(False)
+        torch.cuda.synchronize(dev)
     t0 = time.perf_counter()                                   # headline: the same loop without the per-stage events
-    for t in range(args.steps):
-        step(args.warmup + 1 + args.steps + t)
+    for t in range(steps):
+        step(warmup + 1 + steps + t)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     res = st.results()
-    if rank == 0:
-        print(json.dumps({"metric": "BASELINE configs[4] stereo 752x480 stream, latency run", "value": round(args.steps / dt, 2),
-                          "unit": "stereo frames/s", "ms_per_step": round(dt / args.steps * 1e3, 4), "n_gpus": 1,
-                          "steps": args.steps, "warmup": args.warmup, "kmax": K, "left_keypoints": int(res["n"][0]),
-                          "stereo_matches": int((res["u_right"][:int(res["n"][0])] >= 0).sum()), "temporal_matches": int(res["S"]),
-                          "entry_point": "rfe_stereo_frame_dev (no host synchronisation inside the loop)",
-                          "ms_per_step_with_stage_events": round(dt_prof / args.steps * 1e3, 4),
-                          "stages_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}))
     st.close()
+    out = {"metric": "BASELINE configs[4] stereo 752x480 stream, latency run", "value": round(steps / dt, 2),
+           "unit": "stereo frames/s", "ms_per_step": round(dt / steps * 1e3, 4), "n_gpus": 1,
+           "steps": steps, "warmup": warmup, "kmax": K, "left_keypoints": int(res["n"][0]),
+           "stereo_matches": int((res["u_right"][:int(res["n"][0])] >= 0).sum()), "temporal_matches": int(res["S"]),
+           "entry_point": "rfe_stereo_frame_dev (no host synchronisation inside the loop)"}
+    if with_stages:
+        out["ms_per_step_with_stage_events"] = round(dt_prof / steps * 1e3, 4)
+        out["stages_ms_per_step"] = {k: round(v[0] / steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+    return out
+
+
+def bench_stereo_stream(args, ctx, capi, synth, torch, dev, rank):
+    out = run_stereo_stream(ctx, capi, synth, torch, dev, args.kmax, args.steps, args.warmup)
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def latency_resident(ctx, capi, synth, sharding, torch, dev, frames, steps=50, warmup=5):
+    """`latency.resident` of the bench line: BASELINE configs[1] / [2] / [4] -- the shapes the reference itself runs (batch 1,
+    src/Extractors/superpoint_onnx.cc:100, src/Matchers/lightglue_onnx.cpp:168-172) -- device-resident, `steps` calls each, no
+    per-stage events, wall clock between two device synchronisations.  `frames`: the first two frames of the bench stream (device)."""
+    pack = sharding.ResultPack(2, KMAX, dev)
+    a = (pack.n.data_ptr(), pack.kxy.data_ptr(), pack.score.data_ptr(), pack.desc.data_ptr())
+
+    def c2():
+        ctx._chk(capi.lib.rfe_extract_u8_dev(ctx.h, frames.data_ptr(), H, W, W, 1, KMAX, 0.0005, *a))
+
+    def c3():
+        ctx._chk(capi.lib.rfe_extract_match_stream_dev(ctx.h, frames.data_ptr(), H, W, W, 2, KMAX, 0.0005, 0.1, *a, pack.S.data_ptr(),
+                                                       pack.pairs.data_ptr(), pack.ms.data_ptr()))
+    out = {}
+    for name, fn, what in (("c2", c2, "configs[1]: SuperPoint, one 640x480 frame, rfe_extract_u8_dev"),
+                           ("c3", c3, "configs[2]: one 640x480 pair = 2 extractions + 1 LightGlue match (K <= 1024), rfe_extract_match_stream_dev B = 2")):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize(dev)
+        out[name] = {"ms": round((time.perf_counter() - t0) / steps * 1e3, 4), "steps": steps, "what": what}
+    out["c2"]["keypoints"] = int(pack.n[0].item())
+    out["c3"]["matches"] = int(pack.S[0].item())
+    r5 = run_stereo_stream(ctx, capi, synth, torch, dev, KMAX, steps, warmup, with_stages=False)
+    out["c5"] = {"ms": r5["ms_per_step"], "steps": steps, "stereo_matches": r5["stereo_matches"], "temporal_matches": r5["temporal_matches"],
+                 "what": "configs[4]: one 752x480 stereo frame = batch-of-2 extraction + ComputeStereoMatches + 1 LightGlue match against the "
+                         "previous left view, rfe_stereo_frame_dev"}
+    return out
+
+
+def latency_dropin(synth, wsp, wlg, pair_np, steps=50, warmup=5, check=True):
+    """`latency.dropin`: the same three configurations through the C++ drop-in classes with HOST pointers in and out -- what a
+    Rover-SLAM Tracking thread sees (SPextractor::operator(), src/Extractors/SPextractor.cc:516-617; SPmatcher::MatchingPoints_onnx(Frame&,
+    Frame&), src/Matchers/SPmatcher.cc:457-542; stereo pair of extractor threads, src/Frame.cc:142-147) -- timed by a compiled driver
+    (tests/cpp/lat_driver.cpp -> rover-slam_amd/lat_driver, built by __graft_entry__.build()) in a CHILD process, its last results
+    checked once against the oracle."""
+    import tempfile
+    from rover_slam_amd import weights as Wt
+    exe = os.path.join(ROOT, "rover-slam_amd", "lat_driver")
+    if not os.path.exists(exe):
+        return {"error": f"{exe} missing (python -c 'import __graft_entry__ as g; g.build()')"}
+    T = 8
+    lefts, rights = stereo_frames(synth, T)
+    with tempfile.TemporaryDirectory() as d:
+        Wt.save(os.path.join(d, "sp.rfew"), wsp, 1)
+        Wt.save(os.path.join(d, "lg.rfew"), wlg, 2)
+        np.ascontiguousarray(pair_np[:2]).tofile(os.path.join(d, "pair.u8"))
+        np.stack([np.stack([l, r]) for l, r in zip(lefts, rights)]).tofile(os.path.join(d, "stereo.u8"))
+        env = dict(os.environ, RFE_SP_WEIGHTS=os.path.join(d, "sp.rfew"), RFE_LG_WEIGHTS=os.path.join(d, "lg.rfew"))
+        r = subprocess.run([exe, os.path.join(d, "pair.u8"), os.path.join(d, "stereo.u8"), str(T), str(steps), str(warmup), os.path.join(d, "out.bin")],
+                           env=env, capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:
+            return {"error": f"lat_driver exit {r.returncode}: {(r.stdout + r.stderr)[-300:]}"}
+        out = json.loads(r.stdout.strip().splitlines()[-1])
+        buf = open(os.path.join(d, "out.bin"), "rb").read()
+    out["driver"] = ("tests/cpp/lat_driver.cpp (child process): SPextractor::operator() / SPmatcher::MatchingPoints_onnx(Frame&, Frame&) / left + right "
+                     "extractor threads + ComputeStereoMatches_rfe + MatchingPoints_onnx(current, previous); pageable host memory in and out on every call")
+    if not check:
+        return out
+    # ---- the driver's last results against the oracle (once)
+    from oracle import oracle as O
+    from tolerances import lists_agree_borderline
+    off = 0
+
+    def take_frame():
+        nonlocal off
+        n = int(np.frombuffer(buf, np.int32, 1, off)[0]); off += 4
+        kp = np.frombuffer(buf, np.float32, n * 3, off).reshape(n, 3); off += n * 12
+        de = np.frombuffer(buf, np.float32, n * 256, off).reshape(n, 256); off += n * 1024
+        return n, kp, de
+
+    def take_ints(k):
+        nonlocal off
+        v = np.frombuffer(buf, np.int32, k, off); off += 4 * k
+        return v
+
+    def sp_ok(fr, img):
+        n, kp, de = fr
+        o = O.superpoint(wsp, img, kmax=KMAX)
+        return bool(n == o["n"] and np.array_equal(kp[:, :2], o["kxy"][:n].astype(np.float32)) and np.array_equal(kp[:, 2], o["score"][:n])
+                    and np.array_equal(de, o["desc"][:n])), o
+
+    def lg_ok(vn, s, oa, ob, rows, cols):
+        lg = O.lightglue(wlg, O.normalize_keypoints(oa["kxy"][:oa["n"]].astype(np.float32), rows, cols),
+                         O.normalize_keypoints(ob["kxy"][:ob["n"]].astype(np.float32), rows, cols), oa["desc"][:oa["n"]], ob["desc"][:ob["n"]], debug=True)
+        sref = {(int(i), int(j)): float(m) for (i, j), m in zip(lg["pairs"], lg["ms"])}
+        got = [(i, int(j)) for i, j in enumerate(vn) if j >= 0]
+        ok, _, only = lists_agree_borderline(np.array(got).reshape(-1, 2), [sref.get(k, 0.0) for k in got], lg["pairs"], lg["ms"], lg["scores"], KMAX)
+        return bool(ok and s == len(got)), only, lg["S"]
+
+    f0, f1 = take_frame(), take_frame()
+    s3, m = take_ints(2)
+    vn = take_ints(int(m))
+    ok0, o0 = sp_ok(f0, pair_np[0]); ok1, o1 = sp_ok(f1, pair_np[1])
+    okm, only3, S3 = lg_ok(vn, int(s3), o0, o1, H, W)
+    tcur, tprev = take_ints(2)
+    fl, fr_, fp = take_frame(), take_frame(), take_frame()
+    (m,) = take_ints(1)
+    u_right = np.frombuffer(buf, np.float32, int(m), off); off += 4 * int(m)
+    depth = np.frombuffer(buf, np.float32, int(m), off); off += 4 * int(m)
+    s5, m = take_ints(2)
+    vt = take_ints(int(m))
+    okl, ol = sp_ok(fl, lefts[int(tcur)]); okr, orr = sp_ok(fr_, rights[int(tcur)]); okp, op_ = sp_ok(fp, lefts[int(tprev)])
+    u_ref, z_ref = O.stereo_match(lefts[int(tcur)], rights[int(tcur)], ol["kxy"][:ol["n"]].astype(np.float32), orr["kxy"][:orr["n"]].astype(np.float32),
+                                  ol["desc"][:ol["n"]], orr["desc"][:orr["n"]], 0.11, 0.11 * 435.0)
+    oks = bool(np.array_equal(u_right, u_ref) and np.array_equal(depth, z_ref))
+    okt, only5, S5 = lg_ok(vt, int(s5), ol, op_, 480, 752)
+    out["verified_against_oracle"] = {"ok": bool(ok0 and ok1 and okm and okl and okr and okp and oks and okt),
+                                      "c3_superpoint_bit_exact": bool(ok0 and ok1), "c3_match_list_agrees": okm, "c3_matches_oracle": int(S3),
+                                      "c3_one_sided_borderline": int(only3), "c5_superpoint_bit_exact": bool(okl and okr and okp),
+                                      "c5_stereo_matches_bit_exact": oks, "c5_temporal_match_list_agrees": okt, "c5_matches_oracle": int(S5),
+                                      "c5_one_sided_borderline": int(only5)}
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -430,6 +565,9 @@ def main():
     ap.add_argument("--no-variants", action="store_true", help="skip the short Kmax = 256 / 512 and K < Kmax (dustbin weights) runs of SURVEY 8(d) (N=1)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the short PCIe-inclusive measurement (N=1)")
     ap.add_argument("--no-pool", action="store_true", help="skip the short run through the C-ABI pool (rfe_pool_*, N=1)")
+    ap.add_argument("--no-latency", action="store_true",
+                    help="skip the `latency` object: BASELINE configs[1] / [2] / [4] device-resident and through the C++ drop-in classes (N=1)")
+    ap.add_argument("--latency-steps", type=int, default=50)
     ap.add_argument("--gather-desc", action="store_true", help="also gather scores and the 256-d descriptors to rank 0")
     ap.add_argument("--lg-fold", type=int, default=None, choices=[0, 1], help="override RFE_OPT_LG_FOLD_WO (default: the library's)")
     ap.add_argument("--lg-fp16x2", type=int, default=0, choices=[0, 1],
@@ -656,103 +794,116 @@ def main():
     fp16x2_out = None
     if world == 1 and not args.no_variants and args.workload == "c4" and not args.lg_fp16x2:
         variants = {}
-
-        def run_variant(kmax, tag, note):
-            vp = sharding.ResultPack(B, kmax, dev)
-            def vstep():
-                ctx._chk(capi.lib.rfe_extract_match_stream_dev(
-                    ctx.h, frames.data_ptr(), H, W, W, B, kmax, 0.0005, 0.1, vp.n.data_ptr(), vp.kxy.data_ptr(), vp.score.data_ptr(),
-                    vp.desc.data_ptr(), vp.S.data_ptr(), vp.pairs.data_ptr(), vp.ms.data_ptr()))
-            for _ in range(2):
-                vstep()
-            fence()
-            t1 = time.perf_counter()
-            nst = max(3, min(args.steps, 10))
-            for _ in range(nst):
-                vstep()
-            fence()
-            dtv = time.perf_counter() - t1
-            kk = vp.n.cpu().numpy()
-            variants[tag] = {"value": round(FRAMES_PER_GPU * nst / dtv, 2), "unit": "frames/s", "kmax": kmax, "steps": nst,
-                             "ms_per_step": round(dtv / nst * 1e3, 3), "keypoints_per_frame": {"mean": float(kk.mean()), "min": int(kk.min()), "max": int(kk.max())},
-                             "matches_per_pair_mean": float(vp.S.float().mean().item()), "note": note}
-        run_variant(512, "kmax512", "same frames and weights, keypoint budget 512")
-        run_variant(256, "kmax256", "same frames and weights, keypoint budget 256")
-        # bias chosen on the bench frames with the oracle: +9 still saturates Kmax = 1024 on every frame, +9.5 leaves 700-900 keypoints
-        # (a different count per frame), +10 about 340, +12 none
-        ctx.set_weights(capi.KIND_SUPERPOINT, Wt.make_superpoint(seed=7, dustbin_bias=9.5))
-        run_variant(KMAX, "dustbin_k_below_kmax", "SuperPoint weights with dustbin bias +9.5 (SURVEY 8(d)): fewer candidates than Kmax pass the 0.0005 "
-                                                  "threshold, every frame has its own keypoint count (ragged sequences, masked attention / assignment)")
-        ctx.set_weights(capi.KIND_SUPERPOINT, wsp)
-        step(); fence()      # the resident results are those of the bench weights again (cpu_baseline checks them)
-        # RFE_OPT_LG_FP16X2 (default off, include/rover_fe.h): LightGlue's Linears and attention as split products on the f16 matrix pipe (gemm_h2.hip, lg_attention_h2.hip).
-        # Same frames, weights and Kmax as the headline; compared here with the fp32 path's resident results, never the headline.
-        S32, p32, m32 = S.cpu().numpy().copy(), pairs.cpu().numpy().copy(), ms.cpu().numpy().copy()
-        ctx.set_option(capi.OPT_LG_FP16X2, 1)
         try:
-            run_variant(KMAX, "fp16x2", "RFE_OPT_LG_FP16X2 = 1: every LightGlue Linear and the fused attention of the batched call as fp16 (hi + lo) x fp16 (hi + lo), "
-                                        "three products on v_mfma_f32_32x32x16_f16 with fp32 accumulation; softmax, LayerNorm / GELU, assignment and SuperPoint unchanged (fp32)")
-            ctx.profile_filter(None); ctx.profile(True); ctx.profile_reset()
-            for _ in range(3):
-                step()
-            fence()
-            ph2 = ctx.profile_read()
-            ctx.profile(False)
-            variants["fp16x2"]["stages_ms_per_step"] = {k: round(v[0] / 3, 4) for k, v in sorted(ph2.items(), key=lambda kv: -kv[1][0])
-                                                                if k.startswith("lg_")}
-            Sh, ph, mh = S.cpu().numpy(), pairs.cpu().numpy(), ms.cpu().numpy()
-            same = bool(np.array_equal(Sh, S32) and all(np.array_equal(ph[q, :S32[q]], p32[q, :S32[q]]) for q in range(B - 1)))
-            devh = max([float(np.abs(mh[q, :S32[q]] - m32[q, :S32[q]]).max()) for q in range(B - 1) if S32[q] > 0 and Sh[q] == S32[q]] or [0.0]) if same else None
-            variants["fp16x2"].update({"match_lists_identical_to_fp32_path": same, "match_score_max_dev_vs_fp32_path": devh,
-                                               "matches_total": int(S32.sum())})
-            fp16x2_out = {"S": Sh.copy(), "pairs": ph.copy(), "ms": mh.copy()}
-        finally:
+
+            def run_variant(kmax, tag, note):
+                vp = sharding.ResultPack(B, kmax, dev)
+                def vstep():
+                    ctx._chk(capi.lib.rfe_extract_match_stream_dev(
+                        ctx.h, frames.data_ptr(), H, W, W, B, kmax, 0.0005, 0.1, vp.n.data_ptr(), vp.kxy.data_ptr(), vp.score.data_ptr(),
+                        vp.desc.data_ptr(), vp.S.data_ptr(), vp.pairs.data_ptr(), vp.ms.data_ptr()))
+                for _ in range(2):
+                    vstep()
+                fence()
+                t1 = time.perf_counter()
+                nst = max(3, min(args.steps, 10))
+                for _ in range(nst):
+                    vstep()
+                fence()
+                dtv = time.perf_counter() - t1
+                kk = vp.n.cpu().numpy()
+                variants[tag] = {"value": round(FRAMES_PER_GPU * nst / dtv, 2), "unit": "frames/s", "kmax": kmax, "steps": nst,
+                                 "ms_per_step": round(dtv / nst * 1e3, 3), "keypoints_per_frame": {"mean": float(kk.mean()), "min": int(kk.min()), "max": int(kk.max())},
+                                 "matches_per_pair_mean": float(vp.S.float().mean().item()), "note": note}
+            run_variant(512, "kmax512", "same frames and weights, keypoint budget 512")
+            run_variant(256, "kmax256", "same frames and weights, keypoint budget 256")
+            # bias chosen on the bench frames with the oracle: +9 still saturates Kmax = 1024 on every frame, +9.5 leaves 700-900 keypoints
+            # (a different count per frame), +10 about 340, +12 none
+            ctx.set_weights(capi.KIND_SUPERPOINT, Wt.make_superpoint(seed=7, dustbin_bias=9.5))
+            run_variant(KMAX, "dustbin_k_below_kmax", "SuperPoint weights with dustbin bias +9.5 (SURVEY 8(d)): fewer candidates than Kmax pass the 0.0005 "
+                                                      "threshold, every frame has its own keypoint count (ragged sequences, masked attention / assignment)")
+            ctx.set_weights(capi.KIND_SUPERPOINT, wsp)
+            step(); fence()      # the resident results are those of the bench weights again (cpu_baseline checks them)
+            # RFE_OPT_LG_FP16X2 (default off, include/rover_fe.h): LightGlue's Linears and attention as split products on the f16 matrix pipe (gemm_h2.hip, lg_attention_h2.hip).
+            # Same frames, weights and Kmax as the headline; compared here with the fp32 path's resident results, never the headline.
+            S32, p32, m32 = S.cpu().numpy().copy(), pairs.cpu().numpy().copy(), ms.cpu().numpy().copy()
+            ctx.set_option(capi.OPT_LG_FP16X2, 1)
+            try:
+                run_variant(KMAX, "fp16x2", "RFE_OPT_LG_FP16X2 = 1: every LightGlue Linear and the fused attention of the batched call as fp16 (hi + lo) x fp16 (hi + lo), "
+                                            "three products on v_mfma_f32_32x32x16_f16 with fp32 accumulation; softmax, LayerNorm / GELU, assignment and SuperPoint unchanged (fp32)")
+                ctx.profile_filter(None); ctx.profile(True); ctx.profile_reset()
+                for _ in range(3):
+                    step()
+                fence()
+                ph2 = ctx.profile_read()
+                ctx.profile(False)
+                variants["fp16x2"]["stages_ms_per_step"] = {k: round(v[0] / 3, 4) for k, v in sorted(ph2.items(), key=lambda kv: -kv[1][0])
+                                                                    if k.startswith("lg_")}
+                Sh, ph, mh = S.cpu().numpy(), pairs.cpu().numpy(), ms.cpu().numpy()
+                same = bool(np.array_equal(Sh, S32) and all(np.array_equal(ph[q, :S32[q]], p32[q, :S32[q]]) for q in range(B - 1)))
+                devh = max([float(np.abs(mh[q, :S32[q]] - m32[q, :S32[q]]).max()) for q in range(B - 1) if S32[q] > 0 and Sh[q] == S32[q]] or [0.0]) if same else None
+                variants["fp16x2"].update({"match_lists_identical_to_fp32_path": same, "match_score_max_dev_vs_fp32_path": devh,
+                                                   "matches_total": int(S32.sum())})
+                fp16x2_out = {"S": Sh.copy(), "pairs": ph.copy(), "ms": mh.copy()}
+            finally:
+                ctx.set_option(capi.OPT_LG_FP16X2, 0)
+            step(); fence()      # ... and of the fp32 path
+        except Exception as e:     # an auxiliary run must never take the headline down with it: record the failure, restore the bench state
+            variants["error"] = f"{type(e).__name__}: {e}"[:300]
+            print(f"bench.py: variants failed: {variants['error']}", file=sys.stderr)
             ctx.set_option(capi.OPT_LG_FP16X2, 0)
-        step(); fence()      # ... and of the fp32 path
+            ctx.set_weights(capi.KIND_SUPERPOINT, wsp)
+            fp16x2_out = None
+            step(); fence()
 
     pcie = None
     if world == 1 and not args.no_pcie:
-        # PCIe-inclusive variant (never the headline `value`): frames start in pinned host memory, results end there.
-        # Double buffered: a copy stream uploads batch k+1 and downloads the results of batch k-1 while batch k computes.
-        h_frames = torch.from_numpy(frames_np).pin_memory()
-        cstream = torch.cuda.Stream(dev)
-        sets = []
-        for _ in range(2):
-            dv = [torch.zeros_like(t) for t in (frames, n, kxy, score, desc, S, pairs, ms)]   # match lists are written up to S only
-            hv = [torch.empty_like(t, device="cpu").pin_memory() for t in dv[1:]]
-            sets.append((dv, hv, torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()))
-        def step_pcie(k):
-            dv, hv, ev_up, ev_done, ev_down = sets[k % 2]
-            with torch.cuda.stream(cstream):
-                cstream.wait_event(ev_done)                    # batch k-2 no longer reads this frame buffer ...
-                dv[0].copy_(h_frames, non_blocking=True)
-                ev_up.record(cstream)
-            stream.wait_event(ev_up)
-            stream.wait_event(ev_down)                         # ... and its results have left the device
-            f_, n_, k_, s_, d_, S_, p_, m_ = dv
-            ctx._chk(capi.lib.rfe_extract_match_stream_dev(
-                ctx.h, f_.data_ptr(), H, W, W, B, KMAX, 0.0005, 0.1, n_.data_ptr(), k_.data_ptr(), s_.data_ptr(),
-                d_.data_ptr(), S_.data_ptr(), p_.data_ptr(), m_.data_ptr()))
-            ev_done.record(stream)
-            with torch.cuda.stream(cstream):
-                cstream.wait_event(ev_done)
-                for h, t in zip(hv, dv[1:]):
-                    h.copy_(t, non_blocking=True)
-                ev_down.record(cstream)
-        for k in range(2):
-            step_pcie(k)
-        fence()
-        t1 = time.perf_counter()
-        npc = max(4, min(args.steps, 10))
-        for k in range(npc):
-            step_pcie(k)
-        fence()
-        pcie = FRAMES_PER_GPU * npc / (time.perf_counter() - t1)
-        for si, (dv_, hv_, *_e) in enumerate(sets):               # same results as the resident path
-            for nm, h_, t_ in zip(("n", "kxy", "score", "desc", "S", "pairs", "ms"), hv_, (n, kxy, score, desc, S, pairs, ms)):
-                if not torch.equal(h_, t_.cpu()):
-                    raise RuntimeError(f"PCIe pipeline: {nm} of buffer set {si} differs from the resident path "
-                                       f"({int((h_ != t_.cpu()).sum())} elements)")
+        try:
+            # PCIe-inclusive variant (never the headline `value`): frames start in pinned host memory, results end there.
+            # Double buffered: a copy stream uploads batch k+1 and downloads the results of batch k-1 while batch k computes.
+            h_frames = torch.from_numpy(frames_np).pin_memory()
+            cstream = torch.cuda.Stream(dev)
+            sets = []
+            for _ in range(2):
+                dv = [torch.zeros_like(t) for t in (frames, n, kxy, score, desc, S, pairs, ms)]   # match lists are written up to S only
+                hv = [torch.empty_like(t, device="cpu").pin_memory() for t in dv[1:]]
+                sets.append((dv, hv, torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()))
+            def step_pcie(k):
+                dv, hv, ev_up, ev_done, ev_down = sets[k % 2]
+                with torch.cuda.stream(cstream):
+                    cstream.wait_event(ev_done)                    # batch k-2 no longer reads this frame buffer ...
+                    dv[0].copy_(h_frames, non_blocking=True)
+                    ev_up.record(cstream)
+                stream.wait_event(ev_up)
+                stream.wait_event(ev_down)                         # ... and its results have left the device
+                f_, n_, k_, s_, d_, S_, p_, m_ = dv
+                ctx._chk(capi.lib.rfe_extract_match_stream_dev(
+                    ctx.h, f_.data_ptr(), H, W, W, B, KMAX, 0.0005, 0.1, n_.data_ptr(), k_.data_ptr(), s_.data_ptr(),
+                    d_.data_ptr(), S_.data_ptr(), p_.data_ptr(), m_.data_ptr()))
+                ev_done.record(stream)
+                with torch.cuda.stream(cstream):
+                    cstream.wait_event(ev_done)
+                    for h, t in zip(hv, dv[1:]):
+                        h.copy_(t, non_blocking=True)
+                    ev_down.record(cstream)
+            for k in range(2):
+                step_pcie(k)
+            fence()
+            t1 = time.perf_counter()
+            npc = max(4, min(args.steps, 10))
+            for k in range(npc):
+                step_pcie(k)
+            fence()
+            pcie = FRAMES_PER_GPU * npc / (time.perf_counter() - t1)
+            for si, (dv_, hv_, *_e) in enumerate(sets):               # same results as the resident path
+                for nm, h_, t_ in zip(("n", "kxy", "score", "desc", "S", "pairs", "ms"), hv_, (n, kxy, score, desc, S, pairs, ms)):
+                    if not torch.equal(h_, t_.cpu()):
+                        raise RuntimeError(f"PCIe pipeline: {nm} of buffer set {si} differs from the resident path "
+                                           f"({int((h_ != t_.cpu()).sum())} elements)")
+        except Exception as e:
+            pcie = {"error": f"{type(e).__name__}: {e}"[:300]}
+            print(f"bench.py: PCIe-inclusive run failed: {pcie['error']}", file=sys.stderr)
+            fence()
 
     pool_line = None
     if world == 1 and not args.no_pool and args.workload == "c4":
@@ -764,8 +915,9 @@ def main():
         sys.stdout.flush()
         _saved1 = os.dup(1)
         os.dup2(2, 1)
-        pool = capi.Pool([dev.index or 0])
+        pool = None
         try:
+            pool = capi.Pool([dev.index or 0])
             pool.set_weights(capi.KIND_SUPERPOINT, wsp); pool.set_weights(capi.KIND_LIGHTGLUE, wlg)
             if args.lg_fold is not None:
                 pool.set_option(capi.OPT_LG_FOLD_WO, args.lg_fold)
@@ -787,11 +939,35 @@ def main():
                                  "calls not overlapped; the C-ABI route to configs[3], not the headline value"}
             if not same:
                 print("bench.py: the pool call's results differ from the resident path", file=sys.stderr)
+        except Exception as e:
+            pool_line = {"error": f"{type(e).__name__}: {e}"[:300]}
+            print(f"bench.py: pool run failed: {pool_line['error']}", file=sys.stderr)
         finally:
-            pool.close()
+            if pool is not None:
+                pool.close()
             _ctp.CDLL(None).fflush(None)
             os.dup2(_saved1, 1)
             os.close(_saved1)
+
+    latency = None
+    if world == 1 and not args.no_latency and args.workload == "c4" and not args.lg_fp16x2:
+        # The reference's own call pattern (batch 1) on the driver's clock: configs[1] / [2] / [4], device-resident and through the C++
+        # drop-in classes with host pointers.  Never the headline value.
+        latency = {"note": "BASELINE configs[1] / [2] / [4]: batch-1 latency in ms per call (c2 = one frame, c3 = one pair incl. both extractions, "
+                           "c5 = one 752x480 stereo frame); `resident` = device-resident entry points, `dropin` = the C++ drop-in classes with "
+                           "host pointers, as a Rover-SLAM thread calls them"}
+        try:
+            latency["resident"] = latency_resident(ctx, capi, synth, sharding, torch, dev, frames, steps=args.latency_steps)
+        except Exception as e:
+            latency["resident"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        try:
+            latency["dropin"] = latency_dropin(synth, wsp, wlg, frames_np, steps=args.latency_steps, check=not args.no_cpu_baseline)
+        except Exception as e:
+            latency["dropin"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        for k in ("resident", "dropin"):
+            if "error" in latency[k]:
+                print(f"bench.py: latency.{k} failed: {latency[k]['error']}", file=sys.stderr)
+        step(); fence()      # the resident results are those of the bench batch again (cpu_baseline checks them)
 
     bad_exit = 0
     gathered_ok = None
@@ -854,7 +1030,11 @@ def main():
             out["variants"] = variants
         if pool_line is not None:
             out["pool_c_abi"] = pool_line
-        if pcie is not None:
+        if latency is not None:
+            out["latency"] = latency
+        if isinstance(pcie, dict):
+            out["pcie_inclusive"] = pcie
+        elif pcie is not None:
             out["pcie_inclusive"] = {"value": round(pcie, 2), "unit": "frames/s",
                                      "note": "same step with H2D of the 33 u8 frames and D2H of all results (descriptors included) per step, pinned host memory, double buffered on a copy stream; not the headline value"}
         if world == 1 and not args.no_cpu_baseline:

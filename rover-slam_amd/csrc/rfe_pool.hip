@@ -12,6 +12,7 @@
 #include <rccl/rccl.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -23,6 +24,7 @@ struct RcclApi {
     void* lib = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;     // optional
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -38,6 +40,7 @@ struct RcclApi {
         RFE_SYM(CommInitAll, "ncclCommInitAll") RFE_SYM(CommDestroy, "ncclCommDestroy") RFE_SYM(GroupStart, "ncclGroupStart")
         RFE_SYM(GroupEnd, "ncclGroupEnd") RFE_SYM(Send, "ncclSend") RFE_SYM(Recv, "ncclRecv") RFE_SYM(GetErrorString, "ncclGetErrorString")
 #undef RFE_SYM
+        CommAbort = reinterpret_cast<decltype(CommAbort)>(dlsym(lib, "ncclCommAbort"));
         return true;
     }
 };
@@ -82,6 +85,7 @@ struct rfe_pool {
     std::string err;
     RcclApi api;
     bool rccl_up = false;
+    std::atomic<bool> rccl_broken{false};                 // a member's gather failed: communicators are torn down, the pool continues on COPY
     std::string rccl_why;                                 // why the RCCL transport is unavailable
     void* root = nullptr; size_t root_bytes = 0;          // gathered results in global order on member 0's device
     // job hand-off to the persistent workers
@@ -156,7 +160,13 @@ static int run_member(rfe_pool* p, int r) {
         Field f[F_COUNT]; field_table(j.Kmax, f);
         size_t goff[F_COUNT];
         pack_layout(j.F, j.Kmax, goff);
-        POOL_NCCL(p, mb, p->api.GroupStart());
+        // A failure between GroupStart and GroupEnd must not leave the group open: the peers have posted (or will post) their
+        // matching operations and would wait for ever.  The first failure is recorded, the remaining operations of the group are
+        // skipped, GroupEnd is ALWAYS called, and on any failure this member aborts its communicator (ncclCommAbort: the peers'
+        // pending operations with it fail instead of hanging; the pool then falls back to the COPY transport, see rfe_pool_extract_match_stream).
+        ncclResult_t first = p->api.GroupStart();
+        const char* where = "ncclGroupStart";
+        const bool opened = first == ncclSuccess;
         auto rows_of = [&](int q, int i, int* first_row) {   // rows of array i that member q contributes, and where they start globally
             int fq, frq, oq;
             rfe_pool_shard(j.F, n, q, &fq, &frq, &oq);
@@ -166,19 +176,28 @@ static int run_member(rfe_pool* p, int r) {
             for (int t = 0; t < n; ++t) { int a, b, c; rfe_pool_shard(j.F, n, t, &a, &b, &c); if (b > 0) last = t; }
             return frq == 0 ? 0 : (q == last ? frq : oq);
         };
-        for (int i = 0; i < F_COUNT; ++i) {
+        for (int i = 0; i < F_COUNT && first == ncclSuccess; ++i) {
             if ((i == F_SCORE && !j.with_score) || (i == F_DESC && !j.with_desc)) continue;
             int fr;
             const int rows = rows_of(r, i, &fr);
-            if (rows > 0) POOL_NCCL(p, mb, p->api.Send((char*)mb.pack + off[i], (size_t)rows * f[i].row, ncclUint8, 0, mb.comm, s));
+            if (rows > 0 && (first = p->api.Send((char*)mb.pack + off[i], (size_t)rows * f[i].row, ncclUint8, 0, mb.comm, s)) != ncclSuccess) { where = "ncclSend"; break; }
             if (r == 0)
-                for (int q = 0; q < n; ++q) {
+                for (int q = 0; q < n && first == ncclSuccess; ++q) {
                     int fq;
                     const int rq = rows_of(q, i, &fq);
-                    if (rq > 0) POOL_NCCL(p, mb, p->api.Recv((char*)p->root + goff[i] + (size_t)fq * f[i].row, (size_t)rq * f[i].row, ncclUint8, q, mb.comm, s));
+                    if (rq > 0 && (first = p->api.Recv((char*)p->root + goff[i] + (size_t)fq * f[i].row, (size_t)rq * f[i].row, ncclUint8, q, mb.comm, s)) != ncclSuccess) where = "ncclRecv";
                 }
         }
-        POOL_NCCL(p, mb, p->api.GroupEnd());
+        if (opened) {
+            const ncclResult_t e = p->api.GroupEnd();
+            if (first == ncclSuccess && e != ncclSuccess) { first = e; where = "ncclGroupEnd"; }
+        }
+        if (first != ncclSuccess) {
+            mb.err = std::string(where) + ": " + p->api.GetErrorString(first);
+            if (p->api.CommAbort && mb.comm) { (void)p->api.CommAbort(mb.comm); mb.comm = nullptr; }
+            p->rccl_broken.store(true);
+            return RFE_ERR_HIP;
+        }
     }
     POOL_HIP(mb, hipStreamSynchronize(s));
     return RFE_OK;
@@ -302,8 +321,10 @@ extern "C" int rfe_pool_extract_match_stream(rfe_pool* p, const uint8_t* img, in
     if (F > 1 && (!S || !pairs || !ms)) return pfail(p, RFE_ERR_INVALID, "pool stream: null match output");
     if (transport != RFE_POOL_AUTO && transport != RFE_POOL_RCCL && transport != RFE_POOL_COPY) return pfail(p, RFE_ERR_INVALID, "pool stream: unknown transport");
     if (transport == RFE_POOL_RCCL && !p->rccl_up) return pfail(p, RFE_ERR_INVALID, "pool stream: RCCL transport unavailable: " + p->rccl_why);
-    const bool rccl = transport == RFE_POOL_RCCL || (transport == RFE_POOL_AUTO && p->rccl_up && p->m.size() > 1);
+    bool rccl = transport == RFE_POOL_RCCL || (transport == RFE_POOL_AUTO && p->rccl_up && p->m.size() > 1);
     const int nm = (int)p->m.size();
+    // the call works on the members' devices; the caller's current device is restored on every exit path
+    struct DeviceGuard { int dev = -1; DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; } ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); } } device_guard;
     Member& root = p->m[0];
     size_t goff[F_COUNT];
     const size_t gbytes = pack_layout(F, Kmax, goff);
@@ -325,6 +346,27 @@ extern "C" int rfe_pool_extract_match_stream(rfe_pool* p, const uint8_t* img, in
         {
             std::unique_lock<std::mutex> lk(p->mu);
             p->cv_done.wait(lk, [&] { return p->pending == 0; });
+        }
+        if (phase == 1 && p->rccl_broken.load()) {
+            // a member could not post its part of the gather: it has closed its group and aborted its communicator, so nobody is left
+            // inside a collective.  Tear the communicators down for good and deliver THIS call's results through the COPY transport
+            // (phase 0 left every member's rows complete in its own buffer); an explicit RFE_POOL_RCCL request is answered with the error.
+            std::string why;
+            for (int r = 0; r < nm; ++r) {
+                Member& mb = p->m[r];
+                if (mb.rc && why.empty()) why = "member " + std::to_string(r) + ": " + mb.err;
+                (void)hipSetDevice(mb.device);
+                if (mb.comm) { (void)(p->api.CommAbort ? p->api.CommAbort(mb.comm) : p->api.CommDestroy(mb.comm)); mb.comm = nullptr; }
+                (void)hipStreamSynchronize(mb.ctx->stream);
+                (void)hipGetLastError();
+                mb.rc = 0;
+            }
+            p->rccl_up = false;
+            p->rccl_why = "a gather failed (" + why + "); the pool continues on the COPY transport";
+            if (transport == RFE_POOL_RCCL) return pfail(p, RFE_ERR_HIP, "pool stream: RCCL gather failed: " + why);
+            rccl = false;
+            if (hipSetDevice(root.device) != hipSuccess) return pfail(p, RFE_ERR_HIP, "pool stream: hipSetDevice(root)");
+            break;
         }
         for (int r = 0; r < nm; ++r)
             if (p->m[r].rc) return pfail(p, p->m[r].rc, "pool stream: member " + std::to_string(r) + " (device " + std::to_string(p->m[r].device) + "): " + p->m[r].err);

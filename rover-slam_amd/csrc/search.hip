@@ -59,7 +59,8 @@ __global__ __launch_bounds__(64) void distinctive_rows_kernel(const float* __res
     extern __shared__ float row[];
     const int lane = threadIdx.x;
     const int g = blockIdx.x;
-    if (g >= offsets[Np]) return;          // the grid is sized for the caller's `total`, an upper bound
+    if (g >= offsets[Np]) return;          // the grid is sized for the caller's `total`, an upper bound (a larger offsets[Np]: rows >= total are
+                                           // never launched, and distinctive_pick_kernel reports their points as -2)
     int lo = 0, hi = Np;                   // invariant: offsets[lo] <= g < offsets[hi]
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
@@ -92,13 +93,15 @@ __global__ __launch_bounds__(64) void distinctive_rows_kernel(const float* __res
     if (lane == 0) med[g] = row[(int)(0.5 * (n - 1))];
 }
 
-__global__ void distinctive_pick_kernel(const float* __restrict__ med, const int32_t* __restrict__ offsets, int Np, int maxn,
+__global__ void distinctive_pick_kernel(const float* __restrict__ med, const int32_t* __restrict__ offsets, int Np, int maxn, int total,
                                         int32_t* __restrict__ best, float* __restrict__ median) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= Np) return;
     const int o = offsets[p], n = offsets[p + 1] - o;
     if (n <= 0) { best[p] = -1; median[p] = 0.f; return; }
-    if (n > maxn) { best[p] = -2; median[p] = 0.f; return; }   // more observations than the caller's bound: reported, not computed
+    // more observations than the caller's bound, or a list that leaves the caller's `total` (= the size of the med scratch: an
+    // understated total, a non-zero offsets[0]): reported, not computed -- every read below stays inside med[0, total)
+    if (n > maxn || o < 0 || o + n > total) { best[p] = -2; median[p] = 0.f; return; }
     float bm = 2147483647.0f; int bi = 0;
     for (int i = 0; i < n; ++i) {
         const float m = med[o + i];
@@ -114,7 +117,7 @@ void launch_distinctive(hipStream_t s, const float* desc, const int32_t* offsets
     while (P2 < maxn) P2 <<= 1;
     if (total > 0)
         hipLaunchKernelGGL(distinctive_rows_kernel, dim3(total), dim3(64), (size_t)P2 * 4, s, desc, offsets, Np, P2, med);
-    hipLaunchKernelGGL(distinctive_pick_kernel, dim3((Np + 255) / 256), dim3(256), 0, s, med, offsets, Np, P2, best, median);
+    hipLaunchKernelGGL(distinctive_pick_kernel, dim3((Np + 255) / 256), dim3(256), 0, s, med, offsets, Np, P2, total, best, median);
 }
 
 }  // namespace rfe

@@ -1,0 +1,120 @@
+// lat_driver.cpp -- the reference's OWN call pattern on the clock: batch 1, host pointers in and out, through the drop-in C++
+// classes, exactly as a Rover-SLAM Tracking thread would drive them (bench.py's `latency.dropin`).
+//   c2  BASELINE configs[1]: one 640x480 frame through SPextractor::operator()            (src/Frame.cc:544-559 -> SPextractor.cc:516-617)
+//   c3  BASELINE configs[2]: a 640x480 pair: two extractions + SPmatcher::MatchingPoints_onnx(Frame&, Frame&)
+//                                                                                          (src/Matchers/SPmatcher.cc:457-542)
+//   c5  BASELINE configs[4]: a 752x480 stereo frame: left and right extraction on TWO THREADS with two extractors
+//       (src/Frame.cc:142-147), ComputeStereoMatches (:1159-1446) and the temporal match against the previous left view
+//       (SearchBySP, src/Matchers/SPmatcher.cc:1050-1054)
+// Every call copies its image / keypoints / descriptors from pageable host memory and its results back: this is what the reference's
+// interface forces, and what the device-resident entry points (bench.py `latency.resident`) avoid.
+// usage: lat_driver <pair.u8: 2 x 480x640> <stereo.u8: T x 2 x 480x752> T steps warmup <out.bin>
+// weights via $RFE_SP_WEIGHTS / $RFE_LG_WEIGHTS; prints ONE JSON line; out.bin holds the last results for bench.py's oracle check.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+#include <vector>
+#include "Extractors/SPextractor.h"
+#include "Matchers/SPmatcher.h"
+#include "rfe/stereo_match.h"
+
+struct MockFrame {                      // the members SPmatcher::MatchingPoints_onnx(Frame&, Frame&) and ComputeStereoMatches read
+    std::vector<cv::KeyPoint> mvKeys, mvKeysRight;
+    cv::Mat mDescriptors, mDescriptorsRight, imgLeft, imgRight;
+    float mb = 0.11f, mbf = 0.11f * 435.0f;
+    std::vector<float> mvuRight, mvDepth;
+};
+
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static void put(FILE* f, const void* p, size_t n) { fwrite(p, 1, n, f); }
+static void put_frame(FILE* f, const std::vector<cv::KeyPoint>& k, const cv::Mat& d) {
+    const int32_t n = (int32_t)k.size();
+    put(f, &n, 4);
+    for (const auto& kp : k) { float v[3] = {kp.pt.x, kp.pt.y, kp.response}; put(f, v, sizeof(v)); }
+    for (int r = 0; r < n; ++r) put(f, d.ptr<float>(r), 256 * 4);
+}
+
+int main(int argc, char** argv) {
+    if (argc < 7) { fprintf(stderr, "usage: lat_driver pair.u8 stereo.u8 T steps warmup out.bin\n"); return 2; }
+    const int H = 480, W = 640, Hs = 480, Ws = 752;
+    const int T = atoi(argv[3]), steps = atoi(argv[4]), warm = atoi(argv[5]);
+    std::vector<unsigned char> pair((size_t)2 * H * W), stereo((size_t)T * 2 * Hs * Ws);
+    FILE* fi = fopen(argv[1], "rb");
+    if (!fi || fread(pair.data(), 1, pair.size(), fi) != pair.size()) { fprintf(stderr, "cannot read %s\n", argv[1]); return 2; }
+    fclose(fi);
+    fi = fopen(argv[2], "rb");
+    if (!fi || fread(stereo.data(), 1, stereo.size(), fi) != stereo.size()) { fprintf(stderr, "cannot read %s\n", argv[2]); return 2; }
+    fclose(fi);
+
+    // as Tracking builds them: two extractors (left / right, src/Tracking.cc:645-651) and one matcher (:70)
+    ORB_SLAM3::SPextractor extL(1000, 1.2f, 1, 20, 7), extR(1000, 1.2f, 1, 20, 7);
+    ORB_SLAM3::SPmatcher matcher(0.0f);
+    if (!extL.featureExtractor->ExtractorSession || !extR.featureExtractor->ExtractorSession || !matcher.featureMatcher->MatcherSession) return 3;
+
+    // ---- c2: one frame
+    MockFrame f0, f1;
+    f0.imgLeft = cv::Mat(H, W, CV_8UC1, pair.data());
+    f1.imgLeft = cv::Mat(H, W, CV_8UC1, pair.data() + (size_t)H * W);
+    double t0 = 0;
+    for (int i = -warm; i < steps; ++i) {
+        if (i == 0) t0 = now_ms();
+        f0.mvKeys.clear();
+        extL(f0.imgLeft, f0.mvKeys, f0.mDescriptors);
+    }
+    const double c2 = (now_ms() - t0) / steps;
+
+    // ---- c3: a pair = two extractions + one LightGlue match (Frame overload: true image size)
+    std::vector<int> vn;
+    int s3 = 0;
+    for (int i = -warm; i < steps; ++i) {
+        if (i == 0) t0 = now_ms();
+        f0.mvKeys.clear(); f1.mvKeys.clear();
+        extL(f0.imgLeft, f0.mvKeys, f0.mDescriptors);
+        extL(f1.imgLeft, f1.mvKeys, f1.mDescriptors);
+        s3 = matcher.MatchingPoints_onnx(f0, f1, vn);
+    }
+    const double c3 = (now_ms() - t0) / steps;
+
+    // ---- c5: stereo stream
+    MockFrame cur, prev;
+    std::vector<int> vt;
+    int s5 = 0, last_t = 0;
+    bool have_prev = false;
+    for (int i = -warm; i < steps; ++i) {
+        if (i == 0) t0 = now_ms();
+        const int t = ((i + warm) % T);
+        cur.imgLeft = cv::Mat(Hs, Ws, CV_8UC1, stereo.data() + (size_t)(2 * t) * Hs * Ws);
+        cur.imgRight = cv::Mat(Hs, Ws, CV_8UC1, stereo.data() + (size_t)(2 * t + 1) * Hs * Ws);
+        cur.mvKeys.clear(); cur.mvKeysRight.clear();
+        std::thread thr([&] { extR(cur.imgRight, cur.mvKeysRight, cur.mDescriptorsRight); });      // src/Frame.cc:142-147
+        extL(cur.imgLeft, cur.mvKeys, cur.mDescriptors);
+        thr.join();
+        if (ORB_SLAM3::ComputeStereoMatches_rfe(extL.featureExtractor->ExtractorSession, cur) != 0) return 5;
+        s5 = have_prev ? matcher.MatchingPoints_onnx(cur, prev, vt) : 0;                             // SearchBySP(current, last)
+        if (i + 1 < steps) {
+            prev.mvKeys = cur.mvKeys; prev.mDescriptors = cur.mDescriptors.clone(); prev.imgLeft = cur.imgLeft;
+            have_prev = true;
+        }
+        last_t = t;
+    }
+    const double c5 = (now_ms() - t0) / steps;
+
+    FILE* fo = fopen(argv[6], "wb");
+    if (!fo) return 4;
+    put_frame(fo, f0.mvKeys, f0.mDescriptors); put_frame(fo, f1.mvKeys, f1.mDescriptors);
+    int32_t m = (int32_t)vn.size();
+    put(fo, &s3, 4); put(fo, &m, 4); put(fo, vn.data(), (size_t)m * 4);
+    const int32_t tt[2] = {last_t, (last_t + T - 1) % T};
+    put(fo, tt, 8);
+    put_frame(fo, cur.mvKeys, cur.mDescriptors); put_frame(fo, cur.mvKeysRight, cur.mDescriptorsRight); put_frame(fo, prev.mvKeys, prev.mDescriptors);
+    m = (int32_t)cur.mvuRight.size();
+    put(fo, &m, 4); put(fo, cur.mvuRight.data(), (size_t)m * 4); put(fo, cur.mvDepth.data(), (size_t)m * 4);
+    m = (int32_t)vt.size();
+    put(fo, &s5, 4); put(fo, &m, 4); put(fo, vt.data(), (size_t)m * 4);
+    fclose(fo);
+    printf("{\"c2_ms\": %.4f, \"c3_ms\": %.4f, \"c5_ms\": %.4f, \"steps\": %d, \"warmup\": %d, \"c2_keypoints\": %d, \"c3_matches\": %d, "
+           "\"c5_left_keypoints\": %d, \"c5_temporal_matches\": %d}\n",
+           c2, c3, c5, steps, warm, (int)f0.mvKeys.size(), s3, (int)cur.mvKeys.size(), s5);
+    return 0;
+}
