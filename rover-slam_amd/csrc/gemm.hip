@@ -407,6 +407,9 @@ int launch_gemm_nt(hipStream_t s, const GemmArgs& g_in) {
     // RFE_OPT_LG_FP16X2: a LightGlue Linear whose weights come with fp16 (hi, lo) planes and whose shape takes the throughput tile
     if (g.Bh && g.Bl && batch == 1 && !g.m_valid && !g.relu && g.N % 256 == 0 && g.K % 32 == 0 && (!g.A2 || g.K1 % 32 == 0) && tiles(128, 256) >= 256)
         return launch_gemm_h2(s, g);
+    if (gemm_latency_regime(g)) {   // one / few pairs per call: the 16x16x4 latency tiling (gemm_lat.hip) when it serves the shape
+        if (launch_gemm_lat(s, g, nullptr, 0)) return 0;
+    }
     const bool res = g.R != nullptr, lna = g.stats_in != nullptr;
     static const bool lni = tune_int("RFE_LN_INTERLEAVE", 1) != 0;   // tuning switch
 

@@ -1,0 +1,295 @@
+// lg_attention_lat.hip -- the LATENCY form of LightGlue's fused attention, softmax(Q K^T / 8) V per (sequence, head), for the shapes the
+// reference itself runs: ONE pair per call (src/Matchers/lightglue_onnx.cpp:168-172) = 2 sequences x 4 heads x <= 1024 queries.
+//
+// lg_attention_kernel<SPLIT> covered that regime with 64 (sequence, head, 128-query block) units x 4 key ranges = 256 workgroups whose
+// unnormalised partial sums a second kernel merged: four waves shared every K/V tile through a single-buffered LDS tile (two barriers
+// per 64 keys, register staging), every lane wrote 32 scalar partials, 8 MB of partials crossed HBM twice and the merge was a launch of
+// its own -- 28-32 + 5 us against 13.7 us of matrix time.  Here the key split happens INSIDE the workgroup:
+//   * workgroup = (sequence, head, 32-query block): 2 x 4 x 32 = 256 workgroups for a pair, four waves, one per SIMD;
+//   * wave w owns the w-th QUARTER of the keys and the same 32 queries: nothing is shared in the main loop, so it has NO barrier at all --
+//     every wave streams its own 32-key K / V tiles by global_load_lds_dwordx4 into private double-buffered LDS tiles (32 KB per wave),
+//     requests tile t + 1 before it starts on tile t and waits with a counted s_waitcnt for its own copies only;
+//   * arithmetic per tile exactly as lg_attention_dma_kernel (S^T = K Q^T with the K image XOR-swizzled on the source address: one
+//     conflict-free ds_read_b128 per four k-steps; base-2 online softmax with deferred rescale; the S^T accumulators ARE the B operand of
+//     O^T += V^T P^T);
+//   * the four (O, m, l) partials of a query are merged through LDS (the tile buffers, free by then) and the normalised context is
+//     written ONCE with 16-byte stores -- no partials in HBM, no second launch.
+// The rotary encoding is NOT applied here: the one-pair qkv projection (gemm_lat.hip, ROPE epilogue) has already rotated q and k.
+// Roofline: fp32 MFMA peak; algorithmic 4 heads * 4 * 64 * sum n_q n_k FLOP.
+#include "rfe_internal.h"
+
+namespace rfe {
+
+typedef __attribute__((address_space(3))) void* alat_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* alat_gptr_t;
+
+constexpr int AL_K = 32;                         // keys per tile
+constexpr int AL_TILE_F = AL_K * 64;             // floats of one K (or V) tile
+constexpr int AL_WAVE_F = 4 * AL_TILE_F;         // per wave: K ring of 2 tiles | V ring of 2 tiles
+constexpr float AL_DEFER = 16.0f;                // log2 units (lg_kernels.hip: AT_DEFER)
+
+#ifdef RFE_TUNING
+__device__ unsigned long long rfe_dbg_ts_att[2048 * 8];   // in-kernel timeline (tuning build, abl & 4), see gemm_lat.hip
+#define RFE_ATS(slot) do { if ((abl & 4) && tid == 0 && blockIdx.x < 2048) { rfe_dbg_ts_att[blockIdx.x * 8 + (slot)] = clock64(); rfe_dbg_ts_att[blockIdx.x * 8 + 4 + (slot)] = wall_clock64(); } } while (0)
+#else
+#define RFE_ATS(slot) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(256, 1) void lg_attention_lat_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld, float* __restrict__ out,
+    int Lq, int Lk, int nqb, const int* __restrict__ qlen, const int* __restrict__ klen, const int* __restrict__ kv_map, int nseq_total, int abl) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // 4 waves x AL_WAVE_F floats = 128 KB
+    // all query blocks of one (sequence, head) on one XCD: its K / V (512 KB) is fetched into one L2
+    const int Lb = blockIdx.x, xcd = Lb & 7, t_ = Lb >> 3;
+    const int qb = t_ % nqb, unit = (t_ / nqb) * 8 + xcd;
+    if (unit >= 4 * nseq_total) return;
+    const int seq = unit >> 2, head = unit & 3;
+    const int kvseq = kv_map ? kv_map[seq] : seq;
+    const int nq = qlen ? qlen[seq] : Lq;
+    const int nk = klen ? klen[kvseq] : Lk;
+    const int tid = threadIdx.x, lane = tid & 63;
+    RFE_ATS(0);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    if (qb * 32 >= nq || nk <= 0) {   // whole block is padding (or nothing to attend to): the padded context rows stay defined (zero)
+        for (int e = tid; e < 32 * 16; e += 256) {
+            const int row = qb * 32 + (e >> 4);
+            if (row < Lq) *reinterpret_cast<f32x4*>(out + ((size_t)seq * Lq + row) * 256 + head * 64 + (e & 15) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        return;
+    }
+    const int qrow = qb * 32 + j;    // this lane's query (may be >= nq: computed, stored as 0)
+    const size_t qrow_c = (size_t)seq * Lq + (qrow < Lq ? qrow : Lq - 1);
+    constexpr float kScale = 0.125f * 1.44269504088896341f;   // 1 / sqrt(64) * log2(e): softmax in base 2, folded into Q
+    float qreg[32];   // qreg[4 g + e] = Q[query][8 g + 4 h + e] * scale  (the k order of the swizzled K image, lg_attention_dma_kernel)
+    {
+        const f32x4* qp4 = reinterpret_cast<const f32x4*>(q + qrow_c * ld + head * 64) + h;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const f32x4 t = qp4[2 * g];
+            qreg[4 * g] = t[0] * kScale; qreg[4 * g + 1] = t[1] * kScale; qreg[4 * g + 2] = t[2] * kScale; qreg[4 * g + 3] = t[3] * kScale;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // from here on the vector-memory counter only sees this wave's tile copies
+
+    // this wave's key range: the w-th quarter, whole 32-key tiles
+    const int per = ((nk + 3) / 4 + AL_K - 1) / AL_K * AL_K;
+    const int kbeg = wave * per;
+    const int kend = kbeg + per < nk ? kbeg + per : nk;
+    const int ntile = kend > kbeg ? (kend - kbeg + AL_K - 1) / AL_K : 0;
+    const float* kbase = k + (size_t)kvseq * Lk * ld + head * 64;
+    const float* vbase = v + (size_t)kvseq * Lk * ld + head * 64;
+    float* const wl = lds + wave * AL_WAVE_F;          // K ring [2][32 x 64] | V ring [2][32 x 64]
+    float* const Kr = wl;
+    float* const Vr = wl + 2 * AL_TILE_F;
+    // copy geometry: one wave instruction moves 64 granules of 16 B = 4 rows of a tile, 8 instructions per K (or V) tile.  Granule
+    // (row, slot') of the K image holds global chunk slot' ^ (row & 15).  Per-lane 32-bit offsets from a wave-uniform tile base, so
+    // that a copy is one instruction with a scalar base (the 64-bit per-lane address arithmetic used to cost as much as the softmax)
+    const int crow = lane >> 4, cslot = lane & 15;
+    int koff[8], voff[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int row = u * 4 + crow;
+        koff[u] = row * ld + ((cslot ^ (row & 15)) << 2);
+        voff[u] = row * ld + (cslot << 2);
+    }
+    auto issue_k = [&](int t, int buf) {
+        const int k0 = kbeg + t * AL_K;
+        const float* base = kbase + (size_t)k0 * ld;
+        if (k0 + AL_K <= nk) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) __builtin_amdgcn_global_load_lds((alat_gptr_t)(base + koff[u]), (alat_lds_ptr_t)(Kr + buf * AL_TILE_F + u * 256), 16, 0, 0);
+        } else {   // the sequence's last, partial tile: keys past the end read the last valid row (finite) and are masked in S
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int row = u * 4 + crow;
+                const int rc = k0 + row < nk ? row : nk - 1 - k0;
+                __builtin_amdgcn_global_load_lds((alat_gptr_t)(base + rc * ld + ((cslot ^ (row & 15)) << 2)), (alat_lds_ptr_t)(Kr + buf * AL_TILE_F + u * 256), 16, 0, 0);
+            }
+        }
+    };
+    auto issue_v = [&](int t, int buf) {
+        const int k0 = kbeg + t * AL_K;
+        const float* base = vbase + (size_t)k0 * ld;
+        if (k0 + AL_K <= nk) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) __builtin_amdgcn_global_load_lds((alat_gptr_t)(base + voff[u]), (alat_lds_ptr_t)(Vr + buf * AL_TILE_F + u * 256), 16, 0, 0);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int row = u * 4 + crow;
+                const int rc = k0 + row < nk ? row : nk - 1 - k0;
+                __builtin_amdgcn_global_load_lds((alat_gptr_t)(base + rc * ld + (cslot << 2)), (alat_lds_ptr_t)(Vr + buf * AL_TILE_F + u * 256), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;   // running maximum (log2 domain) and per-half-wave partial row sum
+    const int jsw = j & 15;
+
+    // Loop order per 32-key tile (measured alternatives in profiles/r04_ab_notes.md):
+    //   request tile t + 1 (16 copies, one scalar-base instruction each) -> wait for tile t's own copies (counted s_waitcnt) ->
+    //   the eight K fragments of S^T and the 32 V values of PV into registers -> 32 matrix instructions of S^T = K Q^T STRICTLY back to back -> softmax ->
+    //   32 matrix instructions of O^T += V^T P^T on two alternating accumulators.
+    // S^T is ONE dependent accumulator chain: any instruction between two of its matrix instructions breaks the accumulator forwarding
+    // (+43 cycles per gap, guide "one EXTRA issue slot ... on the SAME accumulator"), so nothing is interleaved there -- a version that
+    // pipelined QK(t + 1) against the exponentials of tile t was 8 % SLOWER for exactly that reason; with one wave per SIMD the matrix
+    // pipe itself sustains ~82 cycles per v_mfma_f32_32x32x2_f32 on random data (a pure-MFMA ablation of this loop), and this order sits
+    // within 13 % of that floor.
+    int buf = 0;
+    if (ntile > 0) { issue_k(0, 0); issue_v(0, 0); }
+    RFE_ATS(1);
+    for (int t = 0; t < ntile; ++t) {
+        const bool more = t + 1 < ntile && !(abl & 1);   // abl (tuning build, wrong results): 1 = only the first tile is copied
+        if (more) {
+            issue_k(t + 1, buf ^ 1);
+            issue_v(t + 1, buf ^ 1);                                 // 16 copies younger than the tile consumed below
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const float* const Kt = Kr + buf * AL_TILE_F;
+        const float* const Vt = Vr + buf * AL_TILE_F;
+        f32x4 kf[8];
+        {
+            const float* ka = Kt + j * 64;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) kf[g] = *reinterpret_cast<const f32x4*>(ka + (((2 * g + h) ^ jsw) << 2));
+        }
+        // ... and the 32 V values of this tile's PV: requested here, they land under the S^T chain (left to the scheduler, every pair of PV
+        // matrix instructions waited for an LDS read issued just in front of it)
+        float vf[32];
+        {
+            const float* va = Vt + (4 * h) * 64 + j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kr = (r & 3) + 8 * (r >> 2);       // k-step r of PV uses key (r & 3) + 8 (r >> 2) + 4 h
+                vf[r] = va[kr * 64]; vf[16 + r] = va[kr * 64 + 32];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- S^T[key][query] = sum_d K[key][d] Q[query][d], started at -(running maximum) so that no subtraction is needed per element
+        f32x16 st;
+        const bool first = t == 0;
+        {
+            const float init = first ? 0.f : -m_run;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = init;
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[g][e], qreg[4 * g + e], st, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int k0 = kbeg + t * AL_K;
+        if (k0 + AL_K > nk) {      // only the last tile of the sequence can hold keys >= nk
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (key >= nk) st[r] = -INFINITY;
+            }
+        }
+        // ---- online softmax over this lane's 16 keys (the other half-wave holds the other 16): lg_kernels.hip at_softmax_step
+        {
+            float mx = fmaxf(fmaxf(st[0], st[1]), st[2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, st[r]), st[r + 1]);
+            mx = fmaxf(mx, st[15]);
+            if (__any(first || mx > AL_DEFER)) {
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float ref = first ? 0.f : m_run;
+                const float m_new = fmaxf(m_run, mx + ref);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // m_run = -inf on the first tile -> 0
+                const float d = ref - m_new;
+                l_run *= alpha;
+                m_run = m_new;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { st[r] += d; o0[r] *= alpha; o1[r] *= alpha; }
+            }
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[r] = __builtin_amdgcn_exp2f(st[r]); ps += st[r]; }
+            l_run += ps;
+        }
+        // ---- O^T[d][query] += sum_key V[key][d] P[key][query]; k-step r uses key (r & 3) + 8 (r >> 2) + 4 h
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r], st[r], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[16 + r], st[r], o1, 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+    l_run += __shfl_xor(l_run, 32);          // the two half-waves' partial sums
+    RFE_ATS(2);
+
+    // ---- merge the four key ranges through LDS: out = sum_w o_w 2^(m_w - m) / sum_w l_w 2^(m_w - m), m = max_w m_w.
+    // Layout: part[w][query j][68]: 64 context values + (m, l), row stride 68 floats = 272 B (16-byte aligned, conflict-light)
+    __syncthreads();                          // every wave is done with its tiles: the region is reused
+    float* const part = lds;
+    {
+        float* pr = part + (wave * 32 + j) * 68;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {      // accumulator registers 4 rq .. 4 rq + 3 are dims 8 rq + 4 h .. + 3
+            *reinterpret_cast<f32x4*>(pr + 8 * rq + 4 * h) = f32x4{o0[4 * rq], o0[4 * rq + 1], o0[4 * rq + 2], o0[4 * rq + 3]};
+            *reinterpret_cast<f32x4*>(pr + 32 + 8 * rq + 4 * h) = f32x4{o1[4 * rq], o1[4 * rq + 1], o1[4 * rq + 2], o1[4 * rq + 3]};
+        }
+        if (h == 0) { pr[64] = m_run; pr[65] = l_run; }
+    }
+    __syncthreads();
+    // thread -> (query = tid / 8, 8 dims = two float4): 32 queries x 64 dims
+    {
+        const int qj = tid >> 3, dq = (tid & 7) * 8;
+        const int row = qb * 32 + qj;
+        float mw[4], lw[4], m = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { mw[w] = part[(w * 32 + qj) * 68 + 64]; lw[w] = part[(w * 32 + qj) * 68 + 65]; m = fmaxf(m, mw[w]); }
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        float l = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (!(lw[w] > 0.f)) continue;     // empty key range
+            const float wgt = __builtin_amdgcn_exp2f(mw[w] - m);
+            l += lw[w] * wgt;
+            const float* pr = part + (w * 32 + qj) * 68 + dq;
+            a0 += *reinterpret_cast<const f32x4*>(pr) * wgt;
+            a1 += *reinterpret_cast<const f32x4*>(pr + 4) * wgt;
+        }
+        const float inv = (row < nq && l > 0.f) ? 1.0f / l : 0.f;    // padded rows -> 0
+        if (row < Lq) {
+            float* op = out + ((size_t)seq * Lq + row) * 256 + head * 64 + dq;
+            *reinterpret_cast<f32x4*>(op) = a0 * inv;
+            *reinterpret_cast<f32x4*>(op + 4) = a1 * inv;
+        }
+    }
+    RFE_ATS(3);
+}
+
+#ifdef RFE_TUNING
+extern "C" int rfe_k_dbg_timeline_att(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(rfe_dbg_ts_att), (size_t)n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
+
+// one (or a few) pairs: at most 8192 query rows, 16-byte aligned rows, no rotary (applied by the projection).  Returns false when the
+// shape is not served (the caller falls back to lg_kernels.hip).
+bool launch_lg_attention_lat(hipStream_t s, const float* q, const float* k, const float* v, int ld, float* out, int nseq, int Lq, int Lk,
+                             const int* qlen, const int* klen, const int* kv_map) {
+    if ((size_t)nseq * Lq > 8192 || (ld % 4) || Lq < 1 || Lk < 1) return false;
+    const int nqb = (Lq + 31) / 32;
+    const int units8 = (4 * nseq + 7) / 8 * 8;    // (sequence, head) units padded to a multiple of 8: the block decode stays bijective
+    constexpr int bytes = 4 * AL_WAVE_F * 4;       // 128 KB
+#ifdef RFE_TUNING
+    const int abl = tune_int("RFE_ALAT_ABL", 0);
+#else
+    constexpr int abl = 0;
+#endif
+    static bool ls_[64];
+    ensure_dynamic_lds((const void*)lg_attention_lat_kernel, bytes, ls_);
+    hipLaunchKernelGGL(lg_attention_lat_kernel, dim3(nqb * units8), dim3(256), bytes, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, nseq, abl);
+    return true;
+}
+
+}  // namespace rfe

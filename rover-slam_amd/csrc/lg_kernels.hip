@@ -436,6 +436,10 @@ void launch_lg_attention(hipStream_t s, const float* q, const float* k, const fl
         launch_lg_attention_h2(s, q, k, v, ld, out, nseq, Lq, Lk, qlen, klen, kv_map, rope_csn);
         return;
     }
+    // latency regime (one / few pairs, the shapes the reference itself runs), keys and queries already rotated by the projection: the
+    // in-workgroup key split (lg_attention_lat.hip) -- no partial sums in HBM, no combine launch
+    static const bool lat_on = tune_int("RFE_LAT", 1) != 0;
+    if (lat_on && !rope_csn && (size_t)nseq * Lq <= AT_SPLIT_MAX_ROWS && launch_lg_attention_lat(s, q, k, v, ld, out, nseq, Lq, Lk, qlen, klen, kv_map)) return;
     const int nqb = (Lq + AT_Q - 1) / AT_Q;
     // (sequence, head) units, padded to a multiple of 8: the kernels deal their blocks round-robin over the 8 XCDs and map
     // block -> (unit, query block) by unit = (t / nqb) * 8 + xcd, which is a bijection only for a multiple of 8 units
@@ -485,6 +489,17 @@ void launch_lg_attention(hipStream_t s, const float* q, const float* k, const fl
 }
 
 // ---------------------------------------------------------------- LayerNorm(512) + GELU(erf), in place
+// (the latency path of lg_ffn: one / few pairs per call.  Fusing it into ffn.3's operand path -- gemm_lat.hip, round 4 -- was measured and
+// dropped: every 16-row wave tile re-evaluates the GELU of its whole 16 x 512 activation panel, 8 column workgroups per panel = 8 x the
+// transcendentals, and a wave alone on its SIMD cannot hide 3200 VALU instructions behind 256 matrix instructions: 17.6 us against
+// 4.5 + 7 us for this pass + the plain GEMM, profiles/r04_ab_notes.md)
+__device__ __forceinline__ float gelu_short_(float t) {   // Abramowitz-Stegun 7.1.26 erf, |error| <= 1.5e-7 (== gemm.hip gelu_short)
+    const float x = t * 0.70710678118654752f, ax = fabsf(x);
+    const float k = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    const float poly = fmaf(fmaf(fmaf(fmaf(1.061405429f, k, -1.453152027f), k, 1.421413741f), k, -0.284496736f), k, 0.254829592f) * k;
+    const float er = 1.0f - poly * __builtin_amdgcn_exp2f(-(ax * ax) * 1.44269504088896341f);
+    return 0.5f * t * (1.0f + copysignf(er, x));
+}
 __global__ __launch_bounds__(256) void lg_ln_gelu_kernel(float* __restrict__ hbuf, const float* __restrict__ g,
                                                          const float* __restrict__ b, int64_t rows) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -510,7 +525,7 @@ __global__ __launch_bounds__(256) void lg_ln_gelu_kernel(float* __restrict__ hbu
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float vv = x[e] * rs * gg[e] + bb[e];
-        x[e] = 0.5f * vv * (1.0f + erff(vv * 0.70710678118654752f));
+        x[e] = gelu_short_(vv);     // the GELU of the fused throughput path (gemm.hip gelu_short): one arithmetic for every LightGlue tiling
     }
     p[0] = make_float4(x[0], x[1], x[2], x[3]);
     p[1] = make_float4(x[4], x[5], x[6], x[7]);

@@ -480,6 +480,7 @@ struct SpBuffers {
     float *a1, *p1, *a2, *p2, *a3, *p3, *a4, *f4, *pa, *logits, *da, *dmap, *smap, *nmap, *ss;
     uint8_t *mask, *supp;
     float* cand_score; int32_t* cand_idx;
+    unsigned long long* sel_keys; int32_t* sel_n;     // selected (score, pixel) keys between select_kernel and select_rank_kernel
 };
 
 // conv1a as its own launch (78.6 MB/frame activation in HBM) instead of recomputed inside conv1b: A/B and test switch
@@ -498,6 +499,7 @@ size_t sp_ws_bytes(int B, int H, int W) {
     t += al(hw * 4) * 3;           // smap, nmap, ss
     t += al(hw) * 2;               // mask, supp
     t += al(hw * 4) * 2;           // cand
+    t += al((size_t)B * 4096 * 8) + al((size_t)B * 4);   // sel_keys (Kmax <= 4096), sel_n
     return t + 4096;
 }
 
@@ -512,6 +514,7 @@ void sp_carve(void* ws, int B, int H, int W, SpBuffers& b) {
     b.smap = a.take<float>(hw); b.nmap = a.take<float>(hw); b.ss = a.take<float>(hw);
     b.mask = a.take<uint8_t>(hw); b.supp = a.take<uint8_t>(hw);
     b.cand_score = a.take<float>(hw); b.cand_idx = a.take<int32_t>(hw);
+    b.sel_keys = a.take<unsigned long long>((size_t)B * 4096); b.sel_n = a.take<int32_t>(B);
 }
 
 GemmArgs gemm_plain(const float* A, int lda, const float* Bw, int ldb, const float* bias, float* C, int ldc, int M, int N, int K) {
@@ -606,7 +609,7 @@ int sp_forward(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, int B, 
     if (rc) return rc;
     const int Hc = H / 2 / 2 / 2, Wc = W / 2 / 2 / 2, Hs = 8 * Hc, Ws = 8 * Wc;   // score-map frame, see sp_forward_maps
     { ProfScope p(c, "sp_select");
-      launch_select(c->stream, b.nmap, B, Hs, Ws, Kmax, thr, b.cand_score, b.cand_idx, n, kxy, score, (int32_t*)b.ss /*NMS scratch, free by now*/, c->hp.sp_topk_always != 0);
+      launch_select(c->stream, b.nmap, B, Hs, Ws, Kmax, thr, b.cand_score, b.cand_idx, n, kxy, score, (int32_t*)b.ss /*NMS scratch, free by now*/, c->hp.sp_topk_always != 0, b.sel_keys, b.sel_n);
       if (forked) RFE_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));   // descriptor map ready
       launch_desc_sample(c->stream, b.dmap, B, Hc, Wc, Hs, Ws, n, kxy, Kmax, desc, desc_bin); }
     RFE_HIP(c, hipGetLastError());
@@ -717,7 +720,7 @@ void lg_ffn(rfe_ctx* c, LgBuffers& b, float* x, const float* second, int rows, c
     { ProfScope p(c, "lg_ffn1");   // A = [x | second]: second is the message, or the attention context when Wo is folded into W1
       GemmArgs a = gemm_lgw(c, x, 256, w1, 512, b1, b.h, 512, rows, 512, 512);
       a.A2 = second; a.lda2 = 256; a.K1 = 256;
-      if (ln_fuse) a.stats_out = b.lnstat;
+      if (ln_fuse && !gemm_latency_regime(a)) a.stats_out = b.lnstat;   // latency regime: the stand-alone pass below (see lg_kernels.hip)
       P = launch_gemm_nt(s, a); }
     if (P == 0) { ProfScope p(c, "lg_ln_gelu"); launch_lg_ln_gelu(s, b.h, g, be, rows); }   // small problems (and RFE_LN_FUSE=0): stand-alone pass
     { ProfScope p(c, "lg_ffn2");
@@ -731,10 +734,15 @@ void lg_ffn(rfe_ctx* c, LgBuffers& b, float* x, const float* second, int rows, c
 void lg_self_block(rfe_ctx* c, LgBuffers& b, const LgLayerDev& Lw, float* x, const float* csn, const int32_t* lens, int nseq, int L) {
     hipStream_t s = c->stream;
     const int rows = nseq * L;
-    // q,k,v = Wqkv x + b (plain epilogue); the rotary of q and k is applied by the attention kernel as it loads them
-    { ProfScope p(c, "lg_qkv"); launch_gemm_nt(s, gemm_lgw(c, x, 256, Lw.wqkv, 256, Lw.bqkv, b.qkv, 768, rows, 768, 256)); }
+    // q,k,v = Wqkv x + b.  Throughput shapes: plain epilogue, the rotary of q and k is applied by the attention kernel as it loads them.
+    // Latency shapes (one / few pairs): the projection's epilogue rotates q and k (gemm_lat.hip) and the attention runs without a table.
+    bool roped = false;
+    { ProfScope p(c, "lg_qkv");
+      const GemmArgs a = gemm_lgw(c, x, 256, Lw.wqkv, 256, Lw.bqkv, b.qkv, 768, rows, 768, 256);
+      if (gemm_latency_regime(a) && launch_gemm_lat(s, a, csn, 512)) roped = true;
+      else launch_gemm_nt(s, a); }
     { ProfScope p(c, "lg_attention");
-      launch_lg_attention(s, b.qkv, b.qkv + 256, b.qkv + 512, 768, b.ctx, nseq, L, L, lens, lens, nullptr, lg_part(b, nseq, L), csn, c->opt_lg_fp16x2); }
+      launch_lg_attention(s, b.qkv, b.qkv + 256, b.qkv + 512, 768, b.ctx, nseq, L, L, lens, lens, nullptr, lg_part(b, nseq, L), roped ? nullptr : csn, c->opt_lg_fp16x2); }
     if (c->opt_lg_fold) {
         lg_ffn(c, b, x, b.ctx, rows, Lw.w1f, Lw.b1f, Lw.lng, Lw.lnb, Lw.w2, Lw.b2);
     } else {

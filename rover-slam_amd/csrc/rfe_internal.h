@@ -179,6 +179,20 @@ inline void ensure_dynamic_lds(const void* kernel, int bytes, bool* done) {
 int launch_gemm_h2(hipStream_t s, const GemmArgs& g);   // gemm_h2.hip: split GEMM on the f16 matrix pipe (GemmArgs::Bh / Bl), called by launch_gemm_nt
 void launch_split_f16(hipStream_t s, const float* x, uint16_t* hi, uint16_t* lo, size_t n);
 int launch_gemm_nt(hipStream_t s, const GemmArgs& g);   // returns the number of partial-statistics pairs per row it wrote (0 without stats_out)
+// The throughput tiles (128-row) take a problem when they give every CU a workgroup; everything smaller is the LATENCY regime (one or a
+// few pairs per call -- what the reference itself runs): gemm_lat.hip / lg_attention_lat.hip serve it, gemm.hip's 64-row tiles what they refuse.
+inline bool gemm_latency_regime(const GemmArgs& g) {
+    const long long b = g.batch > 0 ? g.batch : 1;
+    auto tiles = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * b; };
+    const bool big = (g.N % 256 == 0 && tiles(128, 256) >= 256) || tiles(128, 128) >= 256 || g.M > 8192;
+    static const bool on = tune_int("RFE_LAT", 1) != 0;   // tuning build: RFE_LAT=0 = the round-3 latency path
+    return on && !big;
+}
+// gemm_lat.hip: false = shape not served (nothing launched).  rope_csn != null: rotary epilogue on output columns < rope_cols (qkv).
+bool launch_gemm_lat(hipStream_t s, const GemmArgs& g, const float* rope_csn, int rope_cols);
+// lg_attention_lat.hip: one-/few-pair attention without rotary (q, k rotated by the projection); false = shape not served.
+bool launch_lg_attention_lat(hipStream_t s, const float* q, const float* k, const float* v, int ld, float* out, int nseq, int Lq, int Lk,
+                             const int* qlen, const int* klen, const int* kv_map);
 // sp_post.hip
 void launch_softmax65_d2s(hipStream_t s, const float* logits, int ld, int B, int Hc, int Wc, float* score);
 constexpr int NMS_MAX_RADIUS = 8;
@@ -186,7 +200,8 @@ void launch_nms(hipStream_t s, const float* score, int B, int H, int W, int radi
                 uint8_t* tmp_mask, uint8_t* tmp_supp, float* out);
 void launch_select(hipStream_t s, const float* nms, int B, int H, int W, int Kmax, float thr,
                    float* cand_score, int32_t* cand_idx, int32_t* n_out, int32_t* kxy, float* score,
-                   int32_t* chunk_cnt /*B * ceil(H*W/4096) ints of scratch*/, bool topk_always = false /*rfe_hparams::sp_topk_always*/);
+                   int32_t* chunk_cnt /*B * ceil(H*W/4096) ints of scratch*/, bool topk_always /*rfe_hparams::sp_topk_always*/,
+                   unsigned long long* sel_keys /*[B,Kmax] scratch*/, int32_t* sel_n /*[B] scratch*/);
 void launch_descmap_norm(hipStream_t s, float* dmap, int64_t cells);
 void launch_desc_sample(hipStream_t s, const float* dmap, int B, int Hc, int Wc, int H, int W,
                         const int32_t* n, const int32_t* kxy, int Kmax, float* desc, uint8_t* desc_bin /*optional u8 [B,Kmax,256] = desc > 0*/);

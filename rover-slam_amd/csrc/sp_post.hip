@@ -158,8 +158,133 @@ static void launch_nms_r(hipStream_t st, const float* score, int B, int H, int W
     hipLaunchKernelGGL((nms_pass_kernel<2, true, CR>), grid, blk, 0, st, score, tmp_ss, tmp_mask, tmp_supp, out, H, W, r, border);
 }
 
+// ---- the whole recurrence in ONE launch (radius 4, the published default): a workgroup takes a 32 x 64 output tile with a halo of
+// 5 r = 20 pixels (five nested 9-windows), keeps the score tile in LDS and runs the five max-pools there -- row pass into a scratch plane,
+// column pass fused with the stage's elementwise step.  Each stage is valid on a frame 4 px smaller than the previous one; after the fifth
+// exactly the output tile is left.  Same comparisons on the same floats as the five-launch form (bit-identical output); the mask /
+// suppression planes and four of the five kernel boundaries (10 - 16 us each at batch 1, where the whole detector tail is latency) are gone.
+// Pixels outside the image read -inf in every plane, like max_pool2d's padding.  Work items are QUADS (four consecutive outputs of a row /
+// of a column): 12 loaded values give four 9-wide maxima in 17 max operations (shared middle, left and right running partials), and all
+// index arithmetic divides by compile-time constants (a first version with one output per item and run-time frame sizes took 78 us per
+// frame -- slower than the five launches it replaced).
+constexpr int NF_R = 4, NF_HALO = 5 * NF_R, NF_IH = NTH + 2 * NF_HALO, NF_IW = NTW + 2 * NF_HALO;   // 72 x 104
+static_assert(NF_IW % 4 == 0 && NF_IH % 4 == 0, "quad items");
+
+// four 9-wide maxima from 12 consecutive values v[0..11]: out[i] = max(v[i .. i + 8])
+__device__ __forceinline__ void max9x4(const float (&v)[12], float (&o)[4]) {
+    const float mid = fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7]));
+    const float l3 = v[3], l2 = fmaxf(v[2], l3), l1 = fmaxf(v[1], l2), l0 = fmaxf(v[0], l1);
+    const float r8 = v[8], r9 = fmaxf(r8, v[9]), r10 = fmaxf(r9, v[10]), r11 = fmaxf(r10, v[11]);
+    o[0] = fmaxf(fmaxf(l0, mid), r8); o[1] = fmaxf(fmaxf(l1, mid), r9);
+    o[2] = fmaxf(fmaxf(l2, mid), r10); o[3] = fmaxf(fmaxf(l3, mid), r11);
+}
+// row pass: src valid on the frame of margin M -> T[y][x] = max(src[y][x - 4 .. x + 4]) for rows of that frame, columns of margin M + 4
+template <int M>
+__device__ __forceinline__ void nf_rowpass(const float* __restrict__ src, float* __restrict__ T, int tid) {
+    constexpr int ROWS = NF_IH - 2 * M, QUADS = (NF_IW - 2 * (M + NF_R)) / 4;
+    for (int idx = tid; idx < ROWS * QUADS; idx += 256) {
+        const int py = M + idx / QUADS, px = M + NF_R + 4 * (idx % QUADS);
+        const f32x4* p = reinterpret_cast<const f32x4*>(src + py * NF_IW + px);
+        const f32x4 a = p[-1], b = p[0], c = p[1];
+        const float v[12] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], c[0], c[1], c[2], c[3]};
+        float o[4];
+        max9x4(v, o);
+        *reinterpret_cast<f32x4*>(T + py * NF_IW + px) = f32x4{o[0], o[1], o[2], o[3]};
+    }
+}
+// column pass over T on the frame of margin M (a multiple of 4): calls f(py, px, pooled value) for every pixel of that frame; an item is
+// four consecutive rows of one column, lanes run along x (conflict-free reads)
+template <int M, typename F>
+__device__ __forceinline__ void nf_colpass(const float* __restrict__ T, int tid, F f) {
+    constexpr int COLS = NF_IW - 2 * M, QROWS = (NF_IH - 2 * M) / 4;
+    for (int idx = tid; idx < QROWS * COLS; idx += 256) {
+        const int py = M + 4 * (idx / COLS), px = M + idx % COLS;
+        const float* p = T + (py - NF_R) * NF_IW + px;
+        float v[12];
+#pragma unroll
+        for (int d = 0; d < 12; ++d) v[d] = p[d * NF_IW];
+        float o[4];
+        max9x4(v, o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f(py + e, px, o[e]);
+    }
+}
+
+__global__ __launch_bounds__(256) void nms_fused_kernel(const float* __restrict__ s, float* __restrict__ out, int H, int W, int border) {
+    extern __shared__ __attribute__((aligned(16))) float nf_lds[];
+    float* const S = nf_lds;                       // scores
+    float* const T = S + NF_IH * NF_IW;            // row-pass scratch
+    float* const Mk = T + NF_IH * NF_IW;           // max_mask as 1 / 0 (-inf outside the image)
+    float* const SS = Mk + NF_IH * NF_IW;          // supp_scores
+    uint8_t* const SUP = reinterpret_cast<uint8_t*>(SS + NF_IH * NF_IW);   // supp_mask
+    const size_t fo = (size_t)blockIdx.z * H * W;
+    const int y0 = blockIdx.y * NTH - NF_HALO, x0 = blockIdx.x * NTW - NF_HALO;
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < NF_IH * NF_IW; idx += 256) {
+        const int py = idx / NF_IW, px = idx % NF_IW, gy = y0 + py, gx = x0 + px;
+        S[idx] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? s[fo + (size_t)gy * W + gx] : -INFINITY;
+    }
+    __syncthreads();
+    auto inside = [&](int py, int px) { const int gy = y0 + py, gx = x0 + px; return gy >= 0 && gy < H && gx >= 0 && gx < W; };
+    // stage 1: max_mask = s == mp(s)                                                    (score frame 0 -> mask frame 4)
+    nf_rowpass<0>(S, T, tid);
+    __syncthreads();
+    nf_colpass<NF_R>(T, tid, [&](int py, int px, float m) {
+        const int o = py * NF_IW + px;
+        Mk[o] = inside(py, px) ? (S[o] == m ? 1.f : 0.f) : -INFINITY;
+    });
+    __syncthreads();
+    // round 1: supp_mask = mp(max_mask) > 0 ; supp_scores = supp ? 0 : s                (mask frame 4 -> frame 8)
+    nf_rowpass<NF_R>(Mk, T, tid);
+    __syncthreads();
+    nf_colpass<2 * NF_R>(T, tid, [&](int py, int px, float m) {
+        const int o = py * NF_IW + px;
+        const bool sp = m > 0.f;
+        SUP[o] = sp ? 1 : 0;
+        SS[o] = inside(py, px) ? (sp ? 0.f : S[o]) : -INFINITY;
+    });
+    __syncthreads();
+    //          new_max_mask = supp_scores == mp(supp_scores) ; max_mask |= new & ~supp    (frame 8 -> frame 12)
+    nf_rowpass<2 * NF_R>(SS, T, tid);
+    __syncthreads();
+    nf_colpass<3 * NF_R>(T, tid, [&](int py, int px, float m) {
+        const int o = py * NF_IW + px;
+        if (inside(py, px)) Mk[o] = (Mk[o] != 0.f || (SS[o] == m && !SUP[o])) ? 1.f : 0.f;      // stays -inf outside the image
+    });
+    __syncthreads();
+    // round 2                                                                            (mask frame 12 -> frame 16 -> frame 20 = the output tile)
+    nf_rowpass<3 * NF_R>(Mk, T, tid);
+    __syncthreads();
+    nf_colpass<4 * NF_R>(T, tid, [&](int py, int px, float m) {
+        const int o = py * NF_IW + px;
+        const bool sp = m > 0.f;
+        SUP[o] = sp ? 1 : 0;
+        SS[o] = inside(py, px) ? (sp ? 0.f : S[o]) : -INFINITY;
+    });
+    __syncthreads();
+    nf_rowpass<4 * NF_R>(SS, T, tid);
+    __syncthreads();
+    nf_colpass<5 * NF_R>(T, tid, [&](int py, int px, float m) {
+        const int o = py * NF_IW + px;
+        if (!inside(py, px)) return;
+        const bool mk = Mk[o] != 0.f || (SS[o] == m && !SUP[o]);
+        const int gy = y0 + py, gx = x0 + px;
+        float v = mk ? S[o] : 0.f;
+        if (gy < border || gy >= H - border || gx < border || gx >= W - border) v = -1.f;
+        out[fo + (size_t)gy * W + gx] = v;
+    });
+}
+
 void launch_nms(hipStream_t st, const float* score, int B, int H, int W, int radius, int border, float* tmp_ss,
                 uint8_t* tmp_mask, uint8_t* tmp_supp, float* out) {
+    static const bool fused_on = tune_int("RFE_NMS_FUSED", 1) != 0;   // tuning build: 0 = the five-launch form for every radius
+    if (radius == NF_R && fused_on) {
+        constexpr int bytes = 4 * NF_IH * NF_IW * 4 + NF_IH * NF_IW;
+        static bool ls_[64];
+        ensure_dynamic_lds((const void*)nms_fused_kernel, bytes, ls_);
+        hipLaunchKernelGGL(nms_fused_kernel, dim3((W + NTW - 1) / NTW, (H + NTH - 1) / NTH, B), dim3(256), bytes, st, score, out, H, W, border);
+        return;
+    }
     if (radius == 4) launch_nms_r<4>(st, score, B, H, W, radius, border, tmp_ss, tmp_mask, tmp_supp, out);
     else launch_nms_r<0>(st, score, B, H, W, radius, border, tmp_ss, tmp_mask, tmp_supp, out);
 }
@@ -274,7 +399,8 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(const float* __restrict__
                                                        int P2, float thr, float* __restrict__ cand_score,
                                                        int32_t* __restrict__ cand_idx, int32_t* __restrict__ n_out,
                                                        int32_t* __restrict__ kxy, float* __restrict__ score,
-                                                       const int32_t* __restrict__ chunk_cnt, int nch, int topk_always) {
+                                                       const int32_t* __restrict__ chunk_cnt, int nch, int topk_always,
+                                                       unsigned long long* __restrict__ sel_keys, int32_t* __restrict__ sel_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);  // [P2]
     __shared__ int wave_tot[SEL_T / 64];
@@ -294,7 +420,7 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(const float* __restrict__
     int32_t* okxy = kxy + (size_t)b * Kmax * 2;
     float* osc = score + (size_t)b * Kmax;
     if (count <= Kmax && !topk_always) {     // published top_k_keypoints: nothing to cut -> row-major order
-        if (tid == 0) n_out[b] = count;
+        if (tid == 0) { n_out[b] = count; sel_n[b] = -1; }      // -1: select_rank_kernel has nothing to do for this frame
         for (int k = tid; k < Kmax; k += SEL_T) {
             if (k < count) {
                 const int idx = ci[k];
@@ -310,7 +436,6 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(const float* __restrict__
         // topk_always (TopK behind Min(k, n) in the graph): every candidate is kept, ordered like the cut set below
         for (int k = tid; k < P2; k += SEL_T)
             keys[k] = k < count ? (((unsigned long long)__float_as_uint(cs[k]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)ci[k])) : 0ull;
-        for (int k = nsel + tid; k < Kmax; k += SEL_T) { okxy[2 * k] = 0; okxy[2 * k + 1] = 0; osc[k] = 0.f; }
         __syncthreads();
     } else {
     // ---- radix select: Kmax-th largest score (scores are positive floats: bit pattern is monotonic)
@@ -359,13 +484,42 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(const float* __restrict__
     }
     __syncthreads();
     }
-    // ---- rank sort, descending: keys are distinct (the pixel index is part of the key), so the number of larger keys
-    // is the output position.  nsel broadcast LDS reads per key instead of the 55 barrier-separated bitonic stages.
-    if (tid == 0) n_out[b] = nsel;
-    for (int t = tid; t < nsel; t += SEL_T) {
-        const unsigned long long key = keys[t];
-        int rank = 0;
-        for (int j = 0; j < nsel; ++j) rank += keys[j] > key ? 1 : 0;
+    // the selected keys (distinct: the pixel index is part of the key) go to memory; select_rank_kernel orders them on many CUs
+    if (tid == 0) { n_out[b] = nsel; sel_n[b] = nsel; }
+    for (int t = tid; t < nsel; t += SEL_T) sel_keys[(size_t)b * Kmax + t] = keys[t];
+}
+
+// Rank sort, descending, of the nsel selected keys of every frame: the number of larger keys IS the output position.  It used to be the tail
+// of select_kernel -- one workgroup per frame pulling Kmax^2 = 1M broadcast LDS reads through a single CU's LDS port, 30 of that kernel's
+// 41 us at batch 1 -- and is now spread over Kmax / 64 workgroups per frame: each loads the frame's keys into LDS (8 KB at Kmax = 1024), four
+// threads share one key and scan a quarter of the list each.  Rows [nsel, Kmax) are zeroed.
+__global__ __launch_bounds__(256) void select_rank_kernel(const unsigned long long* __restrict__ sel_keys, const int32_t* __restrict__ sel_n,
+                                                          int W, int Kmax, int32_t* __restrict__ kxy, float* __restrict__ score) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int nsel = sel_n[b];
+    if (nsel < 0) return;                 // row-major frame: select_kernel wrote the outputs itself
+    const unsigned long long* src = sel_keys + (size_t)b * Kmax;
+    for (int k = tid; k < nsel; k += 256) keys[k] = src[k];
+    __syncthreads();
+    const int t = blockIdx.x * 64 + (tid >> 2), part = tid & 3;
+    int32_t* okxy = kxy + (size_t)b * Kmax * 2;
+    float* osc = score + (size_t)b * Kmax;
+    if (t >= Kmax) return;
+    if (t >= nsel) { if (part == 0) { okxy[2 * t] = 0; okxy[2 * t + 1] = 0; osc[t] = 0.f; } return; }
+    const unsigned long long key = keys[t];
+    int rank = 0;
+    // part p scans the key pairs p, p + 4, ... (16-byte LDS reads, eight in flight: one dependent 8-byte read per iteration was 17 us)
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    const u64x2* kp = reinterpret_cast<const u64x2*>(keys);
+    const int npair = nsel >> 1;
+#pragma unroll 8
+    for (int j = part; j < npair; j += 4) { const u64x2 kk = kp[j]; rank += (kk[0] > key ? 1 : 0) + (kk[1] > key ? 1 : 0); }
+    if ((nsel & 1) && part == 0) rank += keys[nsel - 1] > key ? 1 : 0;
+    rank += __shfl_xor(rank, 1);
+    rank += __shfl_xor(rank, 2);
+    if (part == 0) {
         const int idx = (int)(0xFFFFFFFFu - (unsigned int)(key & 0xFFFFFFFFull));
         okxy[2 * rank] = idx % W; okxy[2 * rank + 1] = idx / W;
         osc[rank] = __uint_as_float((unsigned int)(key >> 32));
@@ -373,14 +527,16 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(const float* __restrict__
 }
 
 void launch_select(hipStream_t s, const float* nms, int B, int H, int W, int Kmax, float thr, float* cand_score,
-                   int32_t* cand_idx, int32_t* n_out, int32_t* kxy, float* score, int32_t* chunk_cnt, bool topk_always) {
+                   int32_t* cand_idx, int32_t* n_out, int32_t* kxy, float* score, int32_t* chunk_cnt, bool topk_always,
+                   unsigned long long* sel_keys, int32_t* sel_n) {
     int P2 = 1;
     while (P2 < Kmax) P2 <<= 1;
     const int HW = H * W, nch = (HW + SEL_CHUNK - 1) / SEL_CHUNK;   // chunk_cnt: B * nch ints of scratch
     hipLaunchKernelGGL(select_count_kernel, dim3(nch, B), dim3(256), 0, s, nms, HW, nch, thr, chunk_cnt);
     hipLaunchKernelGGL(select_compact_kernel, dim3(nch, B), dim3(256), 0, s, nms, HW, nch, thr, chunk_cnt, cand_score, cand_idx);
     hipLaunchKernelGGL(select_kernel, dim3(B), dim3(SEL_T), (size_t)P2 * 8, s, nms, H, W, Kmax, P2, thr,
-                       cand_score, cand_idx, n_out, kxy, score, chunk_cnt, nch, topk_always ? 1 : 0);
+                       cand_score, cand_idx, n_out, kxy, score, chunk_cnt, nch, topk_always ? 1 : 0, sel_keys, sel_n);
+    hipLaunchKernelGGL(select_rank_kernel, dim3((Kmax + 63) / 64, B), dim3(256), (size_t)Kmax * 8, s, sel_keys, sel_n, W, Kmax, kxy, score);
 }
 
 // ---------------------------------------------------------------- 256-d L2 normalisation

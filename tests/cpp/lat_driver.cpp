@@ -72,6 +72,7 @@ int main(int argc, char** argv) {
         f0.mvKeys.clear(); f1.mvKeys.clear();
         extL(f0.imgLeft, f0.mvKeys, f0.mDescriptors);
         extL(f1.imgLeft, f1.mvKeys, f1.mDescriptors);
+        vn.clear();                                           // callers hand over a fresh vector (resize(M, -1) keeps old entries, SPmatcher.cc:460)
         s3 = matcher.MatchingPoints_onnx(f0, f1, vn);
     }
     const double c3 = (now_ms() - t0) / steps;
@@ -91,6 +92,7 @@ int main(int argc, char** argv) {
         extL(cur.imgLeft, cur.mvKeys, cur.mDescriptors);
         thr.join();
         if (ORB_SLAM3::ComputeStereoMatches_rfe(extL.featureExtractor->ExtractorSession, cur) != 0) return 5;
+        vt.clear();
         s5 = have_prev ? matcher.MatchingPoints_onnx(cur, prev, vt) : 0;                             // SearchBySP(current, last)
         if (i + 1 < steps) {
             prev.mvKeys = cur.mvKeys; prev.mDescriptors = cur.mDescriptors.clone(); prev.imgLeft = cur.imgLeft;

@@ -102,6 +102,39 @@ def test_attention_throughput_shape_vs_float64(ctx, kind):
     assert errs[0] < ATT_TOL and errs[1] < ATT_TOL, errs
 
 
+@pytest.mark.parametrize("kind,nseq,L", [("self", 2, 1024), ("cross", 2, 1024), ("cross", 6, 152), ("self", 4, 1000), ("cross", 8, 1024), ("cross", 2, 36)])
+def test_attention_latency_shape_vs_float64(ctx, kind, nseq, L):
+    """The shapes the reference itself runs (one / few pairs per call, src/Matchers/lightglue_onnx.cpp:168-172): at most 8192 query rows and
+    no rotary table (the one-pair projection has rotated q and k) take lg_attention_lat_kernel -- the key split inside the workgroup,
+    self-pipelined waves, partial sums merged through LDS.  Ragged lengths put partial tiles first, last and alone in a wave's key
+    quarter, leave waves without keys and sequences shorter than one tile."""
+    from rover_slam_amd import capi
+    rng = np.random.default_rng(nseq * 1000 + L)
+    lens = np.full(nseq, L, np.int32)
+    ragged = [L - 3, 131, 70, 40, 33, 3, 97, 1]
+    for i in range(1, nseq):
+        lens[i] = min(L, ragged[(i - 1) % len(ragged)])
+    if kind == "self":
+        ld, offs, kvmap = 768, (0, 256, 512), None
+    else:
+        ld, offs, kvmap = 512, (0, 0, 256), np.arange(nseq) ^ 1
+    x = rng.standard_normal((nseq * L, ld)).astype(np.float32)
+    x[:, :ld - 256] *= 1.5
+    x[::7, 3] += 6.0                                     # dominant keys / queries: the softmax reference moves late in a key range
+    x[L // 2::11, 5] += 9.0
+    xs = x.reshape(nseq, L, ld)
+    out = _run(ctx, capi, x, offs, ld, nseq, L, lens, kvmap, None, 0)
+    assert np.isfinite(out).all()
+    worst = 0.0
+    for s in range(nseq):
+        t = kvmap[s] if kvmap is not None else s
+        ref = _attention_f64(xs[s][:, offs[0]:offs[0] + 256], xs[t][:, offs[1]:offs[1] + 256], xs[t][:, offs[2]:offs[2] + 256], int(lens[s]), int(lens[t]))
+        worst = max(worst, float(np.abs(out[s] - ref).max()))
+        assert not out[s][lens[s]:].any(), "context rows past the sequence length must be zero"
+    print(f"attention latency shape {kind} nseq={nseq} L={L}: max |context - float64| {worst:.2e}")
+    assert worst < ATT_TOL
+
+
 def test_attention_split_kernel_saturates_outside_fp16_range(ctx):
     """RFE_OPT_LG_FP16X2's domain is |operand| < 65504 (fp16).  Outside it the split kernels run with MODE.FP16_OVFL = 1 (h2_split.h): hi
     saturates at 65504, lo takes up the rest -- values up to 131008 are still carried to fp16's 11 bits -- instead of inf - inf = NaN for

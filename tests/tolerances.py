@@ -18,7 +18,11 @@ one where the ORACLE sits 2.6e-4 from float64 and the HIP path 7e-5): 1e-4 is be
 size, and the fold does not change the picture.  Final token states agree to 1e-5 (bar 1e-4).
 """
 LG_SCORE_TOL = 5e-4         # |match score difference|, any keypoint count up to 1024
-LG_SCORE_TOL_SMALL = 1e-4   # <= 256 keypoints per side
+LG_SCORE_TOL_SMALL = 2e-4   # <= 256 keypoints per side.  Round 4 (profiles/r04_lg_tolerance_k256.md, 20 cases at K <= 256): the ORACLE sits up to 1.19e-4
+                            # from the float64 evaluation of the same graph, the HIP path 1.27e-4 from the oracle and 1.54e-4 from float64 (match lists
+                            # identical in every case) -- a 1e-4 bar against the oracle was below the noise floor of fp32 here too; it held in rounds
+                            # 1-3 only because the one-pair GEMM tiles happened to sum k in the oracle's order (bit-identical Linears), which the
+                            # 16x16x4 latency tiling (gemm_lat.hip: k permuted inside 16-k groups, LayerNorm + GELU fused) no longer does
 LG_STATE_TOL = 1e-4         # final token states x0 / x1
 LG_LOGSCORE_RTOL = 1e-5     # log-domain assignment matrix relative to its largest magnitude (|values| up to ~450, one fp32
                             # ulp there is 3e-5; measured 2.4e-3 absolute = 5.4e-6 relative)
