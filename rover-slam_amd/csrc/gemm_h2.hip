@@ -63,6 +63,10 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GemmArgs g) {
     unsigned char* const As = lds;                    // [2 planes][BM][64 B]
     unsigned char* const Bs = lds + 2 * BM * 64;      // [2 planes][BN][64 B] (DMA: x 2 buffers)
     const int tid = threadIdx.x, lane = tid & 63;
+    // Activations are split while they are staged (h2_split2): with the default mode one |a| >= 65520 becomes inf and lo = inf - inf = NaN for
+    // its whole output row.  MODE.FP16_OVFL saturates instead (h2_split.h) -- set for the variants without the fused LayerNorm + GELU, where it
+    // measured free (round-3 advisor finding; the LNA variant's operand has just been through a LayerNorm, |a| is O(10))
+    if (!LNA) h2_saturate_mode();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int i = lane & 31, h = lane >> 5;

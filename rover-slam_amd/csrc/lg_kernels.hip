@@ -290,8 +290,13 @@ __global__ __launch_bounds__(256, 4) void lg_attention_dma_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld, float* __restrict__ out,
     int Lq, int Lk, int nqb, const int* __restrict__ qlen, const int* __restrict__ klen, const int* __restrict__ kv_map,
     int prio, int nseq_total) {
-    __shared__ __attribute__((aligned(16))) float Kd[2][AD_K * 64];
-    __shared__ __attribute__((aligned(16))) float Vd[2][AD_K * 64];
+    // Dynamic LDS on purpose: with static `__shared__ float Kd[2][..]` tiles the compiler's wait-count pass cannot tell buffer buf from
+    // buf ^ 1 and puts an s_waitcnt vmcnt(0) in front of the first ds_read of tile t -- i.e. AFTER tile t + 1 has just been requested, so
+    // every wave sat out that round trip and nothing overlapped (round-3 advisor finding, visible in the ISA).  With one dynamic array and
+    // the explicit wait + barrier below, the only vmcnt wait of the loop is the one that covers tile t.
+    extern __shared__ __attribute__((aligned(16))) float ad_lds[];
+    float (*Kd)[AD_K * 64] = reinterpret_cast<float (*)[AD_K * 64]>(ad_lds);
+    float (*Vd)[AD_K * 64] = reinterpret_cast<float (*)[AD_K * 64]>(ad_lds + 2 * AD_K * 64);
     const int Lb = blockIdx.x, xcd = Lb & 7, t_ = Lb >> 3;
     const int qb = t_ % nqb, unit = (t_ / nqb) * 8 + xcd;
     if (unit >= 4 * nseq_total) return;
@@ -321,6 +326,7 @@ __global__ __launch_bounds__(256, 4) void lg_attention_dma_kernel(
             qreg[4 * g] = t.x * kScale; qreg[4 * g + 1] = t.y * kScale; qreg[4 * g + 2] = t.z * kScale; qreg[4 * g + 3] = t.w * kScale;
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // Q is in: from here on the vector-memory counter only sees tile copies
     f32x16 o0, o1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
@@ -346,7 +352,8 @@ __global__ __launch_bounds__(256, 4) void lg_attention_dma_kernel(
     int buf = 0;
     const int jsw = j & 15;
     for (int k0 = 0; k0 < nk; k0 += AD_K) {
-        __syncthreads();   // tile k0 has landed (vmcnt(0) in front of the barrier, every wave); the other buffer is no longer read
+        // tile k0 has landed (this wave's copies: the wait; everybody's: the barrier) and the other buffer is no longer read
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (k0 + AD_K < nk) issue(k0 + AD_K, buf ^ 1);
         f32x16 st;
         const bool first = k0 == 0;
@@ -481,7 +488,7 @@ void launch_lg_attention(hipStream_t s, const float* q, const float* k, const fl
     static const int prio = tune_int("RFE_ATT_PRIO", 1);   // s_setprio(1) around the MFMA clusters (+0.8 %); RFE_ATT_PRIO=0 disables
     static const bool dma = tune_int("RFE_ATT_DMA", 1) != 0;   // tuning switch: 0 = register-staged tiles for the cross blocks too
     if (!rope && dma && (ld % 4) == 0)
-        hipLaunchKernelGGL(lg_attention_dma_kernel, dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nseq);
+        hipLaunchKernelGGL(lg_attention_dma_kernel, dim3(nqb * units8), dim3(256), 4 * AD_K * 64 * sizeof(float), s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nseq);
     else if (rope)
         hipLaunchKernelGGL((lg_attention_kernel<0, false, true>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nullptr, nseq, rope_csn);
     else
