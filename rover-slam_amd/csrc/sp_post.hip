@@ -277,8 +277,10 @@ __global__ __launch_bounds__(256) void nms_fused_kernel(const float* __restrict_
 
 void launch_nms(hipStream_t st, const float* score, int B, int H, int W, int radius, int border, float* tmp_ss,
                 uint8_t* tmp_mask, uint8_t* tmp_supp, float* out) {
-    static const bool fused_on = tune_int("RFE_NMS_FUSED", 1) != 0;   // tuning build: 0 = the five-launch form for every radius
-    if (radius == NF_R && fused_on) {
+    // One or two frames per call only: the fused kernel needs 127 KB of LDS (one workgroup per CU, 150 tiles per VGA frame -- fine when
+    // there are one or two frames), at 33 frames its 4950 workgroups run in 20 rounds and the five light launches win (0.57 vs 0.25 ms per step)
+    static const int fused_frames = tune_int("RFE_NMS_FUSED", 4);   // tuning build: 0 = the five-launch form at every batch size
+    if (radius == NF_R && B <= fused_frames) {
         constexpr int bytes = 4 * NF_IH * NF_IW * 4 + NF_IH * NF_IW;
         static bool ls_[64];
         ensure_dynamic_lds((const void*)nms_fused_kernel, bytes, ls_);
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(const float* __restrict__
                                                        int32_t* __restrict__ cand_idx, int32_t* __restrict__ n_out,
                                                        int32_t* __restrict__ kxy, float* __restrict__ score,
                                                        const int32_t* __restrict__ chunk_cnt, int nch, int topk_always,
-                                                       unsigned long long* __restrict__ sel_keys, int32_t* __restrict__ sel_n) {
+                                                       unsigned long long* __restrict__ sel_keys, int32_t* __restrict__ sel_n, int min_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);  // [P2]
     __shared__ int wave_tot[SEL_T / 64];
@@ -416,6 +418,7 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(const float* __restrict__
     // candidates were compacted in row-major order by select_count_kernel / select_compact_kernel
     int count = 0;
     for (int c = 0; c < nch; ++c) count += chunk_cnt[b * nch + c];
+    if (count <= min_count) { if (tid == 0) sel_n[b] = -1; return; }   // select_rankall_kernel has done this frame
 
     int32_t* okxy = kxy + (size_t)b * Kmax * 2;
     float* osc = score + (size_t)b * Kmax;
@@ -526,6 +529,62 @@ __global__ __launch_bounds__(256) void select_rank_kernel(const unsigned long lo
     }
 }
 
+// Latency regime (one or two frames per call): selection AND ordering as one rank computation spread over the chip.  Every candidate's
+// rank among ALL candidates of its frame (key = score bits << 32 | ~pixel index, distinct) is the number of larger keys; a candidate with
+// rank < Kmax is a selected keypoint and its rank IS its output row -- no radix select, no single-workgroup tail (select_kernel: 21 us of
+// barriers on one CU, + 5 us of select_rank_kernel).  Workgroup (x, frame) loads the frame's keys into LDS and ranks candidates
+// 64 x .. 64 x + 63, four threads per candidate scanning a quarter of the list each with 16-byte reads.  count <= Kmax without the
+// unconditional top-k: row-major copy (the published top_k_keypoints).  Frames with more than RA_MAX candidates (does not happen after a
+// radius-4 NMS on VGA-class images: at most one survivor per 5 x 5 block) are left to select_kernel / select_rank_kernel, which are
+// launched behind this kernel and return at once otherwise.
+constexpr int RA_MAX = 16384;
+__global__ __launch_bounds__(256) void select_rankall_kernel(const float* __restrict__ cand_score, const int32_t* __restrict__ cand_idx,
+                                                             const int32_t* __restrict__ chunk_cnt, int nch, int HW, int W, int Kmax,
+                                                             int topk_always, int32_t* __restrict__ n_out, int32_t* __restrict__ kxy,
+                                                             float* __restrict__ score) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
+    const int b = blockIdx.y, tid = threadIdx.x;
+    int count = 0;
+    for (int c = 0; c < nch; ++c) count += chunk_cnt[b * nch + c];
+    if (count > RA_MAX) return;
+    const float* cs = cand_score + (size_t)b * HW;
+    const int32_t* ci = cand_idx + (size_t)b * HW;
+    int32_t* okxy = kxy + (size_t)b * Kmax * 2;
+    float* osc = score + (size_t)b * Kmax;
+    const int nsel = count < Kmax ? count : Kmax;
+    if (blockIdx.x == 0 && tid == 0) n_out[b] = nsel;
+    const int t0 = blockIdx.x * 64;
+    if (t0 >= count && t0 >= Kmax) return;
+    // rows [nsel, Kmax) of the padded outputs
+    { const int t = t0 + (tid >> 2); if ((tid & 3) == 0 && t >= nsel && t < Kmax) { okxy[2 * t] = 0; okxy[2 * t + 1] = 0; osc[t] = 0.f; } }
+    if (t0 >= count) return;
+    if (count <= Kmax && !topk_always) {      // nothing to cut: row-major order
+        const int t = t0 + (tid >> 2);
+        if ((tid & 3) == 0 && t < count) { const int idx = ci[t]; okxy[2 * t] = idx % W; okxy[2 * t + 1] = idx / W; osc[t] = cs[t]; }
+        return;
+    }
+    for (int k = tid; k < count; k += 256) keys[k] = ((unsigned long long)__float_as_uint(cs[k]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)ci[k]);
+    __syncthreads();
+    const int t = t0 + (tid >> 2), part = tid & 3;
+    if (t >= count) return;
+    const unsigned long long key = keys[t];
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    const u64x2* kp = reinterpret_cast<const u64x2*>(keys);
+    const int npair = count >> 1;
+    int rank = 0;
+#pragma unroll 8
+    for (int j = part; j < npair; j += 4) { const u64x2 kk = kp[j]; rank += (kk[0] > key ? 1 : 0) + (kk[1] > key ? 1 : 0); }
+    if ((count & 1) && part == 0) rank += keys[count - 1] > key ? 1 : 0;
+    rank += __shfl_xor(rank, 1);
+    rank += __shfl_xor(rank, 2);
+    if (part == 0 && rank < Kmax) {
+        const int idx = (int)(0xFFFFFFFFu - (unsigned int)(key & 0xFFFFFFFFull));
+        okxy[2 * rank] = idx % W; okxy[2 * rank + 1] = idx / W;
+        osc[rank] = __uint_as_float((unsigned int)(key >> 32));
+    }
+}
+
 void launch_select(hipStream_t s, const float* nms, int B, int H, int W, int Kmax, float thr, float* cand_score,
                    int32_t* cand_idx, int32_t* n_out, int32_t* kxy, float* score, int32_t* chunk_cnt, bool topk_always,
                    unsigned long long* sel_keys, int32_t* sel_n) {
@@ -534,8 +593,20 @@ void launch_select(hipStream_t s, const float* nms, int B, int H, int W, int Kma
     const int HW = H * W, nch = (HW + SEL_CHUNK - 1) / SEL_CHUNK;   // chunk_cnt: B * nch ints of scratch
     hipLaunchKernelGGL(select_count_kernel, dim3(nch, B), dim3(256), 0, s, nms, HW, nch, thr, chunk_cnt);
     hipLaunchKernelGGL(select_compact_kernel, dim3(nch, B), dim3(256), 0, s, nms, HW, nch, thr, chunk_cnt, cand_score, cand_idx);
+    // one or two frames: rank-all over the chip; more: one select workgroup per frame already runs the frames in parallel
+    static const int ra_frames = tune_int("RFE_SELECT_RANKALL", 4);   // tuning build: 0 = the radix-select form at every batch size
+    int min_count = -1;
+    if (B <= ra_frames) {
+        const int cap = HW < RA_MAX ? HW : RA_MAX, span = cap > Kmax ? cap : Kmax;
+        static bool ls_[64];
+        ensure_dynamic_lds((const void*)select_rankall_kernel, RA_MAX * 8, ls_);
+        hipLaunchKernelGGL(select_rankall_kernel, dim3((span + 63) / 64, B), dim3(256), (size_t)cap * 8, s, cand_score, cand_idx, chunk_cnt, nch, HW, W,
+                           Kmax, topk_always ? 1 : 0, n_out, kxy, score);
+        if (HW <= RA_MAX) return;           // no frame of this size can exceed the rank-all capacity
+        min_count = RA_MAX;
+    }
     hipLaunchKernelGGL(select_kernel, dim3(B), dim3(SEL_T), (size_t)P2 * 8, s, nms, H, W, Kmax, P2, thr,
-                       cand_score, cand_idx, n_out, kxy, score, chunk_cnt, nch, topk_always ? 1 : 0, sel_keys, sel_n);
+                       cand_score, cand_idx, n_out, kxy, score, chunk_cnt, nch, topk_always ? 1 : 0, sel_keys, sel_n, min_count);
     hipLaunchKernelGGL(select_rank_kernel, dim3((Kmax + 63) / 64, B), dim3(256), (size_t)Kmax * 8, s, sel_keys, sel_n, W, Kmax, kxy, score);
 }
 
