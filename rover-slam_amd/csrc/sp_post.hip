@@ -533,11 +533,11 @@ __global__ __launch_bounds__(256) void select_rank_kernel(const unsigned long lo
 // rank among ALL candidates of its frame (key = score bits << 32 | ~pixel index, distinct) is the number of larger keys; a candidate with
 // rank < Kmax is a selected keypoint and its rank IS its output row -- no radix select, no single-workgroup tail (select_kernel: 21 us of
 // barriers on one CU, + 5 us of select_rank_kernel).  Workgroup (x, frame) loads the frame's keys into LDS and ranks candidates
-// 64 x .. 64 x + 63, four threads per candidate scanning a quarter of the list each with 16-byte reads.  count <= Kmax without the
+// 32 x .. 32 x + 31, eight threads per candidate scanning an eighth of the list each with 16-byte reads.  count <= Kmax without the
 // unconditional top-k: row-major copy (the published top_k_keypoints).  Frames with more than RA_MAX candidates (does not happen after a
 // radius-4 NMS on VGA-class images: at most one survivor per 5 x 5 block) are left to select_kernel / select_rank_kernel, which are
 // launched behind this kernel and return at once otherwise.
-constexpr int RA_MAX = 16384;
+constexpr int RA_MAX = 16384, RA_PER = 32;   // candidates per frame the kernel takes (128 KB of keys in LDS); candidates ranked per workgroup
 __global__ __launch_bounds__(256) void select_rankall_kernel(const float* __restrict__ cand_score, const int32_t* __restrict__ cand_idx,
                                                              const int32_t* __restrict__ chunk_cnt, int nch, int HW, int W, int Kmax,
                                                              int topk_always, int32_t* __restrict__ n_out, int32_t* __restrict__ kxy,
@@ -554,19 +554,29 @@ __global__ __launch_bounds__(256) void select_rankall_kernel(const float* __rest
     float* osc = score + (size_t)b * Kmax;
     const int nsel = count < Kmax ? count : Kmax;
     if (blockIdx.x == 0 && tid == 0) n_out[b] = nsel;
-    const int t0 = blockIdx.x * 64;
+    const int t0 = blockIdx.x * RA_PER;
     if (t0 >= count && t0 >= Kmax) return;
     // rows [nsel, Kmax) of the padded outputs
-    { const int t = t0 + (tid >> 2); if ((tid & 3) == 0 && t >= nsel && t < Kmax) { okxy[2 * t] = 0; okxy[2 * t + 1] = 0; osc[t] = 0.f; } }
+    { const int t = t0 + (tid >> 3); if ((tid & 7) == 0 && t >= nsel && t < Kmax) { okxy[2 * t] = 0; okxy[2 * t + 1] = 0; osc[t] = 0.f; } }
     if (t0 >= count) return;
     if (count <= Kmax && !topk_always) {      // nothing to cut: row-major order
-        const int t = t0 + (tid >> 2);
-        if ((tid & 3) == 0 && t < count) { const int idx = ci[t]; okxy[2 * t] = idx % W; okxy[2 * t + 1] = idx / W; osc[t] = cs[t]; }
+        const int t = t0 + (tid >> 3);
+        if ((tid & 7) == 0 && t < count) { const int idx = ci[t]; okxy[2 * t] = idx % W; okxy[2 * t + 1] = idx / W; osc[t] = cs[t]; }
         return;
     }
-    for (int k = tid; k < count; k += 256) keys[k] = ((unsigned long long)__float_as_uint(cs[k]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)ci[k]);
+    // keys of the whole frame into LDS, four independent (score, index) loads in flight per thread
+    for (int k0 = tid; k0 < count; k0 += 4 * 256) {
+        float sc[4]; int ix[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int k = k0 + u * 256; sc[u] = k < count ? cs[k] : 0.f; ix[u] = k < count ? ci[k] : 0; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * 256;
+            if (k < count) keys[k] = ((unsigned long long)__float_as_uint(sc[u]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)ix[u]);
+        }
+    }
     __syncthreads();
-    const int t = t0 + (tid >> 2), part = tid & 3;
+    const int t = t0 + (tid >> 3), part = tid & 7;      // eight threads per candidate, each scans an eighth of the key pairs
     if (t >= count) return;
     const unsigned long long key = keys[t];
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
@@ -574,10 +584,11 @@ __global__ __launch_bounds__(256) void select_rankall_kernel(const float* __rest
     const int npair = count >> 1;
     int rank = 0;
 #pragma unroll 8
-    for (int j = part; j < npair; j += 4) { const u64x2 kk = kp[j]; rank += (kk[0] > key ? 1 : 0) + (kk[1] > key ? 1 : 0); }
+    for (int j = part; j < npair; j += 8) { const u64x2 kk = kp[j]; rank += (kk[0] > key ? 1 : 0) + (kk[1] > key ? 1 : 0); }
     if ((count & 1) && part == 0) rank += keys[count - 1] > key ? 1 : 0;
     rank += __shfl_xor(rank, 1);
     rank += __shfl_xor(rank, 2);
+    rank += __shfl_xor(rank, 4);
     if (part == 0 && rank < Kmax) {
         const int idx = (int)(0xFFFFFFFFu - (unsigned int)(key & 0xFFFFFFFFull));
         okxy[2 * rank] = idx % W; okxy[2 * rank + 1] = idx / W;
@@ -600,7 +611,7 @@ void launch_select(hipStream_t s, const float* nms, int B, int H, int W, int Kma
         const int cap = HW < RA_MAX ? HW : RA_MAX, span = cap > Kmax ? cap : Kmax;
         static bool ls_[64];
         ensure_dynamic_lds((const void*)select_rankall_kernel, RA_MAX * 8, ls_);
-        hipLaunchKernelGGL(select_rankall_kernel, dim3((span + 63) / 64, B), dim3(256), (size_t)cap * 8, s, cand_score, cand_idx, chunk_cnt, nch, HW, W,
+        hipLaunchKernelGGL(select_rankall_kernel, dim3((span + RA_PER - 1) / RA_PER, B), dim3(256), (size_t)cap * 8, s, cand_score, cand_idx, chunk_cnt, nch, HW, W,
                            Kmax, topk_always ? 1 : 0, n_out, kxy, score);
         if (HW <= RA_MAX) return;           // no frame of this size can exceed the rank-all capacity
         min_count = RA_MAX;

@@ -11,8 +11,10 @@ from contextlib import redirect_stdout
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+import pmc_wait_table
 import rocpd_pmc
 import rocpd_stats
+import stamp
 
 
 def capture(fn, *a):
@@ -31,6 +33,14 @@ def main(tag, rnd=None):
     rnd = rnd or tag[:3]
     O = os.path.join(ROOT, "gpurun_out", tag)
     P = os.path.join(ROOT, "profiles")
+    # identity of the build the run was taken from (tools/stamp.py before the gpurun call, completed on the GPU box by profile_round.sh)
+    st = json.load(open(os.path.join(O, "stamp.json"))) if os.path.exists(os.path.join(O, "stamp.json")) else {}
+    stamp_line = stamp.line(st) if st else "Build: NOT STAMPED (run tools/stamp.py before tools/profile_round.sh)."
+    now = stamp.current()
+    if st and (st.get("so_sha256") != now["so_sha256"] or st.get("box_so_sha256") not in (None, st.get("so_sha256"))):
+        stamp_line += "  **STALE: the library in the tree is no longer the one this run measured.**"
+        print("WARNING:", stamp_line, file=sys.stderr)
+    stamp_line += "\n"
     bench = open(os.path.join(O, "bench.json")).read().strip().splitlines()[-1]
     d = json.loads(bench)
     open(os.path.join(P, f"{rnd}_bench.json"), "w").write(bench + "\n")
@@ -44,7 +54,7 @@ Command (MI355X box, tools/profile_round.sh {tag}): `rocprofv3 --kernel-trace --
 Un-profiled bench.py line from the same box just before: profiles/{rnd}_bench.json ({d['value']} frames/s, {d['ms_per_step']} ms/step; lg_attention avg {d['roofline']['avg_launch_ms'] * 1e3:.1f} us by HIP events in the timed region, {att_avg:.1f} us in this trace over its self (rotary, register-staged) and cross (LDS-DMA) kernels: {', '.join(f'{n} {a:.1f} us x {c}' for n, c, a in att)}).
 
 """
-    open(os.path.join(P, f"{rnd}_kernel_stats.md"), "w").write(head + ks)
+    open(os.path.join(P, f"{rnd}_kernel_stats.md"), "w").write(head + stamp_line + "\n" + ks)
     hbm_tab, hj = split(capture(rocpd_pmc.main, [os.path.join(O, "pmc_fetch", "f_results.db"), os.path.join(O, "pmc_write", "w_results.db")]))
     sq_tab, _ = split(capture(rocpd_pmc.main, [os.path.join(O, "pmc_sq", "s_results.db")]))
     # bench.py's roofline.traffic looks the dominant stage up by kernel-name substring: give the attention one merged entry
@@ -54,6 +64,7 @@ Un-profiled bench.py line from the same box just before: profiles/{rnd}_bench.js
         hj["lg_attention_kernel (self + cross variants, call-weighted)"] = {k: sum(v[k] * v["calls"] for v in am) / tot for k in ("FETCH_SIZE", "WRITE_SIZE", "traffic_bytes", "avg_us")} | {"calls": tot}
     out = {"note": "per-launch HBM traffic from rocprofv3 PMC, (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes, bench.py workload (33 frames / 32 pairs "
                    f"per step), final round-{int(rnd[1:])} kernels; source gpurun_out/{tag} (tools/profile_round.sh)",
+           "build": st,
            "kernels": {k: {"fetch_kib": v.get("FETCH_SIZE"), "write_kib": v.get("WRITE_SIZE"), "traffic_bytes": v.get("traffic_bytes"),
                            "avg_us": v.get("avg_us"), "calls": v.get("calls")} for k, v in hj.items()}}
     json.dump(out, open(os.path.join(P, f"{rnd}_pmc_traffic.json"), "w"), indent=1)
@@ -68,7 +79,45 @@ FETCH_SIZE / WRITE_SIZE: KiB per dispatch averaged per kernel. HBM traffic per l
 SQ rows are per XCD/SE slice: MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (32 * GRBM_GUI_ACTIVE); clock = GRBM_GUI_ACTIVE / duration.
 
 """
-    open(p, "w").write(headp + "## HBM\n" + hbm_tab + "\n\n## SQ / GRBM\n" + sq_tab + "\n\n" + notes)
+    open(p, "w").write(headp + stamp_line + "\n## HBM\n" + hbm_tab + "\n\n## SQ / GRBM\n" + sq_tab + "\n\n" + notes)
+    # ---- latency configurations: un-profiled lines + kernel traces of the same commands
+    lat = [f"# Round {int(rnd[1:])} -- latency configurations (BASELINE configs[1] / [2] / [4]): `bench.py --workload c2|c3|c5 --steps 100 --warmup 10` and the kernel "
+           f"trace of the same command at 30 steps (tools/profile_round.sh {tag})\n", stamp_line]
+    for w in ("c2", "c3", "c5"):
+        f, g = os.path.join(O, f"lat_{w}.json"), os.path.join(O, f"stats_{w}.md")
+        if os.path.exists(f) and open(f).read().strip():
+            x = json.loads(open(f).read().strip().splitlines()[-1])
+            lat.append(f"## {w}: {x['ms_per_step']} ms per step ({x['value']} {x['unit']}); with an event pair around every stage {x.get('ms_per_step_with_stage_events')} ms\n")
+            lat.append("stage table (ms per step, events around every stage): " + ", ".join(f"{k} {v}" for k, v in x.get("stages_ms_per_step", {}).items()) + "\n")
+        if os.path.exists(g):
+            lat.append("\n".join(open(g).read().replace(ROOT + "/", "").splitlines()[:34]) + "\n")
+    open(os.path.join(P, f"{rnd}_latency_kernel_stats.md"), "w").write("\n".join(lat))
+    # ---- RFE_OPT_LG_FP16X2 diagnostic configuration (same binary, same box, same call)
+    fb = os.path.join(O, "bench_fp16x2.json")
+    if os.path.exists(fb) and open(fb).read().strip():
+        line = open(fb).read().strip().splitlines()[-1]
+        open(os.path.join(P, f"{rnd}_bench_fp16x2.json"), "w").write(line + "\n")
+        x = json.loads(line)
+        body = open(os.path.join(O, "stats_fp16x2.md")).read().replace(ROOT + "/", "") if os.path.exists(os.path.join(O, "stats_fp16x2.md")) else ""
+        clk = open(os.path.join(O, "pmc_sq_fp16x2.md")).read() if os.path.exists(os.path.join(O, "pmc_sq_fp16x2.md")) else ""
+        clk = clk[:clk.index("```json")] if "```json" in clk else clk
+        open(os.path.join(P, f"{rnd}_fp16x2_kernel_stats.md"), "w").write(
+            f"# Round {int(rnd[1:])} -- rocprofv3 --kernel-trace summary with RFE_OPT_LG_FP16X2 ON (diagnostic run; the default / headline configuration is "
+            f"{rnd}_kernel_stats.md)\n\n{stamp_line}\nUn-profiled line of the same configuration from the same box, same call (`bench.py --steps 20 --warmup 3 --lg-fp16x2 1 --no-pool "
+            f"--no-pcie`): profiles/{rnd}_bench_fp16x2.json ({x['value']} frames/s, {x['ms_per_step']} ms/step).\n\n" + body +
+            "\n## Clocks in this configuration (`--pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES`; clock = GRBM_GUI_ACTIVE / duration; compare the SQ / GRBM "
+            f"table of {rnd}_pmc.md for the default configuration)\n\n" + clk)
+    # ---- what the waves wait on: throughput step, single pair, fp16x2
+    tags = [t for t in (tag + "_wait", tag + "_wait_c3") if os.path.exists(os.path.join(ROOT, "gpurun_out", t, "table.md"))]
+    if len(tags) == 2:
+        pmc_wait_table.main(rnd, tags[0], tags[1])
+        pw = os.path.join(P, f"{rnd}_pmc_wait.md")
+        t = open(pw).read()
+        extra = ""
+        fx = os.path.join(ROOT, "gpurun_out", tag + "_wait_fp16x2", "table.md")
+        if os.path.exists(fx):
+            extra = "\n## throughput step with RFE_OPT_LG_FP16X2 = 1\n\n" + open(fx).read()
+        open(pw, "w").write(t.replace("\n", "\n" + stamp_line + "\n", 1) + extra)
     print(d["value"], d["ms_per_step"], d["roofline"]["achieved"], d["roofline"]["frac"], d.get("pcie_inclusive", {}).get("value"),
           d.get("cpu_baseline", {}).get("value"))
     for w in ("c2", "c3", "c5"):
