@@ -79,49 +79,13 @@ public:
     }
 
     // u8 fast path used by SPextractor::ExtractSingleLayer (NormalizeImage is fused into the first kernel)
-    int Extractor_Inference_u8(const unsigned char* img, int H, int W, int stride) {
-        extractor_outputtensors.clear();
-        if (!ExtractorSession) { std::cerr << "[ERROR] Extractor inference failed : no session" << std::endl; return EXIT_FAILURE; }
-        const int K = max_keypoints;
-        std::vector<int32_t>& kxy = stage_kxy_;        // grow-only staging owned by the runner: nothing K-sized is allocated per call
-        std::vector<float>&sc = stage_score_, &desc = stage_desc_;
-        if (kxy.size() < (size_t)K * 2) { kxy.resize((size_t)K * 2); sc.resize(K); desc.resize((size_t)K * 256); }
-        int32_t n = 0;
-        auto t0 = std::chrono::high_resolution_clock::now();
-        int rc = rfe_extract_u8(ExtractorSession, img, H, W, stride, 1, K, detection_threshold, &n, kxy.data(), sc.data(), desc.data());
-        extractor_timer += std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count();
-        if (rc != RFE_OK) {
-            std::cerr << "[ERROR] Extractor inference failed : " << rfe_last_error(ExtractorSession) << std::endl;
-            return EXIT_FAILURE;
-        }
-        std::vector<rfe::Tensor> out;
-        out.emplace_back(std::vector<int64_t>{1, n, 2}, sizeof(int64_t));
-        out.emplace_back(std::vector<int64_t>{1, n}, sizeof(float));
-        out.emplace_back(std::vector<int64_t>{1, n, 256}, sizeof(float));
-        int64_t* k64 = out[0].GetTensorMutableData<int64_t>();
-        for (int i = 0; i < 2 * n; ++i) k64[i] = kxy[i];
-        std::copy(sc.begin(), sc.begin() + n, out[1].GetTensorMutableData<float>());
-        std::copy(desc.begin(), desc.begin() + (size_t)n * 256, out[2].GetTensorMutableData<float>());
-        extractor_outputtensors.emplace_back(std::move(out));
-        return EXIT_SUCCESS;
-    }
+    int Extractor_Inference_u8(const unsigned char* img, int H, int W, int stride) { return run_(img, false, H, W, stride); }
 
-    // reference superpoint_onnx.cc:88-162: image is the CV_32F output of NormalizeImage
+    // reference superpoint_onnx.cc:88-162: image is a CV_32F single-channel image, normally NormalizeImage's output; like the graph,
+    // the kernels take the values as they are (no assumption that they are multiples of 1/255 or inside [0, 1])
     int Extractor_Inference(Configuration, const cv::Mat& image) {
-        const int H = image.rows, W = image.cols;
-        std::vector<unsigned char> u8((size_t)H * W);
-        for (int r = 0; r < H; ++r) {
-            const float* s = image.ptr<float>(r);
-            for (int c = 0; c < W; ++c) {
-                const float v = s[c] * 255.0f, q = std::nearbyint(v);
-                if (std::fabs(v - q) > 1e-3f || q < 0.f || q > 255.f) {
-                    std::cerr << "[ERROR] Extractor inference failed : image is not an 8-bit image scaled by 1/255" << std::endl;
-                    return EXIT_FAILURE;
-                }
-                u8[(size_t)r * W + c] = (unsigned char)q;
-            }
-        }
-        return Extractor_Inference_u8(u8.data(), H, W, W);
+        if (image.step % sizeof(float) != 0) { std::cerr << "[ERROR] Extractor inference failed : row step is not a multiple of 4" << std::endl; return EXIT_FAILURE; }
+        return run_(image.ptr<float>(0), true, image.rows, image.cols, (int)(image.step / sizeof(float)));
     }
 
     // reference superpoint_onnx.cc:165-255
@@ -158,6 +122,34 @@ public:
     std::pair<std::vector<cv::Point2f>, std::vector<cv::Point2f>> GetKeypointsResult() { return keypoints_result; }
 
 private:
+
+    int run_(const void* img, bool f32, int H, int W, int stride) {
+        extractor_outputtensors.clear();
+        if (!ExtractorSession) { std::cerr << "[ERROR] Extractor inference failed : no session" << std::endl; return EXIT_FAILURE; }
+        const int K = max_keypoints;
+        std::vector<int32_t>& kxy = stage_kxy_;        // grow-only staging owned by the runner: nothing K-sized is allocated per call
+        std::vector<float>&sc = stage_score_, &desc = stage_desc_;
+        if (kxy.size() < (size_t)K * 2) { kxy.resize((size_t)K * 2); sc.resize(K); desc.resize((size_t)K * 256); }
+        int32_t n = 0;
+        auto t0 = std::chrono::high_resolution_clock::now();
+        int rc = f32 ? rfe_extract_f32(ExtractorSession, (const float*)img, H, W, stride, 1, K, detection_threshold, &n, kxy.data(), sc.data(), desc.data())
+                     : rfe_extract_u8(ExtractorSession, (const unsigned char*)img, H, W, stride, 1, K, detection_threshold, &n, kxy.data(), sc.data(), desc.data());
+        extractor_timer += std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count();
+        if (rc != RFE_OK) {
+            std::cerr << "[ERROR] Extractor inference failed : " << rfe_last_error(ExtractorSession) << std::endl;
+            return EXIT_FAILURE;
+        }
+        std::vector<rfe::Tensor> out;
+        out.emplace_back(std::vector<int64_t>{1, n, 2}, sizeof(int64_t));
+        out.emplace_back(std::vector<int64_t>{1, n}, sizeof(float));
+        out.emplace_back(std::vector<int64_t>{1, n, 256}, sizeof(float));
+        int64_t* k64 = out[0].GetTensorMutableData<int64_t>();
+        for (int i = 0; i < 2 * n; ++i) k64[i] = kxy[i];
+        std::copy(sc.begin(), sc.begin() + n, out[1].GetTensorMutableData<float>());
+        std::copy(desc.begin(), desc.begin() + (size_t)n * 256, out[2].GetTensorMutableData<float>());
+        extractor_outputtensors.emplace_back(std::move(out));
+        return EXIT_SUCCESS;
+    }
     std::vector<int32_t> stage_kxy_;
     std::vector<float> stage_score_, stage_desc_;
 };

@@ -153,6 +153,15 @@ int rfe_extract_u8_dev(rfe_ctx* ctx, const uint8_t* img_dev, int H, int W, int s
                        int Kmax, float thr, int32_t* n_dev, int32_t* kxy_dev, float* score_dev,
                        float* desc_dev);
 
+/* The float entry: img is an ALREADY normalised single-channel float image (what NormalizeImage produced, or any CV_32F the
+ * caller hands to Extractor_Inference, src/Extractors/superpoint_onnx.cc:88-118); the values enter conv1a unchanged, whatever
+ * their range.  stride in floats.  For img[i] = u8[i] * (1/255.f) the outputs are bit-identical to rfe_extract_u8's. */
+int rfe_extract_f32(rfe_ctx* ctx, const float* img, int H, int W, int stride, int B, int Kmax,
+                    float thr, int32_t* n, int32_t* kxy, float* score, float* desc);
+int rfe_extract_f32_dev(rfe_ctx* ctx, const float* img_dev, int H, int W, int stride, int B,
+                        int Kmax, float thr, int32_t* n_dev, int32_t* kxy_dev, float* score_dev,
+                        float* desc_dev);
+
 /* The same with a second descriptor output for the loop-closure side: desc_bin u8 [B,Kmax,256] = desc > 0,
  * i.e. Frame::binarize_descriptors (src/Frame.cc:1034-1043) written by the sampling kernel itself, ready for
  * Converter::toDescriptorVector + the DBoW3 vocabulary of Frame::ComputeBoW3 (:1044-1054), which stay on the CPU.

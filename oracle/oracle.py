@@ -71,6 +71,9 @@ def lib():
         L.rfo_superpoint_ex.restype = C.c_int
         L.rfo_superpoint_ex.argtypes = [fp, u8p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
                                         ip, fp, fp, fp, fp, fp, fp]
+        L.rfo_superpoint_f32.restype = C.c_int
+        L.rfo_superpoint_f32.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
+                                         ip, fp, fp, fp, fp, fp, fp]
         L.rfo_lightglue.restype = C.c_int
         L.rfo_lightglue.argtypes = [fp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_float, ip, fp, fp, fp, fp]
         L.rfo_normalize_keypoints.argtypes = [fp, C.c_int, C.c_int, C.c_int, fp]
@@ -166,10 +169,12 @@ def l2norm256(x):
 
 
 def superpoint(weights, img_u8, kmax=1024, thr=0.0005, nms_radius=4, border=4, debug=False, topk_always=False):
-    """One frame.  Returns dict(n, kxy[Kmax,2] i32, score[Kmax], desc[Kmax,256] (+ debug taps))."""
+    """One frame.  Returns dict(n, kxy[Kmax,2] i32, score[Kmax], desc[Kmax,256] (+ debug taps)).
+    A float32 image is taken as already normalised (the reference's float entry, superpoint_onnx.cc:88-118); anything else as u8."""
     w, wp = _f(weights)
     assert w.size == sp_weight_count()
-    img = np.ascontiguousarray(img_u8, dtype=np.uint8)
+    is_f32 = isinstance(img_u8, np.ndarray) and img_u8.dtype == np.float32
+    img = np.ascontiguousarray(img_u8, dtype=np.float32 if is_f32 else np.uint8)
     H, W = img.shape
     Hs, Ws = H // 8 * 8, W // 8 * 8          # score-map frame (= the image when H, W are multiples of 8)
     kxy = np.zeros((kmax, 2), np.int32)
@@ -180,7 +185,8 @@ def superpoint(weights, img_u8, kmax=1024, thr=0.0005, nms_radius=4, border=4, d
         dbg = dict(scoremap=np.empty((Hs, Ws), np.float32), nms=np.empty((Hs, Ws), np.float32),
                    descmap=np.empty((H // 8, W // 8, 256), np.float32),
                    feat=np.empty((H // 8, W // 8, 128), np.float32))
-    n = lib().rfo_superpoint_ex(wp, img.ctypes.data_as(C.POINTER(C.c_uint8)), H, W, kmax, thr, nms_radius, border, int(topk_always),
+    entry = lib().rfo_superpoint_f32 if is_f32 else lib().rfo_superpoint_ex
+    n = entry(wp, img.ctypes.data_as(C.POINTER(C.c_float if is_f32 else C.c_uint8)), H, W, kmax, thr, nms_radius, border, int(topk_always),
                              kxy.ctypes.data_as(C.POINTER(C.c_int32)), _opt(score), _opt(desc),
                              _opt(dbg.get("scoremap")), _opt(dbg.get("nms")), _opt(dbg.get("descmap")),
                              _opt(dbg.get("feat")))

@@ -259,6 +259,19 @@ int rfo_superpoint(const float* wts, const uint8_t* img, int H, int W, int Kmax,
 int rfo_superpoint_ex(const float* wts, const uint8_t* img, int H, int W, int Kmax, float thr,
                       int nms_radius, int border, int topk_always, int32_t* kxy, float* score, float* desc,
                       float* dbg_scoremap, float* dbg_nms, float* dbg_descmap, float* dbg_feat) {
+    /* NormalizeImage: transform.cpp:11  u8 -> f32 * (1/255) */
+    size_t n0 = (size_t)H * W;
+    float* f = (float*)malloc(sizeof(float) * n0);
+    for (size_t i = 0; i < n0; ++i) f[i] = (float)img[i] * 0.003921568859368563f;
+    int n = rfo_superpoint_f32(wts, f, H, W, Kmax, thr, nms_radius, border, topk_always, kxy, score, desc, dbg_scoremap, dbg_nms, dbg_descmap, dbg_feat);
+    free(f);
+    return n;
+}
+
+/* The graph proper: what Session::Run sees (superpoint_onnx.cc:105-136) is the float image, whoever normalised it. */
+int rfo_superpoint_f32(const float* wts, const float* img, int H, int W, int Kmax, float thr,
+                       int nms_radius, int border, int topk_always, int32_t* kxy, float* score, float* desc,
+                       float* dbg_scoremap, float* dbg_nms, float* dbg_descmap, float* dbg_feat) {
     /* Any H, W >= 8, like the ONNX graph (dynamic axes): the three 2x2/2 max-pools floor, so the feature grid is Hc x Wc =
      * floor(H/8) x floor(W/8) and everything after the heads lives on the Hs x Ws = 8Hc x 8Wc score map (= the image when H, W
      * are multiples of 8; e.g. KITTI 1241 x 376 -> 155 x 47 cells, score map 1240 x 376). */
@@ -269,8 +282,7 @@ int rfo_superpoint_ex(const float* wts, const uint8_t* img, int H, int W, int Km
     size_t n0 = (size_t)H * W;
     float* a = (float*)malloc(sizeof(float) * n0 * 64);
     float* b = (float*)malloc(sizeof(float) * n0 * 64);
-    /* NormalizeImage: transform.cpp:11  u8 -> f32 * (1/255) */
-    for (size_t i = 0; i < n0; ++i) a[i] = (float)img[i] * 0.003921568859368563f;
+    memcpy(a, img, sizeof(float) * n0);
     rfo_conv3x3(a, H, W, 1, WOFF(0), BOFF(0), 64, 1, 0, b);
     rfo_conv3x3(b, H, W, 64, WOFF(1), BOFF(1), 64, 1, 1, a);
     rfo_conv3x3(a, Himg / 2, Wimg / 2, 64, WOFF(2), BOFF(2), 64, 1, 0, b);

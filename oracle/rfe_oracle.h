@@ -65,6 +65,12 @@ int rfo_superpoint_ex(const float* weights, const uint8_t* img, int H, int W, in
                       int nms_radius, int border, int topk_always, int32_t* kxy, float* score, float* desc,
                       float* dbg_scoremap, float* dbg_nms, float* dbg_descmap, float* dbg_feat);
 
+/* The same from an already normalised float image [H,W] (the reference's Extractor_Inference takes a CV_32F cv::Mat,
+ * superpoint_onnx.cc:88-118); rfo_superpoint_ex is NormalizeImage + this. */
+int rfo_superpoint_f32(const float* weights, const float* img, int H, int W, int Kmax, float thr,
+                       int nms_radius, int border, int topk_always, int32_t* kxy, float* score, float* desc,
+                       float* dbg_scoremap, float* dbg_nms, float* dbg_descmap, float* dbg_feat);
+
 /* ---- LightGlue end to end (one pair) ----
  * k0n/k1n: normalised keypoints [M,2]/[N,2]; d0/d1: [M,256]/[N,256].
  * pairs: [min(M,N),2] (i,j) ascending i; ms: scores.  Returns S.

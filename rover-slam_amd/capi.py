@@ -17,7 +17,7 @@ OPT_LG_FP16X2 = 2   # LightGlue Linears + attention of batched calls as split pr
 EXPORTS = [
     "rfe_init", "rfe_destroy", "rfe_last_error", "rfe_version", "rfe_load_weights", "rfe_set_weights",
     "rfe_weight_count", "rfe_weights_id", "rfe_get_hparams", "rfe_set_hparams", "rfe_set_option", "rfe_get_option", "rfe_set_stream", "rfe_synchronize", "rfe_malloc", "rfe_free", "rfe_memcpy_h2d",
-    "rfe_memcpy_d2h", "rfe_extract_u8", "rfe_extract_u8_dev", "rfe_extract_u8_bin", "rfe_extract_u8_bin_dev", "rfe_match", "rfe_match_dev", "rfe_match_fused",
+    "rfe_memcpy_d2h", "rfe_extract_u8", "rfe_extract_u8_dev", "rfe_extract_f32", "rfe_extract_f32_dev", "rfe_extract_u8_bin", "rfe_extract_u8_bin_dev", "rfe_match", "rfe_match_dev", "rfe_match_fused",
     "rfe_extract_match_stream_dev", "rfe_stereo_match", "rfe_stereo_match_dev", "rfe_stereo_frame_dev", "rfe_l2_distance_matrix", "rfe_binarize_descriptors",
     "rfe_search_candidates", "rfe_distinctive_descriptors",
     "rfe_l2_distance_matrix_dev", "rfe_binarize_descriptors_dev", "rfe_search_candidates_dev", "rfe_distinctive_descriptors_dev",
@@ -70,6 +70,8 @@ lib.rfe_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
 lib.rfe_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
 _ext = [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _ip, _ip, _fp, _fp]
 lib.rfe_extract_u8.argtypes = _ext
+lib.rfe_extract_f32.argtypes = _ext
+lib.rfe_extract_f32_dev.argtypes = _ext
 lib.rfe_extract_u8_dev.argtypes = _ext
 lib.rfe_extract_u8_bin.argtypes = _ext + [_u8p]
 lib.rfe_extract_u8_bin_dev.argtypes = _ext + [_u8p]
@@ -363,6 +365,21 @@ class Context:
             return n, kxy, score, desc, dbin
         self._chk(lib.rfe_extract_u8(self.h, img.ctypes.data, H, W, stride, B, kmax, thr, n.ctypes.data, kxy.ctypes.data,
                                      score.ctypes.data, desc.ctypes.data))
+        return n, kxy, score, desc
+
+    def extract_f32(self, img_f32, kmax=1024, thr=0.0005):
+        """The float entry: img_f32 [B,H,W] or [H,W] float32, already normalised (what the reference's Extractor_Inference is handed).
+        Same outputs as extract()."""
+        img = np.ascontiguousarray(img_f32, np.float32)
+        if img.ndim == 2:
+            img = img[None]
+        B, H, W = img.shape
+        n = np.zeros((B,), np.int32)
+        kxy = np.zeros((B, kmax, 2), np.int32)
+        score = np.zeros((B, kmax), np.float32)
+        desc = np.zeros((B, kmax, 256), np.float32)
+        self._chk(lib.rfe_extract_f32(self.h, img.ctypes.data, H, W, W, B, kmax, thr, n.ctypes.data, kxy.ctypes.data,
+                                      score.ctypes.data, desc.ctypes.data))
         return n, kxy, score, desc
 
     def match(self, k0n, k1n, d0, d1, m, n, filter_thr=0.1):

@@ -554,7 +554,7 @@ int sp_check(rfe_ctx* c, int H, int W, int B, int Kmax) {
 // backbone + heads up to the NMS'ed score map and the normalised descriptor map
 // join = false: the caller still has detector-only work to enqueue and joins the descriptor stream itself
 // (hipStreamWaitEvent(c->stream, c->ev_join)) when `forked` comes back true
-int sp_forward_maps(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, int B, SpBuffers& b, bool join, bool& forked) {
+int sp_forward_maps(rfe_ctx* c, const void* img, int H, int W, int stride, int B, SpBuffers& b, bool join, bool& forked, bool img_f32 = false) {
     forked = false;
     int rc = ensure_ws(c, &c->ws_sp, &c->ws_sp_bytes, sp_ws_bytes(B, H, W));
     if (rc) return rc;
@@ -566,11 +566,11 @@ int sp_forward_maps(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, in
     // KITTI 1241 x 376 -> 155 x 47 cells, score map 1240 x 376).  The workspace carve (sized from B*H*W) is an upper bound.
     const int H1 = H / 2, W1 = W / 2, H2 = H1 / 2, W2 = W1 / 2, Hc = H2 / 2, Wc = W2 / 2, cells = B * Hc * Wc;
     if (sp_unfused_conv1()) {
-        { ProfScope p(c, "conv1a"); launch_conv1a_u8(s, img, stride, B, H, W, w.conv1a_w, w.bias[L_1A], b.a1); }
+        { ProfScope p(c, "conv1a"); launch_conv1a_u8(s, img, img_f32, stride, B, H, W, w.conv1a_w, w.bias[L_1A], b.a1); }
         { ProfScope p(c, "conv1b"); launch_conv3x3(s, b.a1, B, H, W, 64, w.packed[L_1B], w.bias[L_1B], 64, true, true, b.p1, L_1B); }
     } else {   // conv1a recomputed inside conv1b's LDS staging: the [B,H,W,64] activation never touches HBM
         ProfScope p(c, "conv1ab");
-        launch_conv1ab_fused(s, img, stride, B, H, W, w.conv1a_w, w.bias[L_1A], w.packed[L_1B], w.bias[L_1B], b.p1);
+        launch_conv1ab_fused(s, img, img_f32, stride, B, H, W, w.conv1a_w, w.bias[L_1A], w.packed[L_1B], w.bias[L_1B], b.p1);
     }
     { ProfScope p(c, "conv2a"); launch_conv3x3(s, b.p1, B, H1, W1, 64, w.packed[L_2A], w.bias[L_2A], 64, true, false, b.a2, L_2A); }
     { ProfScope p(c, "conv2b"); launch_conv3x3(s, b.a2, B, H1, W1, 64, w.packed[L_2B], w.bias[L_2B], 64, true, true, b.p2, L_2B); }
@@ -601,11 +601,11 @@ int sp_forward_maps(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, in
     return RFE_OK;
 }
 
-int sp_forward(rfe_ctx* c, const uint8_t* img, int H, int W, int stride, int B, int Kmax, float thr,
-               int32_t* n, int32_t* kxy, float* score, float* desc, uint8_t* desc_bin = nullptr) {
+int sp_forward(rfe_ctx* c, const void* img, int H, int W, int stride, int B, int Kmax, float thr,
+               int32_t* n, int32_t* kxy, float* score, float* desc, uint8_t* desc_bin = nullptr, bool img_f32 = false) {
     SpBuffers b;
     bool forked;
-    int rc = sp_forward_maps(c, img, H, W, stride, B, b, false, forked);
+    int rc = sp_forward_maps(c, img, H, W, stride, B, b, false, forked, img_f32);
     if (rc) return rc;
     const int Hc = H / 2 / 2 / 2, Wc = W / 2 / 2 / 2, Hs = 8 * Hc, Ws = 8 * Wc;   // score-map frame, see sp_forward_maps
     { ProfScope p(c, "sp_select");
@@ -656,6 +656,40 @@ extern "C" int rfe_extract_u8_bin(rfe_ctx* c, const uint8_t* img, int H, int W, 
     uint8_t* d_b = desc_bin ? (uint8_t*)(p + ib + nb + kb + sb + db) : nullptr;
     if ((rc = sp_forward(c, d_img, H, W, W, B, Kmax, thr, d_n, d_k, d_s, d_d, d_b))) return rc;
     if (desc_bin) RFE_HIP(c, hipMemcpyAsync(desc_bin, d_b, (size_t)B * Kmax * 256, hipMemcpyDeviceToHost, c->stream));
+    RFE_HIP(c, hipMemcpyAsync(n, d_n, (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
+    RFE_HIP(c, hipMemcpyAsync(kxy, d_k, (size_t)B * Kmax * 8, hipMemcpyDeviceToHost, c->stream));
+    RFE_HIP(c, hipMemcpyAsync(score, d_s, (size_t)B * Kmax * 4, hipMemcpyDeviceToHost, c->stream));
+    RFE_HIP(c, hipMemcpyAsync(desc, d_d, (size_t)B * Kmax * 1024, hipMemcpyDeviceToHost, c->stream));
+    RFE_HIP(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    return RFE_OK;
+}
+
+// The reference's float entry (Extractor_Inference on an already normalised CV_32F image, src/Extractors/superpoint_onnx.cc:88-118): the
+// pixel values go into conv1a as they are, whatever their range -- no u8 round trip, no NormalizeImage.  stride in floats.
+extern "C" int rfe_extract_f32_dev(rfe_ctx* c, const float* img, int H, int W, int stride, int B, int Kmax,
+                                   float thr, int32_t* n, int32_t* kxy, float* score, float* desc) {
+    int rc = sp_check(c, H, W, B, Kmax);
+    if (rc) return rc;
+    if (!img || !n || !kxy || !score || !desc || stride < W) return fail(c, RFE_ERR_INVALID, "extract: null pointer or stride < W");
+    RFE_HIP(c, hipSetDevice(c->device));
+    return sp_forward(c, img, H, W, stride, B, Kmax, thr, n, kxy, score, desc, nullptr, true);
+}
+
+extern "C" int rfe_extract_f32(rfe_ctx* c, const float* img, int H, int W, int stride, int B, int Kmax, float thr,
+                               int32_t* n, int32_t* kxy, float* score, float* desc) {
+    int rc = sp_check(c, H, W, B, Kmax);
+    if (rc) return rc;
+    if (!img || !n || !kxy || !score || !desc || stride < W) return fail(c, RFE_ERR_INVALID, "extract: null pointer or stride < W");
+    RFE_HIP(c, hipSetDevice(c->device));
+    const size_t ib = al((size_t)B * H * W * 4), nb = al((size_t)B * 4), kb = al((size_t)B * Kmax * 8),
+                 sb = al((size_t)B * Kmax * 4), db = al((size_t)B * Kmax * 1024);
+    if ((rc = ensure_ws(c, &c->ws_io, &c->ws_io_bytes, ib + nb + kb + sb + db))) return rc;
+    char* p = (char*)c->ws_io;
+    float* d_img = (float*)p; int32_t* d_n = (int32_t*)(p + ib); int32_t* d_k = (int32_t*)(p + ib + nb);
+    float* d_s = (float*)(p + ib + nb + kb); float* d_d = (float*)(p + ib + nb + kb + sb);
+    RFE_HIP(c, hipMemcpy2DAsync(d_img, (size_t)W * 4, img, (size_t)stride * 4, (size_t)W * 4, (size_t)B * H, hipMemcpyHostToDevice, c->stream));
+    if ((rc = sp_forward(c, d_img, H, W, W, B, Kmax, thr, d_n, d_k, d_s, d_d, nullptr, true))) return rc;
     RFE_HIP(c, hipMemcpyAsync(n, d_n, (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
     RFE_HIP(c, hipMemcpyAsync(kxy, d_k, (size_t)B * Kmax * 8, hipMemcpyDeviceToHost, c->stream));
     RFE_HIP(c, hipMemcpyAsync(score, d_s, (size_t)B * Kmax * 4, hipMemcpyDeviceToHost, c->stream));

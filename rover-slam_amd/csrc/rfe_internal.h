@@ -158,12 +158,13 @@ int ensure_ws(rfe_ctx* c, void** p, size_t* cur, size_t need);
 void pack_conv3x3_weights(const float* w_oihw, int cin, int cout, std::vector<float>& out);
 size_t packed_conv3x3_count(int cin, int cout);
 int conv_ck();   // input channels per LDS chunk the 3x3 weights are packed for (8; RFE_CONV_CK=16 for A/B)
-void launch_conv1a_u8(hipStream_t s, const uint8_t* img, int stride, int B, int H, int W,
+// img: u8 pixels (NormalizeImage fused) or, img_f32, already normalised float pixels; stride in pixels
+void launch_conv1a_u8(hipStream_t s, const void* img, bool img_f32, int stride, int B, int H, int W,
                       const float* w9x64, const float* bias, float* out);
 void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin,
                     const float* wpacked, const float* bias, int cout, bool relu, bool pool, float* out,
                     int tag = 0);
-void launch_conv1ab_fused(hipStream_t s, const uint8_t* img, int stride, int B, int H, int W, const float* w1a,
+void launch_conv1ab_fused(hipStream_t s, const void* img, bool img_f32, int stride, int B, int H, int W, const float* w1a,
                           const float* b1a, const float* wp, const float* bias, float* out);
 // gemm.hip
 // hipFuncAttributeMaxDynamicSharedMemorySize belongs to the CURRENT device's copy of a kernel: set it once per (kernel, device) -- pools run

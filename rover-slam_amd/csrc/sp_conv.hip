@@ -590,9 +590,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_comp_kernel(
 // 8-channel chunk is recomputed in LDS from the u8 image tile (NormalizeImage * 1/255, conv1a 1->64,
 // bias, ReLU -- same fmaf chain as conv1a_u8_kernel / the oracle, so still bit-exact), then conv1b +
 // ReLU + 2x2 max-pool as above.  Removes the 78.6 MB/frame round trip of the largest activation.
-template <int CK>
+// PX = uint8_t: the reference's NormalizeImage (x * 1/255) is applied here; PX = float: an already normalised CV_32F image as the reference's
+// Extractor_Inference takes it (src/Extractors/superpoint_onnx.cc:88-118) is used as it is.  stride in pixels.
+template <typename PX>
+__device__ __forceinline__ float px_value(PX v) {
+    if constexpr (sizeof(PX) == 1) return (float)v * 0.003921568859368563f;
+    else return v;
+}
+
+template <int CK, typename PX>
 __global__ __launch_bounds__(256, 2) void conv1ab_fused_kernel(
-    const uint8_t* __restrict__ img, int stride, const float* __restrict__ w1a /*[9][64]*/, const float* __restrict__ b1a,
+    const PX* __restrict__ img, int stride, const float* __restrict__ w1a /*[9][64]*/, const float* __restrict__ b1a,
     const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ out, int H, int W) {
     constexpr int CIN = 64, COUT = 64, KCH = CK * 9;
     constexpr int MH = TH + 4, MW = TW + 4;   // image tile with a 2-pixel halo
@@ -618,12 +626,12 @@ __global__ __launch_bounds__(256, 2) void conv1ab_fused_kernel(
     conv_a_offsets(aoff, h, wave, col);
     const int boff = h * NT + col;
 
-    const uint8_t* im = img + (size_t)b * stride * H;
+    const PX* im = img + (size_t)b * stride * H;
     for (int idx = tid; idx < MH * MW; idx += 256) {
         const int py = idx / MW, px = idx % MW;
         const int gy = y0 - 2 + py, gx = x0 - 2 + px;
         float v = 0.f;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = (float)im[(size_t)gy * stride + gx] * 0.003921568859368563f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = px_value(im[(size_t)gy * stride + gx]);
         lds_img[idx] = v;
     }
 
@@ -665,13 +673,20 @@ __global__ __launch_bounds__(256, 2) void conv1ab_fused_kernel(
     conv_store<true, true>(acc, out, b, H, W, COUT, x0, y0, 0, wave, col, h);
 }
 
-void launch_conv1ab_fused(hipStream_t s, const uint8_t* img, int stride, int B, int H, int W, const float* w1a,
+void launch_conv1ab_fused(hipStream_t s, const void* img, bool img_f32, int stride, int B, int H, int W, const float* w1a,
                           const float* b1a, const float* wp, const float* bias, float* out) {
     dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B);
+    if (img_f32) {
+        if (conv_ck() == 8)
+            hipLaunchKernelGGL((conv1ab_fused_kernel<8, float>), grid, dim3(256), 0, s, (const float*)img, stride, w1a, b1a, wp, bias, out, H, W);
+        else
+            hipLaunchKernelGGL((conv1ab_fused_kernel<16, float>), grid, dim3(256), 0, s, (const float*)img, stride, w1a, b1a, wp, bias, out, H, W);
+        return;
+    }
     if (conv_ck() == 8)
-        hipLaunchKernelGGL((conv1ab_fused_kernel<8>), grid, dim3(256), 0, s, img, stride, w1a, b1a, wp, bias, out, H, W);
+        hipLaunchKernelGGL((conv1ab_fused_kernel<8, uint8_t>), grid, dim3(256), 0, s, (const uint8_t*)img, stride, w1a, b1a, wp, bias, out, H, W);
     else
-        hipLaunchKernelGGL((conv1ab_fused_kernel<16>), grid, dim3(256), 0, s, img, stride, w1a, b1a, wp, bias, out, H, W);
+        hipLaunchKernelGGL((conv1ab_fused_kernel<16, uint8_t>), grid, dim3(256), 0, s, (const uint8_t*)img, stride, w1a, b1a, wp, bias, out, H, W);
 }
 
 #define RFE_CONV_LAUNCH(CIN, POOL, RELU, TAG)                                                                            \
@@ -761,7 +776,8 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
 // conv1a: u8 image -> (x * 1/255) -> conv3x3 1->64 + bias + ReLU, NHWC out.  HBM bound (writes
 // 256 B per pixel).  16 lanes per pixel, 4 output channels per lane: a wave stores 1 KB contiguous.
 // NormalizeImage (reference src/Matchers/transform.cpp:11) is fused here.
-__global__ __launch_bounds__(256) void conv1a_u8_kernel(const uint8_t* __restrict__ img, int stride,
+template <typename PX>
+__global__ __launch_bounds__(256) void conv1a_u8_kernel(const PX* __restrict__ img, int stride,
                                                         int H, int W, const float* __restrict__ w9x64,
                                                         const float* __restrict__ bias,
                                                         float* __restrict__ out) {
@@ -774,7 +790,7 @@ __global__ __launch_bounds__(256) void conv1a_u8_kernel(const uint8_t* __restric
         for (int e = 0; e < 4; ++e) wr[k][e] = w9x64[k * 64 + cg * 4 + e];
 #pragma unroll
     for (int e = 0; e < 4; ++e) br[e] = bias[cg * 4 + e];
-    const uint8_t* im = img + (size_t)b * stride * H;
+    const PX* im = img + (size_t)b * stride * H;
     float* ob = out + (size_t)b * H * W * 64;
     const int npix = H * W;
     for (int p = blockIdx.x * 16 + (threadIdx.x >> 4); p < npix; p += gridDim.x * 16) {
@@ -786,7 +802,7 @@ __global__ __launch_bounds__(256) void conv1a_u8_kernel(const uint8_t* __restric
             for (int kx = 0; kx < 3; ++kx) {
                 const int gy = y + ky - 1, gx = x + kx - 1;
                 float v = 0.f;
-                if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = (float)im[(size_t)gy * stride + gx] * 0.003921568859368563f;
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = px_value(im[(size_t)gy * stride + gx]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) a[e] = fmaf(v, wr[ky * 3 + kx][e], a[e]);
             }
@@ -795,11 +811,12 @@ __global__ __launch_bounds__(256) void conv1a_u8_kernel(const uint8_t* __restric
     }
 }
 
-void launch_conv1a_u8(hipStream_t s, const uint8_t* img, int stride, int B, int H, int W,
+void launch_conv1a_u8(hipStream_t s, const void* img, bool img_f32, int stride, int B, int H, int W,
                       const float* w9x64, const float* bias, float* out) {
     int blocks = (H * W + 15) / 16;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(conv1a_u8_kernel, dim3(blocks, B), dim3(256), 0, s, img, stride, H, W, w9x64, bias, out);
+    if (img_f32) hipLaunchKernelGGL(conv1a_u8_kernel<float>, dim3(blocks, B), dim3(256), 0, s, (const float*)img, stride, H, W, w9x64, bias, out);
+    else hipLaunchKernelGGL(conv1a_u8_kernel<uint8_t>, dim3(blocks, B), dim3(256), 0, s, (const uint8_t*)img, stride, H, W, w9x64, bias, out);
 }
 
 }  // namespace rfe

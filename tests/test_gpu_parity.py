@@ -112,6 +112,26 @@ def test_extract_bitexact_vs_oracle(ctx, oracle, H, W, kmax):
         assert np.array_equal(desc[i], r["desc"])      # stated bar 1e-4; achieved: bit-exact
 
 
+@pytest.mark.parametrize("H,W,kmax", [(120, 160, 300), (480, 640, 1024), (93, 201, 64)])
+def test_extract_float_entry_bitexact_vs_oracle(ctx, oracle, H, W, kmax):
+    """rfe_extract_f32 = the reference's Extractor_Inference on a CV_32F image (superpoint_onnx.cc:88-118): (a) on u8 * (1/255) it is the u8
+    entry bit for bit, (b) on values off the 1/255 lattice and outside [0, 1] it is the oracle's float entry bit for bit."""
+    frames, _ = synth.make_frames(2, H, W, seed=kmax + 1)
+    w = Wt.make_superpoint(seed=7)
+    f = frames.astype(np.float32) * np.float32(0.003921568859368563)
+    a = ctx.extract(frames, kmax=kmax)
+    b = ctx.extract_f32(f, kmax=kmax)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    rng = np.random.default_rng(kmax)
+    g = (f * np.float32(1.7) - np.float32(0.2) + rng.uniform(-0.001, 0.001, f.shape).astype(np.float32)).astype(np.float32)
+    n, kxy, score, desc = ctx.extract_f32(g, kmax=kmax)
+    for i in range(2):
+        r = oracle.superpoint(w, g[i], kmax=kmax)
+        assert n[i] == r["n"] and r["n"] > 10
+        assert np.array_equal(kxy[i], r["kxy"]) and np.array_equal(score[i], r["score"]) and np.array_equal(desc[i], r["desc"])
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_extract_vs_golden(ctx, golden_dir, tag):
     g = np.load(f"{golden_dir}/sp_{tag}.npz")

@@ -103,3 +103,23 @@ def test_descriptors_unit_norm_and_keypoints_inside_border(oracle):
     k = r["kxy"][:n]
     assert (k[:, 0] >= 4).all() and (k[:, 0] < 160 - 4).all() and (k[:, 1] >= 4).all() and (k[:, 1] < 120 - 4).all()
     assert (r["score"][:n] > 0.0005).all()
+
+
+def test_float_entry_is_the_graph_behind_normalize_image(oracle):
+    """Reference: Extractor_Inference is handed a CV_32F image (superpoint_onnx.cc:88-118) that NormalizeImage made from the u8 frame
+    (transform.cpp:11).  The oracle's float entry on u8 * (1/255) must therefore equal its u8 entry bit for bit, and a float image
+    that is NOT on the 1/255 lattice (what the HIP shim used to refuse) must give a different, valid result."""
+    from rover_slam_amd import synth
+    w = Wt.make_superpoint(seed=7)
+    img = synth.make_frames(1, 72, 104, seed=12)[0][0]
+    a = oracle.superpoint(w, img, kmax=200)
+    f = img.astype(np.float32) * np.float32(0.003921568859368563)
+    b = oracle.superpoint(w, f, kmax=200)
+    assert a["n"] == b["n"] > 10
+    for k in ("kxy", "score", "desc"):
+        assert np.array_equal(a[k], b[k])
+    rng = np.random.default_rng(5)
+    g = (f * np.float32(1.7) - np.float32(0.2) + rng.uniform(-0.001, 0.001, f.shape).astype(np.float32)).astype(np.float32)   # out of [0, 1], off-lattice
+    c = oracle.superpoint(w, g, kmax=200)
+    assert c["n"] > 10 and not np.array_equal(c["score"], a["score"])
+    assert np.allclose(np.linalg.norm(c["desc"][:c["n"]], axis=1), 1.0, atol=1e-5)

@@ -23,7 +23,7 @@ cd $R
 for w in c2 c3 c5; do
   python bench.py --workload $w --steps 100 --warmup 10 > $OUT/lat_$w.json 2>> $OUT/bench.err
   (cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/trace_$w -o t -- python3 $R/bench.py --workload $w --steps 30 --warmup 5 > $OUT/trace_$w.log 2>&1)
-  python3 tools/rocpd_stats.py $(find $OUT/trace_$w -name "*_results.db" | head -1) > $OUT/stats_$w.md
+  python3 tools/rocpd_stats.py $(find $OUT/trace_$w -name "*_results.db" | head -1) --gaps > $OUT/stats_$w.md
   rm -rf $OUT/trace_$w
 done
 bash tools/pmc_wait.sh ${TAG}_wait --steps 2 --warmup 1 > /dev/null 2>&1

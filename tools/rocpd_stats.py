@@ -31,5 +31,29 @@ def main(path):
         print(f"| `{short(name)}` | {a[0]} | {a[1] / 1e6:.3f} | {a[1] / a[0] / 1e3:.1f} | {a[2] / 1e3:.1f} | {a[3] / 1e3:.1f} | {100.0 * a[1] / tot:.1f} |")
 
 
+    if "--gaps" in sys.argv:
+        gaps(rows)
+
+
+def gaps(rows):
+    """How much of a step is NOT kernel time: idle intervals between consecutive dispatches (union over streams).  Gaps above 100 us are the
+    host side between steps (synchronise, timing, next call) and are listed apart."""
+    iv = sorted((s, e) for _, s, e in rows)
+    busy = 0; cur_s, cur_e = iv[0]; small = []; big = []
+    for s, e in iv[1:]:
+        if s > cur_e:
+            busy += cur_e - cur_s
+            (small if s - cur_e < 100_000 else big).append(s - cur_e)
+            cur_s, cur_e = s, e
+        else:
+            cur_e = max(cur_e, e)
+    busy += cur_e - cur_s
+    small.sort()
+    n = len(small)
+    print(f"\nTimeline: {busy / 1e6:.3f} ms with at least one kernel running; {n} idle gaps < 100 us between consecutive dispatches, total {sum(small) / 1e6:.3f} ms "
+          f"(median {small[n // 2] / 1e3 if n else 0:.2f} us, 90th percentile {small[int(n * 0.9)] / 1e3 if n else 0:.2f} us, max {small[-1] / 1e3 if n else 0:.2f} us) "
+          f"= {100.0 * sum(small) / max(busy + sum(small), 1):.1f} % of the in-step time; {len(big)} gaps >= 100 us (between steps / calls), total {sum(big) / 1e6:.3f} ms.")
+
+
 if __name__ == "__main__":
     main(sys.argv[1])
