@@ -127,29 +127,29 @@ private:
         extractor_outputtensors.clear();
         if (!ExtractorSession) { std::cerr << "[ERROR] Extractor inference failed : no session" << std::endl; return EXIT_FAILURE; }
         const int K = max_keypoints;
-        std::vector<int32_t>& kxy = stage_kxy_;        // grow-only staging owned by the runner: nothing K-sized is allocated per call
-        std::vector<float>&sc = stage_score_, &desc = stage_desc_;
-        if (kxy.size() < (size_t)K * 2) { kxy.resize((size_t)K * 2); sc.resize(K); desc.resize((size_t)K * 256); }
+        std::vector<int32_t>& kxy = stage_kxy_;        // grow-only staging owned by the runner (int32 keypoints; the tensors below are int64 / float)
+        if (kxy.size() < (size_t)K * 2) kxy.resize((size_t)K * 2);
+        // the library writes scores and descriptors straight into K-row tensors; the n <= K detected rows are declared afterwards
+        std::vector<rfe::Tensor> out;
+        out.emplace_back(std::vector<int64_t>{1, K, 2}, sizeof(int64_t));
+        out.emplace_back(std::vector<int64_t>{1, K}, sizeof(float));
+        out.emplace_back(std::vector<int64_t>{1, K, 256}, sizeof(float));
+        float* sc = out[1].GetTensorMutableData<float>();
+        float* desc = out[2].GetTensorMutableData<float>();
         int32_t n = 0;
         auto t0 = std::chrono::high_resolution_clock::now();
-        int rc = f32 ? rfe_extract_f32(ExtractorSession, (const float*)img, H, W, stride, 1, K, detection_threshold, &n, kxy.data(), sc.data(), desc.data())
-                     : rfe_extract_u8(ExtractorSession, (const unsigned char*)img, H, W, stride, 1, K, detection_threshold, &n, kxy.data(), sc.data(), desc.data());
+        int rc = f32 ? rfe_extract_f32(ExtractorSession, (const float*)img, H, W, stride, 1, K, detection_threshold, &n, kxy.data(), sc, desc)
+                     : rfe_extract_u8(ExtractorSession, (const unsigned char*)img, H, W, stride, 1, K, detection_threshold, &n, kxy.data(), sc, desc);
         extractor_timer += std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count();
         if (rc != RFE_OK) {
             std::cerr << "[ERROR] Extractor inference failed : " << rfe_last_error(ExtractorSession) << std::endl;
             return EXIT_FAILURE;
         }
-        std::vector<rfe::Tensor> out;
-        out.emplace_back(std::vector<int64_t>{1, n, 2}, sizeof(int64_t));
-        out.emplace_back(std::vector<int64_t>{1, n}, sizeof(float));
-        out.emplace_back(std::vector<int64_t>{1, n, 256}, sizeof(float));
         int64_t* k64 = out[0].GetTensorMutableData<int64_t>();
         for (int i = 0; i < 2 * n; ++i) k64[i] = kxy[i];
-        std::copy(sc.begin(), sc.begin() + n, out[1].GetTensorMutableData<float>());
-        std::copy(desc.begin(), desc.begin() + (size_t)n * 256, out[2].GetTensorMutableData<float>());
+        out[0].ShrinkTo({1, n, 2}); out[1].ShrinkTo({1, n}); out[2].ShrinkTo({1, n, 256});
         extractor_outputtensors.emplace_back(std::move(out));
         return EXIT_SUCCESS;
     }
     std::vector<int32_t> stage_kxy_;
-    std::vector<float> stage_score_, stage_desc_;
 };

@@ -22,6 +22,9 @@ public:
     TensorShapeInfo GetTensorTypeAndShapeInfo() const { return TensorShapeInfo{shape_}; }
     template <typename T> T* GetTensorMutableData() { return (T*)buf_.get(); }
     template <typename T> const T* GetTensorData() const { return (const T*)buf_.get(); }
+    // keep the buffer, declare fewer elements (the drop-in runner lets the library write straight into a K-row tensor and then
+    // declares the n <= K rows that were detected, instead of copying out of a staging vector)
+    void ShrinkTo(std::vector<int64_t> shape) { shape_ = std::move(shape); }
     bool IsTensor() const { return true; }
     bool HasValue() const { return (bool)buf_; }
 private:

@@ -49,11 +49,12 @@ __device__ unsigned long long rfe_dbg_ts[2048 * 8];
 // WI x WJ: 16-column (n) x 16-row (m) blocks per wave; WGN x WGM: waves per workgroup along n and m (WGN * WGM == 4).
 // LSTAGES: depth of the LDS ring (LSTAGES - 1 stages in flight under the matrix instructions of one).
 template <int WI, int WJ, int WGN, int WGM, int LSTAGES, bool RES, bool ROPE>
-__global__ __launch_bounds__(256, 1) void gemm_lat_kernel(GemmArgs g, const float* __restrict__ rope_csn, int rope_cols, int MT, int abl) {
-    static_assert(WGN * WGM == 4, "four waves per workgroup");
+__global__ __launch_bounds__(64 * WGN * WGM, 1) void gemm_lat_kernel(GemmArgs g, const float* __restrict__ rope_csn, int rope_cols, int MT, int abl) {
+    constexpr int NW = WGN * WGM;                         // waves per workgroup: 4 (one per SIMD) or 8 (two per SIMD)
+    static_assert(NW == 4 || NW == 8, "four or eight waves per workgroup");
     constexpr int BN = 16 * WI * WGN, BM = 16 * WJ * WGM, ROWS = BN + BM, STAGE_F = ROWS * LBK;
-    constexpr int NDMA = ROWS / 16;                       // copy instructions per wave and stage (one moves 4 rows)
-    static_assert(ROWS % 16 == 0, "rows per stage must split over 4 waves x 4 rows");
+    constexpr int NDMA = ROWS / (4 * NW);                 // copy instructions per wave and stage (one moves 4 rows)
+    static_assert(ROWS % (4 * NW) == 0, "rows per stage must split over the waves x 4 rows");
     static_assert(LSTAGES >= 2 && LSTAGES <= 6 && 4 * NDMA <= 63, "ring depth / copy count outside the counted-wait cases below");
     extern __shared__ __attribute__((aligned(16))) float lds[];   // LSTAGES stages of (BN + BM) x 64 floats
 
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256, 1) void gemm_lat_kernel(GemmArgs g, const floa
     const float* src2[NDMA];
 #pragma unroll
     for (int u = 0; u < NDMA; ++u) {
-        const int R = (wave + 4 * u) * 4 + (lane >> 4);
+        const int R = (wave + NW * u) * 4 + (lane >> 4);
         const int sl = ((lane & 15) ^ (R & 15)) << 2;
         if (R < BN) { src[u] = g.B + (size_t)(n0 + R) * g.ldb + sl; src2[u] = src[u]; }
         else {
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256, 1) void gemm_lat_kernel(GemmArgs g, const floa
 #pragma unroll
         for (int u = 0; u < NDMA; ++u) {
             const float* p = (second ? src2[u] : src[u]) + k0;
-            __builtin_amdgcn_global_load_lds((glat_gptr_t)p, (glat_lds_ptr_t)(lds + st * STAGE_F + (wave + 4 * u) * 4 * LBK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glat_gptr_t)p, (glat_lds_ptr_t)(lds + st * STAGE_F + (wave + NW * u) * 4 * LBK), 16, 0, 0);
         }
     };
 
@@ -232,8 +233,9 @@ bool launch_gemm_lat(hipStream_t s, const GemmArgs& g, const float* rope_csn, in
 #ifdef RFE_TUNING
     const int abl = tune_int("RFE_GLAT_ABL", 0);         // 1 = only the first LSTAGES - 1 stages are copied (timing ablation, wrong results); 4 = record the timeline
     const int stages_env = tune_int("RFE_GLAT_STAGES", 0);
+    const int w8 = tune_int("RFE_GLAT_W8", 3);           // bit 0: qkv, bit 1: residual form with EIGHT waves per workgroup (two per SIMD)
 #else
-    constexpr int abl = 0, stages_env = 0;
+    constexpr int abl = 0, stages_env = 0, w8 = 3;
 #endif
 #define RFE_GLAT_LAUNCH(WI_, WJ_, WGN_, WGM_, LS_, RES_, ROPE_)                                                                  \
     do {                                                                                                                         \
@@ -241,7 +243,7 @@ bool launch_gemm_lat(hipStream_t s, const GemmArgs& g, const float* rope_csn, in
         const int MT = (g.M + BM_ - 1) / BM_;                                                                                    \
         auto kern = gemm_lat_kernel<WI_, WJ_, WGN_, WGM_, LS_, RES_, ROPE_>;                                                     \
         static bool ls_[64]; ensure_dynamic_lds((const void*)kern, BYTES_, ls_);                                                 \
-        hipLaunchKernelGGL(kern, dim3((g.N / BN_) * ((MT + 7) / 8 * 8)), dim3(256), BYTES_, s, g, rope_csn, rope_cols, MT, abl); \
+        hipLaunchKernelGGL(kern, dim3((g.N / BN_) * ((MT + 7) / 8 * 8)), dim3(64 * WGN_ * WGM_), BYTES_, s, g, rope_csn, rope_cols, MT, abl); \
         return true;                                                                                                             \
     } while (0)
     // ring depth: as many 64-k stages as the 160 KB of LDS hold, at most 6 (measured: 3 is as fast -- the kernel is bound by the matrix
@@ -253,14 +255,19 @@ bool launch_gemm_lat(hipStream_t s, const GemmArgs& g, const float* rope_csn, in
         if (stages_env == 3) RFE_GLAT_LAUNCH(WI_, WJ_, WGN_, WGM_, 3, RES_, ROPE_);                                              \
         RFE_GLAT_LAUNCH(WI_, WJ_, WGN_, WGM_, LSMAX_, RES_, ROPE_);                                                              \
     } while (0)
-    // tile: the widest column tile (96 / 64 / 32 columns x 64 rows) that still gives the chip about one workgroup per CU
+    // tile: the widest column tile (96 / 64 / 32 columns x 64 rows) that still gives the chip about one workgroup per CU.  The qkv and the
+    // residual forms run EIGHT waves per workgroup (wave tiles 48 x 16 / 16 x 16 instead of 48 x 32 / 32 x 16): measured on one pair, qkv
+    // 138.6 -> 131.2 us per forward, ffn.3 221 -> 213; the 64-wide plain tiles (ffn.0, cross-qkv) do not gain (305 -> 303) and keep four
+    // (profiles/r04_ab_notes.md) -- the matrix pipe, not latency hiding, is what these kernels wait for
     const long long panels = (g.M + 63) / 64;
     if (rope) {   // qkv
         if (g.N % 96 || res || (rope_cols % 64)) return false;
+        if (w8 & 1) RFE_GLAT_GO(3, 1, 2, 4, false, true);
         RFE_GLAT_GO(3, 2, 2, 2, false, true);
     }
     if (res) {
         if (g.N % 32) return false;
+        if (w8 & 2) RFE_GLAT_GO(1, 1, 2, 4, true, false);
         RFE_GLAT_GO(2, 1, 1, 4, true, false);
     }
     if (g.N % 96 == 0 && panels * (g.N / 96) >= 224) RFE_GLAT_GO(3, 2, 2, 2, false, false);

@@ -33,6 +33,21 @@ int ensure_ws(rfe_ctx* c, void** p, size_t* cur, size_t need) {
     return RFE_OK;
 }
 
+// Pinned host staging (grow-only) for the host-pointer entries a tracking thread calls once per frame: the caller's arrays are pageable
+// (std::vector, cv::Mat), and a hipMemcpyAsync on pageable memory is a synchronous, internally staged copy PER CALL -- four to six of them per
+// entry.  Packing the inputs into one pinned block (one DMA in) and fetching the contiguous device results with one DMA out, then scattering
+// on the host -- together with the runner writing straight into its output tensors -- measured through the drop-in classes (bench.py
+// latency.dropin): one frame 0.914 -> 0.793 ms, one pair 3.28 -> 2.99 ms, one stereo frame 3.43 -> 3.25 ms (profiles/r04_ab_notes.md).
+int ensure_pin(rfe_ctx* c, size_t need) {
+    if (need <= c->h_pin_bytes) return RFE_OK;
+    if (c->h_pin) { RFE_HIP(c, hipStreamSynchronize(c->stream)); RFE_HIP(c, hipHostFree(c->h_pin)); c->h_pin = nullptr; c->h_pin_bytes = 0; }
+    need = (need + ((size_t)1 << 20)) & ~(((size_t)1 << 20) - 1);
+    hipError_t e = hipHostMalloc(&c->h_pin, need, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(c, RFE_ERR_OOM, std::string("hipHostMalloc staging: ") + hipGetErrorString(e));
+    c->h_pin_bytes = need;
+    return RFE_OK;
+}
+
 ProfScope::ProfScope(rfe_ctx* ctx, const char* name, hipStream_t on) : c(ctx), idx(-1), st(on ? on : ctx->stream) {
     if (!c->prof) return;
     if (!c->prof_filter.empty() && c->prof_filter != name) return;
@@ -119,6 +134,7 @@ extern "C" void rfe_destroy(rfe_ctx* c) {
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
     c->sp_hold.reset(); c->lg_hold.reset();   // the last ctx holding a device copy frees it
     fr(c->ws_sp); fr(c->ws_lg); fr(c->ws_io); fr(c->ws_tmp); fr(c->ws_st);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -649,18 +665,22 @@ extern "C" int rfe_extract_u8_bin(rfe_ctx* c, const uint8_t* img, int H, int W, 
     const size_t ib = al((size_t)B * H * W), nb = al((size_t)B * 4), kb = al((size_t)B * Kmax * 8),
                  sb = al((size_t)B * Kmax * 4), db = al((size_t)B * Kmax * 1024), bb = desc_bin ? al((size_t)B * Kmax * 256) : 0;
     if ((rc = ensure_ws(c, &c->ws_io, &c->ws_io_bytes, ib + nb + kb + sb + db + bb))) return rc;
+    if ((rc = ensure_pin(c, ib + nb + kb + sb + db + bb))) return rc;
     char* p = (char*)c->ws_io;
+    char* hp = (char*)c->h_pin;
     uint8_t* d_img = (uint8_t*)p; int32_t* d_n = (int32_t*)(p + ib); int32_t* d_k = (int32_t*)(p + ib + nb);
     float* d_s = (float*)(p + ib + nb + kb); float* d_d = (float*)(p + ib + nb + kb + sb);
-    RFE_HIP(c, hipMemcpy2DAsync(d_img, (size_t)W, img, (size_t)stride, (size_t)W, (size_t)B * H, hipMemcpyHostToDevice, c->stream));
     uint8_t* d_b = desc_bin ? (uint8_t*)(p + ib + nb + kb + sb + db) : nullptr;
+    for (size_t r = 0; r < (size_t)B * H; ++r) memcpy(hp + r * W, img + r * stride, (size_t)W);
+    RFE_HIP(c, hipMemcpyAsync(d_img, hp, (size_t)B * H * W, hipMemcpyHostToDevice, c->stream));
     if ((rc = sp_forward(c, d_img, H, W, W, B, Kmax, thr, d_n, d_k, d_s, d_d, d_b))) return rc;
-    if (desc_bin) RFE_HIP(c, hipMemcpyAsync(desc_bin, d_b, (size_t)B * Kmax * 256, hipMemcpyDeviceToHost, c->stream));
-    RFE_HIP(c, hipMemcpyAsync(n, d_n, (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
-    RFE_HIP(c, hipMemcpyAsync(kxy, d_k, (size_t)B * Kmax * 8, hipMemcpyDeviceToHost, c->stream));
-    RFE_HIP(c, hipMemcpyAsync(score, d_s, (size_t)B * Kmax * 4, hipMemcpyDeviceToHost, c->stream));
-    RFE_HIP(c, hipMemcpyAsync(desc, d_d, (size_t)B * Kmax * 1024, hipMemcpyDeviceToHost, c->stream));
+    RFE_HIP(c, hipMemcpyAsync(hp + ib, p + ib, nb + kb + sb + db + bb, hipMemcpyDeviceToHost, c->stream));   // [n | kxy | score | desc | bin] in one DMA
     RFE_HIP(c, hipStreamSynchronize(c->stream));
+    memcpy(n, hp + ib, (size_t)B * 4);
+    memcpy(kxy, hp + ib + nb, (size_t)B * Kmax * 8);
+    memcpy(score, hp + ib + nb + kb, (size_t)B * Kmax * 4);
+    memcpy(desc, hp + ib + nb + kb + sb, (size_t)B * Kmax * 1024);
+    if (desc_bin) memcpy(desc_bin, hp + ib + nb + kb + sb + db, (size_t)B * Kmax * 256);
     prof_collect(c);
     return RFE_OK;
 }
@@ -685,16 +705,20 @@ extern "C" int rfe_extract_f32(rfe_ctx* c, const float* img, int H, int W, int s
     const size_t ib = al((size_t)B * H * W * 4), nb = al((size_t)B * 4), kb = al((size_t)B * Kmax * 8),
                  sb = al((size_t)B * Kmax * 4), db = al((size_t)B * Kmax * 1024);
     if ((rc = ensure_ws(c, &c->ws_io, &c->ws_io_bytes, ib + nb + kb + sb + db))) return rc;
+    if ((rc = ensure_pin(c, ib + nb + kb + sb + db))) return rc;
     char* p = (char*)c->ws_io;
+    char* hp = (char*)c->h_pin;
     float* d_img = (float*)p; int32_t* d_n = (int32_t*)(p + ib); int32_t* d_k = (int32_t*)(p + ib + nb);
     float* d_s = (float*)(p + ib + nb + kb); float* d_d = (float*)(p + ib + nb + kb + sb);
-    RFE_HIP(c, hipMemcpy2DAsync(d_img, (size_t)W * 4, img, (size_t)stride * 4, (size_t)W * 4, (size_t)B * H, hipMemcpyHostToDevice, c->stream));
+    for (size_t r = 0; r < (size_t)B * H; ++r) memcpy(hp + r * W * 4, img + r * stride, (size_t)W * 4);
+    RFE_HIP(c, hipMemcpyAsync(d_img, hp, (size_t)B * H * W * 4, hipMemcpyHostToDevice, c->stream));
     if ((rc = sp_forward(c, d_img, H, W, W, B, Kmax, thr, d_n, d_k, d_s, d_d, nullptr, true))) return rc;
-    RFE_HIP(c, hipMemcpyAsync(n, d_n, (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
-    RFE_HIP(c, hipMemcpyAsync(kxy, d_k, (size_t)B * Kmax * 8, hipMemcpyDeviceToHost, c->stream));
-    RFE_HIP(c, hipMemcpyAsync(score, d_s, (size_t)B * Kmax * 4, hipMemcpyDeviceToHost, c->stream));
-    RFE_HIP(c, hipMemcpyAsync(desc, d_d, (size_t)B * Kmax * 1024, hipMemcpyDeviceToHost, c->stream));
+    RFE_HIP(c, hipMemcpyAsync(hp + ib, p + ib, nb + kb + sb + db, hipMemcpyDeviceToHost, c->stream));
     RFE_HIP(c, hipStreamSynchronize(c->stream));
+    memcpy(n, hp + ib, (size_t)B * 4);
+    memcpy(kxy, hp + ib + nb, (size_t)B * Kmax * 8);
+    memcpy(score, hp + ib + nb + kb, (size_t)B * Kmax * 4);
+    memcpy(desc, hp + ib + nb + kb + sb, (size_t)B * Kmax * 1024);
     prof_collect(c);
     return RFE_OK;
 }
@@ -925,17 +949,23 @@ extern "C" int rfe_match(rfe_ctx* c, const float* k0n, const float* k1n, const f
     int32_t* dm = (int32_t*)p; p += bi; int32_t* dn = (int32_t*)p; p += bi; int32_t* dS = (int32_t*)p; p += bi;
     int32_t* dp = (int32_t*)p; p += bp; float* dms = (float*)p;
     hipStream_t s = c->stream;
-    RFE_HIP(c, hipMemcpyAsync(dk0, k0n, (size_t)P * Mmax * 8, hipMemcpyHostToDevice, s));
-    RFE_HIP(c, hipMemcpyAsync(dk1, k1n, (size_t)P * Nmax * 8, hipMemcpyHostToDevice, s));
-    RFE_HIP(c, hipMemcpyAsync(dd0, d0, (size_t)P * Mmax * 1024, hipMemcpyHostToDevice, s));
-    RFE_HIP(c, hipMemcpyAsync(dd1, d1, (size_t)P * Nmax * 1024, hipMemcpyHostToDevice, s));
-    RFE_HIP(c, hipMemcpyAsync(dm, m, (size_t)P * 4, hipMemcpyHostToDevice, s));
-    RFE_HIP(c, hipMemcpyAsync(dn, n, (size_t)P * 4, hipMemcpyHostToDevice, s));
+    // inputs packed into the pinned mirror of the device block (one DMA in), results fetched with one DMA out: see ensure_pin
+    const size_t in_bytes = bk0 + bk1 + bd0 + bd1 + 2 * bi, out_bytes = bi + bp + bs;
+    if ((rc = ensure_pin(c, in_bytes + out_bytes))) return rc;
+    char* hp = (char*)c->h_pin;
+    memcpy(hp, k0n, (size_t)P * Mmax * 8);
+    memcpy(hp + bk0, k1n, (size_t)P * Nmax * 8);
+    memcpy(hp + bk0 + bk1, d0, (size_t)P * Mmax * 1024);
+    memcpy(hp + bk0 + bk1 + bd0, d1, (size_t)P * Nmax * 1024);
+    memcpy(hp + bk0 + bk1 + bd0 + bd1, m, (size_t)P * 4);
+    memcpy(hp + bk0 + bk1 + bd0 + bd1 + bi, n, (size_t)P * 4);
+    RFE_HIP(c, hipMemcpyAsync(c->ws_io, hp, in_bytes, hipMemcpyHostToDevice, s));
     if ((rc = rfe_match_dev(c, dk0, dk1, dd0, dd1, dm, dn, P, Mmax, Nmax, thr, dS, dp, dms))) return rc;
-    RFE_HIP(c, hipMemcpyAsync(S, dS, (size_t)P * 4, hipMemcpyDeviceToHost, s));
-    RFE_HIP(c, hipMemcpyAsync(pairs, dp, (size_t)P * cap * 8, hipMemcpyDeviceToHost, s));
-    RFE_HIP(c, hipMemcpyAsync(ms, dms, (size_t)P * cap * 4, hipMemcpyDeviceToHost, s));
+    RFE_HIP(c, hipMemcpyAsync(hp + in_bytes, dS, out_bytes, hipMemcpyDeviceToHost, s));
     RFE_HIP(c, hipStreamSynchronize(s));
+    memcpy(S, hp + in_bytes, (size_t)P * 4);
+    memcpy(pairs, hp + in_bytes + bi, (size_t)P * cap * 8);
+    memcpy(ms, hp + in_bytes + bi + bp, (size_t)P * cap * 4);
     prof_collect(c);
     return RFE_OK;
 }

@@ -118,6 +118,7 @@ struct rfe_ctx {
     void* ws_sp = nullptr; size_t ws_sp_bytes = 0;
     void* ws_lg = nullptr; size_t ws_lg_bytes = 0;
     void* ws_io = nullptr; size_t ws_io_bytes = 0;   // staging for host-pointer entry points
+    void* h_pin = nullptr; size_t h_pin_bytes = 0;   // pinned host mirror of ws_io for the per-frame host entries (extract / match): one DMA each way
     void* ws_tmp = nullptr; size_t ws_tmp_bytes = 0; // test hooks
     void* ws_st = nullptr; size_t ws_st_bytes = 0;   // stereo stream state: staged views, previous left view's features
     int st_H = 0, st_W = 0, st_K = 0; bool st_have_prev = false;
