@@ -1419,6 +1419,24 @@ extern "C" int rfe_k_scoremap(rfe_ctx* c, const uint8_t* img, int H, int W, int 
     return RFE_OK;
 }
 
+// keypoint selection alone on a caller-provided post-NMS map [B,H,W] (device): candidates > thr, the top Kmax by (score descending, pixel
+// index ascending) or row-major order, through the forward's own launch_select -- so B selects the form (rank-all up to 4 frames, radix
+// select + rank sort above).  Lets the tests drive candidate counts and tie patterns no network output produces.
+extern "C" int rfe_k_select(rfe_ctx* c, const float* nms, int B, int H, int W, int Kmax, float thr, int topk_always, int32_t* n, int32_t* kxy,
+                            float* score) {
+    int rc = sp_check(c, H, W, B, Kmax);
+    if (rc) return rc;
+    if (!nms || !n || !kxy || !score) return fail(c, RFE_ERR_INVALID, "k_select: null pointer");
+    RFE_HIP(c, hipSetDevice(c->device));
+    if ((rc = ensure_ws(c, &c->ws_sp, &c->ws_sp_bytes, sp_ws_bytes(B, H, W)))) return rc;
+    SpBuffers b;
+    sp_carve(c->ws_sp, B, H, W, b);
+    launch_select(c->stream, nms, B, H, W, Kmax, thr, b.cand_score, b.cand_idx, n, kxy, score, (int32_t*)b.ss, topk_always != 0, b.sel_keys, b.sel_n);
+    RFE_HIP(c, hipGetLastError());
+    RFE_HIP(c, hipStreamSynchronize(c->stream));
+    return RFE_OK;
+}
+
 // x + ffn([x | second]) of one LightGlue block with the loaded weights (unfolded W1: `second` is the attention message), through
 // the same lg_ffn the forward uses -- so `rows` selects the path: >= 32768 rows take the 128x256 tiles with the LayerNorm + GELU
 // fused across ffn.0 / ffn.3, a few thousand rows the 64-row tiles with the stand-alone lg_ln_gelu pass.

@@ -402,7 +402,7 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(const float* __restrict__
                                                        int32_t* __restrict__ cand_idx, int32_t* __restrict__ n_out,
                                                        int32_t* __restrict__ kxy, float* __restrict__ score,
                                                        const int32_t* __restrict__ chunk_cnt, int nch, int topk_always,
-                                                       unsigned long long* __restrict__ sel_keys, int32_t* __restrict__ sel_n, int min_count) {
+                                                       unsigned long long* __restrict__ sel_keys, int32_t* __restrict__ sel_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);  // [P2]
     __shared__ int wave_tot[SEL_T / 64];
@@ -418,7 +418,6 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(const float* __restrict__
     // candidates were compacted in row-major order by select_count_kernel / select_compact_kernel
     int count = 0;
     for (int c = 0; c < nch; ++c) count += chunk_cnt[b * nch + c];
-    if (count <= min_count) { if (tid == 0) sel_n[b] = -1; return; }   // select_rankall_kernel has done this frame
 
     int32_t* okxy = kxy + (size_t)b * Kmax * 2;
     float* osc = score + (size_t)b * Kmax;
@@ -529,15 +528,15 @@ __global__ __launch_bounds__(256) void select_rank_kernel(const unsigned long lo
     }
 }
 
-// Latency regime (one or two frames per call): selection AND ordering as one rank computation spread over the chip.  Every candidate's
+// Latency regime (up to four frames per call): selection AND ordering as one rank computation spread over the chip.  Every candidate's
 // rank among ALL candidates of its frame (key = score bits << 32 | ~pixel index, distinct) is the number of larger keys; a candidate with
 // rank < Kmax is a selected keypoint and its rank IS its output row -- no radix select, no single-workgroup tail (select_kernel: 21 us of
-// barriers on one CU, + 5 us of select_rank_kernel).  Workgroup (x, frame) loads the frame's keys into LDS and ranks candidates
-// 32 x .. 32 x + 31, eight threads per candidate scanning an eighth of the list each with 16-byte reads.  count <= Kmax without the
-// unconditional top-k: row-major copy (the published top_k_keypoints).  Frames with more than RA_MAX candidates (does not happen after a
-// radius-4 NMS on VGA-class images: at most one survivor per 5 x 5 block) are left to select_kernel / select_rank_kernel, which are
-// launched behind this kernel and return at once otherwise.
-constexpr int RA_MAX = 16384, RA_PER = 32;   // candidates per frame the kernel takes (128 KB of keys in LDS); candidates ranked per workgroup
+// barriers on one CU, + 5 us of select_rank_kernel).  A workgroup loads the frame's keys into LDS and ranks 32 candidates, eight threads
+// per candidate scanning an eighth of the list each with 16-byte reads.  count <= Kmax without the unconditional top-k: row-major copy
+// (the published top_k_keypoints).  More than RA_MAX candidates (a radius-4 NMS leaves at most one survivor per 5 x 5 block, 12 288 on a
+// VGA frame -- but ties survive together: a constant image keeps EVERY pixel): the key list is walked in windows of RA_MAX and the
+// workgroups stride over the candidates, so the kernel is complete for any count and nothing is launched behind it.
+constexpr int RA_MAX = 16384, RA_PER = 32;   // keys per LDS window (128 KB); candidates ranked per workgroup and pass
 __global__ __launch_bounds__(256) void select_rankall_kernel(const float* __restrict__ cand_score, const int32_t* __restrict__ cand_idx,
                                                              const int32_t* __restrict__ chunk_cnt, int nch, int HW, int W, int Kmax,
                                                              int topk_always, int32_t* __restrict__ n_out, int32_t* __restrict__ kxy,
@@ -547,52 +546,61 @@ __global__ __launch_bounds__(256) void select_rankall_kernel(const float* __rest
     const int b = blockIdx.y, tid = threadIdx.x;
     int count = 0;
     for (int c = 0; c < nch; ++c) count += chunk_cnt[b * nch + c];
-    if (count > RA_MAX) return;
     const float* cs = cand_score + (size_t)b * HW;
     const int32_t* ci = cand_idx + (size_t)b * HW;
     int32_t* okxy = kxy + (size_t)b * Kmax * 2;
     float* osc = score + (size_t)b * Kmax;
     const int nsel = count < Kmax ? count : Kmax;
     if (blockIdx.x == 0 && tid == 0) n_out[b] = nsel;
-    const int t0 = blockIdx.x * RA_PER;
-    if (t0 >= count && t0 >= Kmax) return;
-    // rows [nsel, Kmax) of the padded outputs
-    { const int t = t0 + (tid >> 3); if ((tid & 7) == 0 && t >= nsel && t < Kmax) { okxy[2 * t] = 0; okxy[2 * t + 1] = 0; osc[t] = 0.f; } }
-    if (t0 >= count) return;
-    if (count <= Kmax && !topk_always) {      // nothing to cut: row-major order
-        const int t = t0 + (tid >> 3);
-        if ((tid & 7) == 0 && t < count) { const int idx = ci[t]; okxy[2 * t] = idx % W; okxy[2 * t + 1] = idx / W; osc[t] = cs[t]; }
-        return;
-    }
-    // keys of the whole frame into LDS, four independent (score, index) loads in flight per thread
-    for (int k0 = tid; k0 < count; k0 += 4 * 256) {
-        float sc[4]; int ix[4];
+    const int span = count > Kmax ? count : Kmax;
+    const int nwin = (count + RA_MAX - 1) / RA_MAX;
+    const bool rowmajor = count <= Kmax && !topk_always;      // nothing to cut: row-major order
+    auto make_key = [](float sc, int ix) { return ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)ix); };
+    // keys [w0, w0 + wn) of the frame into LDS, four independent (score, index) loads in flight per thread
+    auto load_window = [&](int w0, int wn) {
+        for (int k0 = tid; k0 < wn; k0 += 4 * 256) {
+            float sc[4]; int ix[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int k = k0 + u * 256; sc[u] = k < count ? cs[k] : 0.f; ix[u] = k < count ? ci[k] : 0; }
+            for (int u = 0; u < 4; ++u) { const int k = k0 + u * 256; sc[u] = k < wn ? cs[w0 + k] : 0.f; ix[u] = k < wn ? ci[w0 + k] : 0; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = k0 + u * 256;
-            if (k < count) keys[k] = ((unsigned long long)__float_as_uint(sc[u]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)ix[u]);
+            for (int u = 0; u < 4; ++u) { const int k = k0 + u * 256; if (k < wn) keys[k] = make_key(sc[u], ix[u]); }
         }
-    }
-    __syncthreads();
-    const int t = t0 + (tid >> 3), part = tid & 7;      // eight threads per candidate, each scans an eighth of the key pairs
-    if (t >= count) return;
-    const unsigned long long key = keys[t];
-    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-    const u64x2* kp = reinterpret_cast<const u64x2*>(keys);
-    const int npair = count >> 1;
-    int rank = 0;
+    };
+    bool loaded = false;
+    for (int t0 = blockIdx.x * RA_PER; t0 < span; t0 += gridDim.x * RA_PER) {
+        const int t = t0 + (tid >> 3), part = tid & 7;      // eight threads per candidate, each scans an eighth of the key pairs
+        if (part == 0 && t >= nsel && t < Kmax) { okxy[2 * t] = 0; okxy[2 * t + 1] = 0; osc[t] = 0.f; }   // rows [nsel, Kmax) of the padded outputs
+        if (t0 >= count) continue;
+        if (rowmajor) {
+            if (part == 0 && t < count) { const int idx = ci[t]; okxy[2 * t] = idx % W; okxy[2 * t + 1] = idx / W; osc[t] = cs[t]; }
+            continue;
+        }
+        const bool live = t < count;
+        const unsigned long long key = live ? make_key(cs[t], ci[t]) : ~0ull;
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        const u64x2* kp = reinterpret_cast<const u64x2*>(keys);
+        int rank = 0;
+        for (int w = 0; w < nwin; ++w) {
+            const int w0 = w * RA_MAX, wn = count - w0 < RA_MAX ? count - w0 : RA_MAX;
+            if (nwin > 1 || !loaded) {
+                if (loaded) __syncthreads();                 // everybody has left the previous window
+                load_window(w0, wn);
+                loaded = true;
+                __syncthreads();
+            }
+            const int npair = wn >> 1;
 #pragma unroll 8
-    for (int j = part; j < npair; j += 8) { const u64x2 kk = kp[j]; rank += (kk[0] > key ? 1 : 0) + (kk[1] > key ? 1 : 0); }
-    if ((count & 1) && part == 0) rank += keys[count - 1] > key ? 1 : 0;
-    rank += __shfl_xor(rank, 1);
-    rank += __shfl_xor(rank, 2);
-    rank += __shfl_xor(rank, 4);
-    if (part == 0 && rank < Kmax) {
-        const int idx = (int)(0xFFFFFFFFu - (unsigned int)(key & 0xFFFFFFFFull));
-        okxy[2 * rank] = idx % W; okxy[2 * rank + 1] = idx / W;
-        osc[rank] = __uint_as_float((unsigned int)(key >> 32));
+            for (int j = part; j < npair; j += 8) { const u64x2 kk = kp[j]; rank += (kk[0] > key ? 1 : 0) + (kk[1] > key ? 1 : 0); }
+            if ((wn & 1) && part == 0) rank += keys[wn - 1] > key ? 1 : 0;
+        }
+        rank += __shfl_xor(rank, 1);
+        rank += __shfl_xor(rank, 2);
+        rank += __shfl_xor(rank, 4);
+        if (live && part == 0 && rank < Kmax) {
+            const int idx = (int)(0xFFFFFFFFu - (unsigned int)(key & 0xFFFFFFFFull));
+            okxy[2 * rank] = idx % W; okxy[2 * rank + 1] = idx / W;
+            osc[rank] = __uint_as_float((unsigned int)(key >> 32));
+        }
     }
 }
 
@@ -606,18 +614,16 @@ void launch_select(hipStream_t s, const float* nms, int B, int H, int W, int Kma
     hipLaunchKernelGGL(select_compact_kernel, dim3(nch, B), dim3(256), 0, s, nms, HW, nch, thr, chunk_cnt, cand_score, cand_idx);
     // one or two frames: rank-all over the chip; more: one select workgroup per frame already runs the frames in parallel
     static const int ra_frames = tune_int("RFE_SELECT_RANKALL", 4);   // tuning build: 0 = the radix-select form at every batch size
-    int min_count = -1;
     if (B <= ra_frames) {
         const int cap = HW < RA_MAX ? HW : RA_MAX, span = cap > Kmax ? cap : Kmax;
         static bool ls_[64];
         ensure_dynamic_lds((const void*)select_rankall_kernel, RA_MAX * 8, ls_);
         hipLaunchKernelGGL(select_rankall_kernel, dim3((span + RA_PER - 1) / RA_PER, B), dim3(256), (size_t)cap * 8, s, cand_score, cand_idx, chunk_cnt, nch, HW, W,
                            Kmax, topk_always ? 1 : 0, n_out, kxy, score);
-        if (HW <= RA_MAX) return;           // no frame of this size can exceed the rank-all capacity
-        min_count = RA_MAX;
+        return;
     }
     hipLaunchKernelGGL(select_kernel, dim3(B), dim3(SEL_T), (size_t)P2 * 8, s, nms, H, W, Kmax, P2, thr,
-                       cand_score, cand_idx, n_out, kxy, score, chunk_cnt, nch, topk_always ? 1 : 0, sel_keys, sel_n, min_count);
+                       cand_score, cand_idx, n_out, kxy, score, chunk_cnt, nch, topk_always ? 1 : 0, sel_keys, sel_n);
     hipLaunchKernelGGL(select_rank_kernel, dim3((Kmax + 63) / 64, B), dim3(256), (size_t)Kmax * 8, s, sel_keys, sel_n, W, Kmax, kxy, score);
 }
 

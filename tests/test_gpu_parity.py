@@ -450,6 +450,48 @@ def test_constant_image_no_crash(ctx, oracle):
     assert n[0] == r["n"] and np.array_equal(kxy[0], r["kxy"]) and np.array_equal(score[0], r["score"])
 
 
+def _select_reference(m, kmax, thr, always):
+    """numpy statement of the selection rule (oracle: rfe_oracle.c top-k part; published top_k_keypoints)"""
+    idx = np.flatnonzero(m.ravel() > thr)
+    sc = m.ravel()[idx]
+    if idx.size > kmax or always:
+        order = np.lexsort((idx, -sc.astype(np.float64)))[:kmax]      # score descending, pixel index ascending
+        idx, sc = idx[order], sc[order]
+    n = idx.size
+    kxy = np.zeros((kmax, 2), np.int32); score = np.zeros((kmax,), np.float32)
+    kxy[:n, 0] = idx % m.shape[1]; kxy[:n, 1] = idx // m.shape[1]; score[:n] = sc
+    return n, kxy, score
+
+
+@pytest.mark.parametrize("B", [1, 2, 5])
+@pytest.mark.parametrize("density,levels,kmax,always", [(0.5, 7, 1024, 0), (0.9, 3, 4096, 0), (0.02, 5, 1024, 0), (0.02, 5, 1024, 1), (0.6, 0, 333, 0)])
+def test_select_kernels_any_candidate_count(ctx, B, density, levels, kmax, always):
+    """The selection stage alone on synthetic post-NMS maps (rfe_k_select): far more candidates than one LDS window of the rank-all form
+    holds (B <= 4; > 16 384 per frame, which only tie-rich maps produce) and than the radix-select form's Kmax (B = 5), with only a few
+    distinct score levels so that the cut falls INSIDE a run of equal scores and is decided by the pixel index; also counts below Kmax
+    (row-major order, or score order when the graph's TopK is unconditional)."""
+    from rover_slam_amd import capi
+    H, W = 160, 232
+    rng = np.random.default_rng(B * 1000 + kmax + int(density * 100) + always)
+    m = rng.uniform(0.001, 1.0, (B, H, W)).astype(np.float32)
+    if levels:
+        m = (np.floor(m * levels) / levels + 0.01).astype(np.float32)
+    m[rng.uniform(size=m.shape) > density] = 0.0
+    m[:, :4] = -1; m[:, -4:] = -1; m[:, :, :4] = -1; m[:, :, -4:] = -1
+    if density >= 0.5:
+        assert int((m[0] > 0.0005).sum()) > 16384
+    dm = _dev(ctx, m)
+    dn, dk, ds = ctx.alloc(B * 4), ctx.alloc(B * kmax * 8), ctx.alloc(B * kmax * 4)
+    ctx._chk(capi.lib.rfe_k_select(ctx.h, dm.ptr, B, H, W, kmax, 0.0005, always, dn.ptr, dk.ptr, ds.ptr))
+    n = dn.download((B,), np.int32); kxy = dk.download((B, kmax, 2), np.int32); score = ds.download((B, kmax), np.float32)
+    for i in range(B):
+        rn, rk, rs = _select_reference(m[i], kmax, 0.0005, always)
+        assert n[i] == rn
+        assert np.array_equal(kxy[i], rk) and np.array_equal(score[i], rs)
+    for d in (dm, dn, dk, ds):
+        d.free()
+
+
 @pytest.mark.parametrize("B,H,W,K", [(5, 120, 160, 128), (3, 240, 320, 512), (7, 240, 320, 384), (6, 208, 232, 32), (3, 200, 152, 48)])
 def test_stream_mode_equals_pairwise(ctx, oracle, B, H, W, K):
     """rfe_extract_match_stream_dev (B frames, matches (i,i+1), first self block shared per frame) gives the same
