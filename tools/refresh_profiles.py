@@ -90,7 +90,16 @@ SQ rows are per XCD/SE slice: MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (32 
             lat.append(f"## {w}: {x['ms_per_step']} ms per step ({x['value']} {x['unit']}); with an event pair around every stage {x.get('ms_per_step_with_stage_events')} ms\n")
             lat.append("stage table (ms per step, events around every stage): " + ", ".join(f"{k} {v}" for k, v in x.get("stages_ms_per_step", {}).items()) + "\n")
         if os.path.exists(g):
-            lat.append("\n".join(open(g).read().replace(ROOT + "/", "").splitlines()[:34]) + "\n")
+            lines = open(g).read().replace(ROOT + "/", "").splitlines()
+            lat.append("\n".join(lines[:34]) + "\n")
+            tl = [ln for ln in lines if ln.startswith("Timeline:")]
+            if tl:
+                import re as _re
+                m = _re.search(r"Timeline: ([0-9.]+) ms", tl[0])
+                steps_traced = 65            # 30 steps + 5 warm-up, two passes (plain + with stage events)
+                lat.append(tl[0] + f"\n\n(= {float(m.group(1)) / steps_traced:.3f} ms per traced step with at least one kernel running, against the UNTRACED wall time above: the ~10 us gaps are the "
+                           "profiler's per-dispatch completion handling, the untraced stream has none of that size -- a kernel boundary costs 2.4-4.3 us all in, "
+                           f"profiles/{rnd}_grid_barrier.md.)\n")
     open(os.path.join(P, f"{rnd}_latency_kernel_stats.md"), "w").write("\n".join(lat))
     # ---- RFE_OPT_LG_FP16X2 diagnostic configuration (same binary, same box, same call)
     fb = os.path.join(O, "bench_fp16x2.json")
@@ -101,12 +110,34 @@ SQ rows are per XCD/SE slice: MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (32 
         body = open(os.path.join(O, "stats_fp16x2.md")).read().replace(ROOT + "/", "") if os.path.exists(os.path.join(O, "stats_fp16x2.md")) else ""
         clk = open(os.path.join(O, "pmc_sq_fp16x2.md")).read() if os.path.exists(os.path.join(O, "pmc_sq_fp16x2.md")) else ""
         clk = clk[:clk.index("```json")] if "```json" in clk else clk
+
+        def mhz(table, want):
+            """kernel name prefix -> (avg us, GRBM_GUI_ACTIVE) from a rocpd_pmc table whose header names the columns"""
+            cols = None
+            for ln in table.splitlines():
+                cells = [c.strip() for c in ln.strip().strip("|").split("|")]
+                if "GRBM_GUI_ACTIVE" in cells:
+                    cols = (cells.index("avg us"), cells.index("GRBM_GUI_ACTIVE"))
+                elif cols and cells and cells[0].startswith("`" + want):
+                    return float(cells[cols[0]]), float(cells[cols[1]])
+            return None
+        default_pmc = open(os.path.join(P, f"{rnd}_pmc.md")).read() if os.path.exists(os.path.join(P, f"{rnd}_pmc.md")) else ""
+        note = ""
+        rows = []
+        for k in ("conv1ab_fused_kernel", "conv3x3_mfma_kernel<64, false, true, 2, 8>", "conv3x3_mfma_kernel<128, true, true, 5, 8>"):
+            a, b = mhz(default_pmc, k), mhz(clk, k)
+            if a and b:
+                rows.append(f"| `{k}` | {a[0]:.1f} | {a[1]:.4g} | {a[1] / a[0]:.0f} | {b[0]:.1f} | {b[1]:.4g} | {b[1] / b[0]:.0f} |")
+        if rows:
+            note = ("\nThe SuperPoint kernels are the SAME code in both configurations; they take the same number of shader cycles and run at a lower clock when the option is on "
+                    "(consistent with power management over the whole step: its f16 matrix phases draw more; the clock is not a property of the kernel):\n\n"
+                    "| kernel | default: avg us | GRBM_GUI_ACTIVE | MHz | fp16x2 on: avg us | GRBM_GUI_ACTIVE | MHz |\n|---|---:|---:|---:|---:|---:|---:|\n" + "\n".join(rows) + "\n")
         open(os.path.join(P, f"{rnd}_fp16x2_kernel_stats.md"), "w").write(
             f"# Round {int(rnd[1:])} -- rocprofv3 --kernel-trace summary with RFE_OPT_LG_FP16X2 ON (diagnostic run; the default / headline configuration is "
             f"{rnd}_kernel_stats.md)\n\n{stamp_line}\nUn-profiled line of the same configuration from the same box, same call (`bench.py --steps 20 --warmup 3 --lg-fp16x2 1 --no-pool "
             f"--no-pcie`): profiles/{rnd}_bench_fp16x2.json ({x['value']} frames/s, {x['ms_per_step']} ms/step).\n\n" + body +
             "\n## Clocks in this configuration (`--pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES`; clock = GRBM_GUI_ACTIVE / duration; compare the SQ / GRBM "
-            f"table of {rnd}_pmc.md for the default configuration)\n\n" + clk)
+            f"table of {rnd}_pmc.md for the default configuration)\n\n" + clk + note)
     # ---- what the waves wait on: throughput step, single pair, fp16x2
     tags = [t for t in (tag + "_wait", tag + "_wait_c3") if os.path.exists(os.path.join(ROOT, "gpurun_out", t, "table.md"))]
     if len(tags) == 2:
