@@ -69,7 +69,12 @@ __global__ __launch_bounds__(64 * WGN * WGM, 1) void gemm_lat_kernel(GemmArgs g,
     if (mt >= MT) return;
     const int n0 = nt * BN, m0 = mt * BM;
     const int wn = wave % WGN, wm = wave / WGN;
-    const int M = g.M;
+    // batch entry z (the similarity matrix of pair z: A, B, C strided; no second A source / residual there), rows past m_valid[z] not stored
+    const int z = blockIdx.y;
+    int M = g.M;
+    if (g.m_valid) { const int mv = g.m_valid[z]; M = mv < M ? mv : M; }
+    if (m0 >= M) return;
+    g.A += (size_t)z * g.sA; g.B += (size_t)z * g.sB; g.C += (size_t)z * g.sC;
     const int T = g.K / LBK;
 
     // ---- copy geometry: group G = 4 consecutive LDS rows; wave w issues groups w, w + 4, ...  Lane l fills row 4 G + (l >> 4), physical slot l & 15
@@ -227,7 +232,8 @@ extern "C" int rfe_k_dbg_timeline(unsigned long long* host, int n) {   // tuning
 // is launched; the caller falls back to gemm.hip's tiles).
 bool launch_gemm_lat(hipStream_t s, const GemmArgs& g, const float* rope_csn, int rope_cols) {
     const int batch = g.batch > 0 ? g.batch : 1;
-    if (!g.kperm || batch != 1 || g.m_valid || g.K % LBK || (g.A2 && g.K1 % LBK) || g.M > 8192 || g.M < 1 || g.Bh || g.stats_in || g.stats_out) return false;
+    if (batch > 1 && (g.A2 || g.R || rope_csn || batch > 16)) return false;
+    if (!g.kperm || g.K % LBK || (g.A2 && g.K1 % LBK) || g.M > 8192 || g.M < 1 || g.Bh || g.stats_in || g.stats_out) return false;
     if ((g.lda % 4) || (g.ldb % 4) || (g.ldc % 4) || (g.A2 && (g.lda2 % 4)) || (g.R && (g.ldr % 4))) return false;
     const bool res = g.R != nullptr, rope = rope_csn != nullptr;
 #ifdef RFE_TUNING
@@ -243,7 +249,7 @@ bool launch_gemm_lat(hipStream_t s, const GemmArgs& g, const float* rope_csn, in
         const int MT = (g.M + BM_ - 1) / BM_;                                                                                    \
         auto kern = gemm_lat_kernel<WI_, WJ_, WGN_, WGM_, LS_, RES_, ROPE_>;                                                     \
         static bool ls_[64]; ensure_dynamic_lds((const void*)kern, BYTES_, ls_);                                                 \
-        hipLaunchKernelGGL(kern, dim3((g.N / BN_) * ((MT + 7) / 8 * 8)), dim3(64 * WGN_ * WGM_), BYTES_, s, g, rope_csn, rope_cols, MT, abl); \
+        hipLaunchKernelGGL(kern, dim3((g.N / BN_) * ((MT + 7) / 8 * 8), batch), dim3(64 * WGN_ * WGM_), BYTES_, s, g, rope_csn, rope_cols, MT, abl); \
         return true;                                                                                                             \
     } while (0)
     // ring depth: as many 64-k stages as the 160 KB of LDS hold, at most 6 (measured: 3 is as fast -- the kernel is bound by the matrix
@@ -259,7 +265,7 @@ bool launch_gemm_lat(hipStream_t s, const GemmArgs& g, const float* rope_csn, in
     // residual forms run EIGHT waves per workgroup (wave tiles 48 x 16 / 16 x 16 instead of 48 x 32 / 32 x 16): measured on one pair, qkv
     // 138.6 -> 131.2 us per forward, ffn.3 221 -> 213; the 64-wide plain tiles (ffn.0, cross-qkv) do not gain (305 -> 303) and keep four
     // (profiles/r04_ab_notes.md) -- the matrix pipe, not latency hiding, is what these kernels wait for
-    const long long panels = (g.M + 63) / 64;
+    const long long panels = (long long)batch * ((g.M + 63) / 64);
     if (rope) {   // qkv
         if (g.N % 96 || res || (rope_cols % 64)) return false;
         if (w8 & 1) RFE_GLAT_GO(3, 1, 2, 4, false, true);

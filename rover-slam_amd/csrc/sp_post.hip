@@ -167,8 +167,11 @@ static void launch_nms_r(hipStream_t st, const float* score, int B, int H, int W
 // of a column): 12 loaded values give four 9-wide maxima in 17 max operations (shared middle, left and right running partials), and all
 // index arithmetic divides by compile-time constants (a first version with one output per item and run-time frame sizes took 78 us per
 // frame -- slower than the five launches it replaced).
-constexpr int NF_R = 4, NF_HALO = 5 * NF_R, NF_IH = NTH + 2 * NF_HALO, NF_IW = NTW + 2 * NF_HALO;   // 72 x 104
-static_assert(NF_IW % 4 == 0 && NF_IH % 4 == 0, "quad items");
+// The output tile is TH x 64 with TH = 32 / 40 / 48 (LDS 127 / 141 / 156 KB, always one workgroup per CU): the launcher takes the smallest
+// one that puts all frames of the call into ONE round of 256 workgroups (two VGA frames: 2 x 150 tiles of 32 rows are two rounds, 2 x 120 of
+// 40 rows one: 52.6 -> see profiles/r04_ab_notes.md).
+constexpr int NF_R = 4, NF_HALO = 5 * NF_R, NF_IW = NTW + 2 * NF_HALO;   // 104 columns
+static_assert(NF_IW % 4 == 0, "quad items");
 
 // four 9-wide maxima from 12 consecutive values v[0..11]: out[i] = max(v[i .. i + 8])
 __device__ __forceinline__ void max9x4(const float (&v)[12], float (&o)[4]) {
@@ -179,7 +182,7 @@ __device__ __forceinline__ void max9x4(const float (&v)[12], float (&o)[4]) {
     o[2] = fmaxf(fmaxf(l2, mid), r10); o[3] = fmaxf(fmaxf(l3, mid), r11);
 }
 // row pass: src valid on the frame of margin M -> T[y][x] = max(src[y][x - 4 .. x + 4]) for rows of that frame, columns of margin M + 4
-template <int M>
+template <int M, int NF_IH>
 __device__ __forceinline__ void nf_rowpass(const float* __restrict__ src, float* __restrict__ T, int tid) {
     constexpr int ROWS = NF_IH - 2 * M, QUADS = (NF_IW - 2 * (M + NF_R)) / 4;
     for (int idx = tid; idx < ROWS * QUADS; idx += 256) {
@@ -194,7 +197,7 @@ __device__ __forceinline__ void nf_rowpass(const float* __restrict__ src, float*
 }
 // column pass over T on the frame of margin M (a multiple of 4): calls f(py, px, pooled value) for every pixel of that frame; an item is
 // four consecutive rows of one column, lanes run along x (conflict-free reads)
-template <int M, typename F>
+template <int M, int NF_IH, typename F>
 __device__ __forceinline__ void nf_colpass(const float* __restrict__ T, int tid, F f) {
     constexpr int COLS = NF_IW - 2 * M, QROWS = (NF_IH - 2 * M) / 4;
     for (int idx = tid; idx < QROWS * COLS; idx += 256) {
@@ -210,7 +213,10 @@ __device__ __forceinline__ void nf_colpass(const float* __restrict__ T, int tid,
     }
 }
 
+template <int TH_>
 __global__ __launch_bounds__(256) void nms_fused_kernel(const float* __restrict__ s, float* __restrict__ out, int H, int W, int border) {
+    constexpr int NF_IH = TH_ + 2 * NF_HALO;
+    static_assert(NF_IH % 4 == 0, "quad items");
     extern __shared__ __attribute__((aligned(16))) float nf_lds[];
     float* const S = nf_lds;                       // scores
     float* const T = S + NF_IH * NF_IW;            // row-pass scratch
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(256) void nms_fused_kernel(const float* __restrict_
     float* const SS = Mk + NF_IH * NF_IW;          // supp_scores
     uint8_t* const SUP = reinterpret_cast<uint8_t*>(SS + NF_IH * NF_IW);   // supp_mask
     const size_t fo = (size_t)blockIdx.z * H * W;
-    const int y0 = blockIdx.y * NTH - NF_HALO, x0 = blockIdx.x * NTW - NF_HALO;
+    const int y0 = blockIdx.y * TH_ - NF_HALO, x0 = blockIdx.x * NTW - NF_HALO;
     const int tid = threadIdx.x;
     for (int idx = tid; idx < NF_IH * NF_IW; idx += 256) {
         const int py = idx / NF_IW, px = idx % NF_IW, gy = y0 + py, gx = x0 + px;
@@ -227,17 +233,17 @@ __global__ __launch_bounds__(256) void nms_fused_kernel(const float* __restrict_
     __syncthreads();
     auto inside = [&](int py, int px) { const int gy = y0 + py, gx = x0 + px; return gy >= 0 && gy < H && gx >= 0 && gx < W; };
     // stage 1: max_mask = s == mp(s)                                                    (score frame 0 -> mask frame 4)
-    nf_rowpass<0>(S, T, tid);
+    nf_rowpass<0, NF_IH>(S, T, tid);
     __syncthreads();
-    nf_colpass<NF_R>(T, tid, [&](int py, int px, float m) {
+    nf_colpass<NF_R, NF_IH>(T, tid, [&](int py, int px, float m) {
         const int o = py * NF_IW + px;
         Mk[o] = inside(py, px) ? (S[o] == m ? 1.f : 0.f) : -INFINITY;
     });
     __syncthreads();
     // round 1: supp_mask = mp(max_mask) > 0 ; supp_scores = supp ? 0 : s                (mask frame 4 -> frame 8)
-    nf_rowpass<NF_R>(Mk, T, tid);
+    nf_rowpass<NF_R, NF_IH>(Mk, T, tid);
     __syncthreads();
-    nf_colpass<2 * NF_R>(T, tid, [&](int py, int px, float m) {
+    nf_colpass<2 * NF_R, NF_IH>(T, tid, [&](int py, int px, float m) {
         const int o = py * NF_IW + px;
         const bool sp = m > 0.f;
         SUP[o] = sp ? 1 : 0;
@@ -245,26 +251,26 @@ __global__ __launch_bounds__(256) void nms_fused_kernel(const float* __restrict_
     });
     __syncthreads();
     //          new_max_mask = supp_scores == mp(supp_scores) ; max_mask |= new & ~supp    (frame 8 -> frame 12)
-    nf_rowpass<2 * NF_R>(SS, T, tid);
+    nf_rowpass<2 * NF_R, NF_IH>(SS, T, tid);
     __syncthreads();
-    nf_colpass<3 * NF_R>(T, tid, [&](int py, int px, float m) {
+    nf_colpass<3 * NF_R, NF_IH>(T, tid, [&](int py, int px, float m) {
         const int o = py * NF_IW + px;
         if (inside(py, px)) Mk[o] = (Mk[o] != 0.f || (SS[o] == m && !SUP[o])) ? 1.f : 0.f;      // stays -inf outside the image
     });
     __syncthreads();
     // round 2                                                                            (mask frame 12 -> frame 16 -> frame 20 = the output tile)
-    nf_rowpass<3 * NF_R>(Mk, T, tid);
+    nf_rowpass<3 * NF_R, NF_IH>(Mk, T, tid);
     __syncthreads();
-    nf_colpass<4 * NF_R>(T, tid, [&](int py, int px, float m) {
+    nf_colpass<4 * NF_R, NF_IH>(T, tid, [&](int py, int px, float m) {
         const int o = py * NF_IW + px;
         const bool sp = m > 0.f;
         SUP[o] = sp ? 1 : 0;
         SS[o] = inside(py, px) ? (sp ? 0.f : S[o]) : -INFINITY;
     });
     __syncthreads();
-    nf_rowpass<4 * NF_R>(SS, T, tid);
+    nf_rowpass<4 * NF_R, NF_IH>(SS, T, tid);
     __syncthreads();
-    nf_colpass<5 * NF_R>(T, tid, [&](int py, int px, float m) {
+    nf_colpass<5 * NF_R, NF_IH>(T, tid, [&](int py, int px, float m) {
         const int o = py * NF_IW + px;
         if (!inside(py, px)) return;
         const bool mk = Mk[o] != 0.f || (SS[o] == m && !SUP[o]);
@@ -281,10 +287,21 @@ void launch_nms(hipStream_t st, const float* score, int B, int H, int W, int rad
     // there are one or two frames), at 33 frames its 4950 workgroups run in 20 rounds and the five light launches win (0.57 vs 0.25 ms per step)
     static const int fused_frames = tune_int("RFE_NMS_FUSED", 4);   // tuning build: 0 = the five-launch form at every batch size
     if (radius == NF_R && B <= fused_frames) {
-        constexpr int bytes = 4 * NF_IH * NF_IW * 4 + NF_IH * NF_IW;
-        static bool ls_[64];
-        ensure_dynamic_lds((const void*)nms_fused_kernel, bytes, ls_);
-        hipLaunchKernelGGL(nms_fused_kernel, dim3((W + NTW - 1) / NTW, (H + NTH - 1) / NTH, B), dim3(256), bytes, st, score, out, H, W, border);
+        const int gx = (W + NTW - 1) / NTW;
+        auto wgs = [&](int th) { return (long long)gx * ((H + th - 1) / th) * B; };
+        static const int th_env = tune_int("RFE_NMS_TH", 0);   // tuning build: force the tile height
+        const int th = th_env ? th_env : (wgs(32) <= 256 ? 32 : wgs(40) <= 256 ? 40 : wgs(48) <= 256 ? 48 : 32);
+#define RFE_NMS_FUSED_GO(TH_)                                                                                                        \
+        do {                                                                                                                         \
+            constexpr int bytes = (TH_ + 2 * NF_HALO) * NF_IW * 17;   /* four float planes + one byte plane */                         \
+            static bool ls_[64];                                                                                                     \
+            ensure_dynamic_lds((const void*)nms_fused_kernel<TH_>, bytes, ls_);                                                      \
+            hipLaunchKernelGGL(nms_fused_kernel<TH_>, dim3(gx, (H + TH_ - 1) / TH_, B), dim3(256), bytes, st, score, out, H, W, border); \
+        } while (0)
+        if (th == 48) RFE_NMS_FUSED_GO(48);
+        else if (th == 40) RFE_NMS_FUSED_GO(40);
+        else RFE_NMS_FUSED_GO(32);
+#undef RFE_NMS_FUSED_GO
         return;
     }
     if (radius == 4) launch_nms_r<4>(st, score, B, H, W, radius, border, tmp_ss, tmp_mask, tmp_supp, out);
@@ -534,9 +551,9 @@ __global__ __launch_bounds__(256) void select_rank_kernel(const unsigned long lo
 // barriers on one CU, + 5 us of select_rank_kernel).  A workgroup loads the frame's keys into LDS and ranks 32 candidates, eight threads
 // per candidate scanning an eighth of the list each with 16-byte reads.  count <= Kmax without the unconditional top-k: row-major copy
 // (the published top_k_keypoints).  More than RA_MAX candidates (a radius-4 NMS leaves at most one survivor per 5 x 5 block, 12 288 on a
-// VGA frame -- but ties survive together: a constant image keeps EVERY pixel): the key list is walked in windows of RA_MAX and the
+// VGA frame -- but equal scores survive together, and larger frames / smaller radii exist): the key list is walked in windows of RA_MAX and the
 // workgroups stride over the candidates, so the kernel is complete for any count and nothing is launched behind it.
-constexpr int RA_MAX = 16384, RA_PER = 32;   // keys per LDS window (128 KB); candidates ranked per workgroup and pass
+constexpr int RA_MAX = 8192, RA_PER = 32;   // keys per LDS window (64 KB: two workgroups per CU; a VGA frame has 5 000 - 6 500 candidates); candidates ranked per workgroup and pass
 __global__ __launch_bounds__(256) void select_rankall_kernel(const float* __restrict__ cand_score, const int32_t* __restrict__ cand_idx,
                                                              const int32_t* __restrict__ chunk_cnt, int nch, int HW, int W, int Kmax,
                                                              int topk_always, int32_t* __restrict__ n_out, int32_t* __restrict__ kxy,

@@ -132,6 +132,19 @@ def test_extract_float_entry_bitexact_vs_oracle(ctx, oracle, H, W, kmax):
         assert np.array_equal(kxy[i], r["kxy"]) and np.array_equal(score[i], r["score"]) and np.array_equal(desc[i], r["desc"])
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 480, 640), (2, 480, 752), (4, 240, 320), (2, 376, 1241)])
+def test_extract_few_frames_one_round_nms_tiles(ctx, oracle, B, H, W):
+    """Two to four frames per call (a pair, a stereo frame): the fused NMS picks its tile height (32 / 40 / 48 rows) so that all frames fit one
+    round of workgroups, the selection is the rank-all form.  Every frame bit-exact against the oracle."""
+    frames, _ = synth.make_frames(B, H, W, seed=B * H + W)
+    n, kxy, score, desc = ctx.extract(frames, kmax=1024)
+    w = Wt.make_superpoint(seed=7)
+    for i in range(B):
+        r = oracle.superpoint(w, frames[i], kmax=1024)
+        assert n[i] == r["n"]
+        assert np.array_equal(kxy[i], r["kxy"]) and np.array_equal(score[i], r["score"]) and np.array_equal(desc[i], r["desc"])
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_extract_vs_golden(ctx, golden_dir, tag):
     g = np.load(f"{golden_dir}/sp_{tag}.npz")
