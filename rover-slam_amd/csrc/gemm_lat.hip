@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64 * WGN * WGM, 1) void gemm_lat_kernel(GemmArgs g,
         const int st = t % LSTAGES;
         // stage t has landed (this wave's copies: counted wait -- the stages t + 1 .. still in flight are younger; everybody's: barrier),
         // and every wave has left stage t - 1, whose buffer the next request reuses
-#if defined(RFE_EXP) && (RFE_EXP & 2)
+#if defined(RFE_EXP) && (RFE_EXP & 2)   // compile-time ablations of the floor measurement (tools/kbench/build_exp.sh, wrong results): 2 = no waits / barriers after the first stage
         if (t == 0)
 #endif
         {
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(64 * WGN * WGM, 1) void gemm_lat_kernel(GemmArgs g,
 #pragma unroll
             for (int j = 0; j < WJ; ++j) b[j] = *reinterpret_cast<const f32x4*>(as + j * 16 * LBK + sl);
         };
-#if defined(RFE_EXP) && (RFE_EXP & 1)
+#if defined(RFE_EXP) && (RFE_EXP & 1)   // 1 = no LDS fragment reads after the first (operands stay in registers): with 2, the pure-MFMA K loop (38.6 cycles per instruction)
         if (t == 0)
 #endif
         frags(0, a4, b4);
@@ -239,9 +239,9 @@ bool launch_gemm_lat(hipStream_t s, const GemmArgs& g, const float* rope_csn, in
 #ifdef RFE_TUNING
     const int abl = tune_int("RFE_GLAT_ABL", 0);         // 1 = only the first LSTAGES - 1 stages are copied (timing ablation, wrong results); 4 = record the timeline
     const int stages_env = tune_int("RFE_GLAT_STAGES", 0);
-    const int w8 = tune_int("RFE_GLAT_W8", 3);           // bit 0: qkv, bit 1: residual form with EIGHT waves per workgroup (two per SIMD)
+    const int w8 = tune_int("RFE_GLAT_W8", 3);           // bit 0: qkv, bit 1: residual form with EIGHT waves per workgroup (two per SIMD); 0 = four (A/B)
 #else
-    constexpr int abl = 0, stages_env = 0, w8 = 3;
+    constexpr int abl = 0, stages_env = 0;
 #endif
 #define RFE_GLAT_LAUNCH(WI_, WJ_, WGN_, WGM_, LS_, RES_, ROPE_)                                                                  \
     do {                                                                                                                         \
@@ -268,13 +268,17 @@ bool launch_gemm_lat(hipStream_t s, const GemmArgs& g, const float* rope_csn, in
     const long long panels = (long long)batch * ((g.M + 63) / 64);
     if (rope) {   // qkv
         if (g.N % 96 || res || (rope_cols % 64)) return false;
-        if (w8 & 1) RFE_GLAT_GO(3, 1, 2, 4, false, true);
-        RFE_GLAT_GO(3, 2, 2, 2, false, true);
+#ifdef RFE_TUNING
+        if (!(w8 & 1)) RFE_GLAT_GO(3, 2, 2, 2, false, true);
+#endif
+        RFE_GLAT_GO(3, 1, 2, 4, false, true);
     }
     if (res) {
         if (g.N % 32) return false;
-        if (w8 & 2) RFE_GLAT_GO(1, 1, 2, 4, true, false);
-        RFE_GLAT_GO(2, 1, 1, 4, true, false);
+#ifdef RFE_TUNING
+        if (!(w8 & 2)) RFE_GLAT_GO(2, 1, 1, 4, true, false);
+#endif
+        RFE_GLAT_GO(1, 1, 2, 4, true, false);
     }
     if (g.N % 96 == 0 && panels * (g.N / 96) >= 224) RFE_GLAT_GO(3, 2, 2, 2, false, false);
     if (g.N % 64 == 0 && panels * (g.N / 64) >= 224) RFE_GLAT_GO(2, 2, 2, 2, false, false);
