@@ -5,10 +5,12 @@
 // unnormalised partial sums a second kernel merged: four waves shared every K/V tile through a single-buffered LDS tile (two barriers
 // per 64 keys, register staging), every lane wrote 32 scalar partials, 8 MB of partials crossed HBM twice and the merge was a launch of
 // its own -- 28-32 + 5 us against 13.7 us of matrix time.  Here the key split happens INSIDE the workgroup:
-//   * workgroup = (sequence, head, 32-query block): 2 x 4 x 32 = 256 workgroups for a pair, four waves, one per SIMD;
-//   * wave w owns the w-th QUARTER of the keys and the same 32 queries: nothing is shared in the main loop, so it has NO barrier at all --
-//     every wave streams its own 32-key K / V tiles by global_load_lds_dwordx4 into private double-buffered LDS tiles (32 KB per wave),
-//     requests tile t + 1 before it starts on tile t and waits with a counted s_waitcnt for its own copies only;
+//   * workgroup = (sequence, head, 32-query block): 2 x 4 x 32 = 256 workgroups for a pair, NW = 4 waves, one per SIMD (NW = 8, two per
+//     SIMD with an eighth of the keys each, exists in the tuning build: 14 % SLOWER -- two waves' dependent S^T chains interleave on the
+//     matrix pipe and lose the accumulator forwarding exactly like a foreign instruction inside one chain, profiles/r04_ab_notes.md);
+//   * wave w owns the w-th NW-th of the keys and the same 32 queries: nothing is shared in the main loop, so it has NO barrier at all --
+//     every wave streams its own 32-key K / V tiles by global_load_lds_dwordx4 into a private LDS tile pair (16 KB per wave); a tile is
+//     read into registers in one go (8 K fragments, 32 V values), so the SAME buffer takes the copy of tile t + 1 while tile t is computed;
 //   * arithmetic per tile exactly as lg_attention_dma_kernel (S^T = K Q^T with the K image XOR-swizzled on the source address: one
 //     conflict-free ds_read_b128 per four k-steps; base-2 online softmax with deferred rescale; the S^T accumulators ARE the B operand of
 //     O^T += V^T P^T);
@@ -25,7 +27,7 @@ typedef const __attribute__((address_space(1))) void* alat_gptr_t;
 
 constexpr int AL_K = 32;                         // keys per tile
 constexpr int AL_TILE_F = AL_K * 64;             // floats of one K (or V) tile
-constexpr int AL_WAVE_F = 4 * AL_TILE_F;         // per wave: K ring of 2 tiles | V ring of 2 tiles
+constexpr int AL_WAVE_F = 2 * AL_TILE_F;         // per wave: one K tile | one V tile
 constexpr float AL_DEFER = 16.0f;                // log2 units (lg_kernels.hip: AT_DEFER)
 
 #ifdef RFE_TUNING
@@ -35,10 +37,12 @@ __device__ unsigned long long rfe_dbg_ts_att[2048 * 8];   // in-kernel timeline 
 #define RFE_ATS(slot) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(256, 1) void lg_attention_lat_kernel(
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 1) void lg_attention_lat_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld, float* __restrict__ out,
     int Lq, int Lk, int nqb, const int* __restrict__ qlen, const int* __restrict__ klen, const int* __restrict__ kv_map, int nseq_total, int abl) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // 4 waves x AL_WAVE_F floats = 128 KB
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // NW waves x AL_WAVE_F floats (16 KB each); the merge needs NW x 32 x 68 floats
+    constexpr int NT_ = 64 * NW;
     // all query blocks of one (sequence, head) on one XCD: its K / V (512 KB) is fetched into one L2
     const int Lb = blockIdx.x, xcd = Lb & 7, t_ = Lb >> 3;
     const int qb = t_ % nqb, unit = (t_ / nqb) * 8 + xcd;
@@ -52,7 +56,7 @@ __global__ __launch_bounds__(256, 1) void lg_attention_lat_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     if (qb * 32 >= nq || nk <= 0) {   // whole block is padding (or nothing to attend to): the padded context rows stay defined (zero)
-        for (int e = tid; e < 32 * 16; e += 256) {
+        for (int e = tid; e < 32 * 16; e += NT_) {
             const int row = qb * 32 + (e >> 4);
             if (row < Lq) *reinterpret_cast<f32x4*>(out + ((size_t)seq * Lq + row) * 256 + head * 64 + (e & 15) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -72,16 +76,16 @@ __global__ __launch_bounds__(256, 1) void lg_attention_lat_kernel(
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // from here on the vector-memory counter only sees this wave's tile copies
 
-    // this wave's key range: the w-th quarter, whole 32-key tiles
-    const int per = ((nk + 3) / 4 + AL_K - 1) / AL_K * AL_K;
+    // this wave's key range: the w-th NW-th, whole 32-key tiles
+    const int per = ((nk + NW - 1) / NW + AL_K - 1) / AL_K * AL_K;
     const int kbeg = wave * per;
     const int kend = kbeg + per < nk ? kbeg + per : nk;
     const int ntile = kend > kbeg ? (kend - kbeg + AL_K - 1) / AL_K : 0;
     const float* kbase = k + (size_t)kvseq * Lk * ld + head * 64;
     const float* vbase = v + (size_t)kvseq * Lk * ld + head * 64;
-    float* const wl = lds + wave * AL_WAVE_F;          // K ring [2][32 x 64] | V ring [2][32 x 64]
+    float* const wl = lds + wave * AL_WAVE_F;          // K tile [32 x 64] | V tile [32 x 64]
     float* const Kr = wl;
-    float* const Vr = wl + 2 * AL_TILE_F;
+    float* const Vr = wl + AL_TILE_F;
     // copy geometry: one wave instruction moves 64 granules of 16 B = 4 rows of a tile, 8 instructions per K (or V) tile.  Granule
     // (row, slot') of the K image holds global chunk slot' ^ (row & 15).  Per-lane 32-bit offsets from a wave-uniform tile base, so
     // that a copy is one instruction with a scalar base (the 64-bit per-lane address arithmetic used to cost as much as the softmax)
@@ -93,33 +97,33 @@ __global__ __launch_bounds__(256, 1) void lg_attention_lat_kernel(
         koff[u] = row * ld + ((cslot ^ (row & 15)) << 2);
         voff[u] = row * ld + (cslot << 2);
     }
-    auto issue_k = [&](int t, int buf) {
+    auto issue_k = [&](int t) {
         const int k0 = kbeg + t * AL_K;
         const float* base = kbase + (size_t)k0 * ld;
         if (k0 + AL_K <= nk) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) __builtin_amdgcn_global_load_lds((alat_gptr_t)(base + koff[u]), (alat_lds_ptr_t)(Kr + buf * AL_TILE_F + u * 256), 16, 0, 0);
+            for (int u = 0; u < 8; ++u) __builtin_amdgcn_global_load_lds((alat_gptr_t)(base + koff[u]), (alat_lds_ptr_t)(Kr + u * 256), 16, 0, 0);
         } else {   // the sequence's last, partial tile: keys past the end read the last valid row (finite) and are masked in S
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int row = u * 4 + crow;
                 const int rc = k0 + row < nk ? row : nk - 1 - k0;
-                __builtin_amdgcn_global_load_lds((alat_gptr_t)(base + rc * ld + ((cslot ^ (row & 15)) << 2)), (alat_lds_ptr_t)(Kr + buf * AL_TILE_F + u * 256), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((alat_gptr_t)(base + rc * ld + ((cslot ^ (row & 15)) << 2)), (alat_lds_ptr_t)(Kr + u * 256), 16, 0, 0);
             }
         }
     };
-    auto issue_v = [&](int t, int buf) {
+    auto issue_v = [&](int t) {
         const int k0 = kbeg + t * AL_K;
         const float* base = vbase + (size_t)k0 * ld;
         if (k0 + AL_K <= nk) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) __builtin_amdgcn_global_load_lds((alat_gptr_t)(base + voff[u]), (alat_lds_ptr_t)(Vr + buf * AL_TILE_F + u * 256), 16, 0, 0);
+            for (int u = 0; u < 8; ++u) __builtin_amdgcn_global_load_lds((alat_gptr_t)(base + voff[u]), (alat_lds_ptr_t)(Vr + u * 256), 16, 0, 0);
         } else {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int row = u * 4 + crow;
                 const int rc = k0 + row < nk ? row : nk - 1 - k0;
-                __builtin_amdgcn_global_load_lds((alat_gptr_t)(base + rc * ld + (cslot << 2)), (alat_lds_ptr_t)(Vr + buf * AL_TILE_F + u * 256), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((alat_gptr_t)(base + rc * ld + (cslot << 2)), (alat_lds_ptr_t)(Vr + u * 256), 16, 0, 0);
             }
         }
     };
@@ -131,36 +135,27 @@ __global__ __launch_bounds__(256, 1) void lg_attention_lat_kernel(
     const int jsw = j & 15;
 
     // Loop order per 32-key tile (measured alternatives in profiles/r04_ab_notes.md):
-    //   request tile t + 1 (16 copies, one scalar-base instruction each) -> wait for tile t's own copies (counted s_waitcnt) ->
-    //   the eight K fragments of S^T and the 32 V values of PV into registers -> 32 matrix instructions of S^T = K Q^T STRICTLY back to back -> softmax ->
-    //   32 matrix instructions of O^T += V^T P^T on two alternating accumulators.
+    //   wait for tile t's copies -> the eight K fragments of S^T and the 32 V values of PV into registers -> request tile t + 1 into the
+    //   SAME buffer (16 copies, one scalar-base instruction each; they land under this tile's 64 matrix instructions) ->
+    //   32 matrix instructions of S^T = K Q^T STRICTLY back to back -> softmax -> 32 matrix instructions of O^T += V^T P^T on two
+    //   alternating accumulators.
     // S^T is ONE dependent accumulator chain: any instruction between two of its matrix instructions breaks the accumulator forwarding
     // (+43 cycles per gap, guide "one EXTRA issue slot ... on the SAME accumulator"), so nothing is interleaved there -- a version that
     // pipelined QK(t + 1) against the exponentials of tile t was 8 % SLOWER for exactly that reason; with one wave per SIMD the matrix
-    // pipe itself sustains ~82 cycles per v_mfma_f32_32x32x2_f32 on random data (a pure-MFMA ablation of this loop), and this order sits
-    // within 13 % of that floor.
-    int buf = 0;
-    if (ntile > 0) { issue_k(0, 0); issue_v(0, 0); }
+    // pipe itself sustains ~82 cycles per v_mfma_f32_32x32x2_f32 on random data (a pure-MFMA ablation of this loop).
+    if (ntile > 0) { issue_k(0); issue_v(0); }
     RFE_ATS(1);
     for (int t = 0; t < ntile; ++t) {
         const bool more = t + 1 < ntile && !(abl & 1);   // abl (tuning build, wrong results): 1 = only the first tile is copied
-        if (more) {
-            issue_k(t + 1, buf ^ 1);
-            issue_v(t + 1, buf ^ 1);                                 // 16 copies younger than the tile consumed below
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        const float* const Kt = Kr + buf * AL_TILE_F;
-        const float* const Vt = Vr + buf * AL_TILE_F;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const float* const Kt = Kr;
+        const float* const Vt = Vr;
         f32x4 kf[8];
         {
             const float* ka = Kt + j * 64;
 #pragma unroll
             for (int g = 0; g < 8; ++g) kf[g] = *reinterpret_cast<const f32x4*>(ka + (((2 * g + h) ^ jsw) << 2));
         }
-        // ... and the 32 V values of this tile's PV: requested here, they land under the S^T chain (left to the scheduler, every pair of PV
-        // matrix instructions waited for an LDS read issued just in front of it)
         float vf[32];
         {
             const float* va = Vt + (4 * h) * 64 + j;
@@ -170,6 +165,10 @@ __global__ __launch_bounds__(256, 1) void lg_attention_lat_kernel(
                 vf[r] = va[kr * 64]; vf[16 + r] = va[kr * 64 + 32];
             }
         }
+        // the tile is in registers: its buffer is free for the next one (the reads must have RETURNED before a copy may overwrite them)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) { issue_k(t + 1); issue_v(t + 1); }
         __builtin_amdgcn_sched_barrier(0);
         // ---- S^T[key][query] = sum_d K[key][d] Q[query][d], started at -(running maximum) so that no subtraction is needed per element
         f32x16 st;
@@ -220,12 +219,11 @@ __global__ __launch_bounds__(256, 1) void lg_attention_lat_kernel(
             o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r], st[r], o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[16 + r], st[r], o1, 0, 0, 0);
         }
-        buf ^= 1;
     }
     l_run += __shfl_xor(l_run, 32);          // the two half-waves' partial sums
     RFE_ATS(2);
 
-    // ---- merge the four key ranges through LDS: out = sum_w o_w 2^(m_w - m) / sum_w l_w 2^(m_w - m), m = max_w m_w.
+    // ---- merge the NW key ranges through LDS: out = sum_w o_w 2^(m_w - m) / sum_w l_w 2^(m_w - m), m = max_w m_w.
     // Layout: part[w][query j][68]: 64 context values + (m, l), row stride 68 floats = 272 B (16-byte aligned, conflict-light)
     __syncthreads();                          // every wave is done with its tiles: the region is reused
     float* const part = lds;
@@ -239,29 +237,30 @@ __global__ __launch_bounds__(256, 1) void lg_attention_lat_kernel(
         if (h == 0) { pr[64] = m_run; pr[65] = l_run; }
     }
     __syncthreads();
-    // thread -> (query = tid / 8, 8 dims = two float4): 32 queries x 64 dims
+    // thread -> (query, DPT consecutive dims): 32 queries x 64 dims over 64 NW threads
     {
-        const int qj = tid >> 3, dq = (tid & 7) * 8;
+        constexpr int TPQ = NT_ / 32, DPT = 64 / TPQ;            // threads per query (8 / 16), dims per thread (8 / 4)
+        const int qj = tid / TPQ, dq = (tid % TPQ) * DPT;
         const int row = qb * 32 + qj;
-        float mw[4], lw[4], m = -INFINITY;
+        float mw[NW], lw[NW], m = -INFINITY;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { mw[w] = part[(w * 32 + qj) * 68 + 64]; lw[w] = part[(w * 32 + qj) * 68 + 65]; m = fmaxf(m, mw[w]); }
+        for (int w = 0; w < NW; ++w) { mw[w] = part[(w * 32 + qj) * 68 + 64]; lw[w] = part[(w * 32 + qj) * 68 + 65]; m = fmaxf(m, mw[w]); }
         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
         float l = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < NW; ++w) {
             if (!(lw[w] > 0.f)) continue;     // empty key range
             const float wgt = __builtin_amdgcn_exp2f(mw[w] - m);
             l += lw[w] * wgt;
             const float* pr = part + (w * 32 + qj) * 68 + dq;
             a0 += *reinterpret_cast<const f32x4*>(pr) * wgt;
-            a1 += *reinterpret_cast<const f32x4*>(pr + 4) * wgt;
+            if (DPT == 8) a1 += *reinterpret_cast<const f32x4*>(pr + 4) * wgt;
         }
         const float inv = (row < nq && l > 0.f) ? 1.0f / l : 0.f;    // padded rows -> 0
         if (row < Lq) {
             float* op = out + ((size_t)seq * Lq + row) * 256 + head * 64 + dq;
             *reinterpret_cast<f32x4*>(op) = a0 * inv;
-            *reinterpret_cast<f32x4*>(op + 4) = a1 * inv;
+            if (DPT == 8) *reinterpret_cast<f32x4*>(op + 4) = a1 * inv;
         }
     }
     RFE_ATS(3);
@@ -280,15 +279,24 @@ bool launch_lg_attention_lat(hipStream_t s, const float* q, const float* k, cons
     if ((size_t)nseq * Lq > 8192 || (ld % 4) || Lq < 1 || Lk < 1) return false;
     const int nqb = (Lq + 31) / 32;
     const int units8 = (4 * nseq + 7) / 8 * 8;    // (sequence, head) units padded to a multiple of 8: the block decode stays bijective
-    constexpr int bytes = 4 * AL_WAVE_F * 4;       // 128 KB
 #ifdef RFE_TUNING
     const int abl = tune_int("RFE_ALAT_ABL", 0);
+    static const int nw = tune_int("RFE_ALAT_WAVES", 4);   // 8 = two waves per SIMD (A/B: slower)
 #else
     constexpr int abl = 0;
 #endif
-    static bool ls_[64];
-    ensure_dynamic_lds((const void*)lg_attention_lat_kernel, bytes, ls_);
-    hipLaunchKernelGGL(lg_attention_lat_kernel, dim3(nqb * units8), dim3(256), bytes, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, nseq, abl);
+#define RFE_ALAT_GO(NW_)                                                                                                                  \
+    do {                                                                                                                                  \
+        constexpr int bytes = (NW_ * AL_WAVE_F > NW_ * 32 * 68 ? NW_ * AL_WAVE_F : NW_ * 32 * 68) * 4;   /* tiles, later the merge */        \
+        static bool ls_[64];                                                                                                              \
+        ensure_dynamic_lds((const void*)lg_attention_lat_kernel<NW_>, bytes, ls_);                                                        \
+        hipLaunchKernelGGL(lg_attention_lat_kernel<NW_>, dim3(nqb * units8), dim3(64 * NW_), bytes, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, nseq, abl); \
+    } while (0)
+#ifdef RFE_TUNING
+    if (nw == 8) { RFE_ALAT_GO(8); return true; }
+#endif
+    RFE_ALAT_GO(4);
+#undef RFE_ALAT_GO
     return true;
 }
 
