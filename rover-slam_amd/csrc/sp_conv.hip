@@ -336,26 +336,43 @@ __global__ __launch_bounds__(256, 4) void conv3x3_small_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// 16 x 16 x 4 variant for the latency regime (ONE frame -- the reference's own call pattern, batch 1:
-// src/Extractors/superpoint_onnx.cc:100): the 60 x 80 layers.  conv3x3_small_kernel gives every wave ONE 32 x 32 x 2
-// accumulator, i.e. one chain of Cin * 9 / 2 = 576 dependent 64-cycle matrix instructions (22 us before any staging), and its 32-pixel
-// M-blocks waste a sixth of an 80-column row.  Here a wave owns 16 pixels x 32 output channels as two v_mfma_f32_16x16x4_f32 accumulators
-// (32-cycle issue, two independent chains of Cin * 9 / 4), the workgroup 4 rows x 16 columns x 32 channels: 60 x 80 x 128 channels =
-// 1200 waves for 1024 SIMDs instead of 720, 80 = 5 x 16 columns exactly.  The product is formed transposed (matrix-A operand = weights,
-// B = pixels): a lane ends up with four consecutive output channels of one pixel (16-byte bias load and store).
-// Reduction order: k-step s covers kappa = 4 s .. 4 s + 3 (lane group q = kappa & 3), ascending inside the instruction and across
-// instructions, accumulator initialised with the bias -- the oracle's order, bit-exact like every other variant.
-// Staging: 16 input channels (two packed 8-channel weight chunks) per stage, double-buffered in LDS, the next stage's global loads issued
-// before this stage's matrix instructions (one workgroup per CU in this regime: nobody else hides the round trip), one barrier per stage.
+// 16 x 16 x 4 variant for the latency regime (one or two frames -- the reference's own call pattern, batch 1:
+// src/Extractors/superpoint_onnx.cc:100): the 60 x 80 layers (and the 120 x 160 layer without a pool at one frame).  conv3x3_small_kernel
+// gives every wave ONE 32 x 32 x 2 accumulator, i.e. one chain of Cin * 9 / 2 = 576 dependent 64-cycle matrix instructions (22 us before
+// any staging), and its 32-pixel M-blocks waste a sixth of an 80-column row.  Here a wave owns 16 pixels x 32 output channels as two
+// v_mfma_f32_16x16x4_f32 accumulators (32-cycle issue, two independent chains of Cin * 9 / 4), the workgroup 4 rows x 16 columns x 32
+// channels: 60 x 80 x 128 channels = 1200 waves for 1024 SIMDs instead of 720, 80 = 5 x 16 columns exactly.  The product is formed
+// transposed (matrix-A operand = weights, B = pixels): a lane ends up with four consecutive output channels of one pixel (16-byte bias load
+// and store).  Reduction order: k-step s covers kappa = 4 s .. 4 s + 3 (lane group q = kappa & 3), ascending inside the instruction and
+// across instructions, accumulator initialised with the bias -- the oracle's order, bit-exact like every other variant.
 constexpr int T16_H = 4, T16_W = 16, T16_IH = T16_H + 2, T16_IW = T16_W + 2, T16_PLANE = T16_IH * T16_IW, T16_NC = 32, T16_CK = 16;
 
-template <int CIN, bool RELU, bool POOL>
-__global__ __launch_bounds__(256, 2) void conv3x3_t16_kernel(
+// ------------------------------------------------------------------------------------------
+// Staging: BOTH operands are copied by global_load_lds_dwordx4 into three-stage LDS rings (two 16-channel stages in flight under the matrix
+// instructions of a third): no staging registers, no LDS stores, one counted s_waitcnt + one bare barrier per stage.  A first form staged
+// through registers (double-buffered, next stage's loads issued before this stage's matrix instructions): 36 - 38 us per 60 x 80 layer
+// against 11 us of chain time -- a stage's 72 matrix instructions are shorter than the load latency they were supposed to hide, and the
+// compiler drains the vector-memory counter wherever staged registers are live -- this form 25 us (profiles/r04_ab_notes.md).
+//   * weights: the packed rows [kappa][64 co] as they are; one instruction moves 8 rows x 128 B (this tile's half of the 64 channels);
+//   * input: the haloed 6 x 18 pixel tile stays PIXEL-major (a pixel's 16 channels of the stage = 64 B = 4 granules; one instruction moves
+//     16 pixels); granule g of pixel p is stored at g ^ ((p >> 2) & 3) -- swizzle on the source address -- so that the B-operand read of the
+//     16 x-consecutive pixels of a lane group (word p * 16 + ...) is conflict-free; pixels outside the image read a zero line;
+//   * every wave issues the same number of copies per stage (5 + 2; surplus slots re-copy a valid line into padding).
+typedef __attribute__((address_space(3))) void* conv_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* conv_gptr_t;
+constexpr int T16D_WROWS = 144, T16D_PIX = 128;    // ring-stage capacities: weight rows (18 copy slots of 8), pixels (108 used: 8 slots of 16); 3 x 26 KB = 78 KB
+__device__ __attribute__((aligned(64))) float t16d_zero_line[16];   // zero-initialised: the source of every out-of-image pixel
+
+template <int CIN, bool RELU>
+__global__ __launch_bounds__(256, 2) void conv3x3_t16d_kernel(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ out, int H, int W, int COUT, int gx, int gy, int ntiles) {
-    constexpr int KCH = T16_CK * 9, NST = CIN / T16_CK;                    // 144 kappa per stage
-    constexpr int IN_W = T16_CK * T16_PLANE, W_W = KCH * T16_NC, ST_W = IN_W + W_W;   // 1728 + 4608 words per stage buffer
-    __shared__ __attribute__((aligned(16))) float lds[2 * ST_W];
+    constexpr int NST = CIN / T16_CK;                                           // 16 channels = 144 kappa per stage
+    constexpr int IST_W = T16D_PIX * T16_CK, WST_W = T16D_WROWS * T16_NC;        // 2048 + 5120 words per stage
+    // dynamic LDS on purpose (a static array makes the compiler order every ds_read behind ALL outstanding copies): 3 x (8 + 20) KB
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const lin = lds;
+    float* const lwr = lds + 3 * IST_W;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = lane & 15, q = lane >> 4;
@@ -368,104 +385,75 @@ __global__ __launch_bounds__(256, 2) void conv3x3_t16_kernel(
     f32x4 acc[2];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) acc[nb] = *reinterpret_cast<const f32x4*>(bias + co0 + nb * 16 + 4 * q);
-    // pixel-operand offsets of the 9 k-steps of a 36-kappa period (four input channels): kappa = 4 s + q -> (channel, ky, kx)
-    int aoff[9];
+    // pixel-operand addressing of the 9 k-steps of a 36-kappa period (4 input channels = granule c4 of the stage): kappa = 4 s + q ->
+    // (channel e = kappa / 9 inside the granule, tap) -> haloed pixel p; word = p * 16 + ((c4 ^ swizzle(p)) << 2) + e
+    int pbase[9], pswz[9];
 #pragma unroll
     for (int s9 = 0; s9 < 9; ++s9) {
-        const int kap = 4 * s9 + q, ci = kap / 9, tap = kap % 9;
-        aoff[s9] = ci * T16_PLANE + (tap / 3) * T16_IW + tap % 3 + wave * T16_IW + px;
+        const int kap = 4 * s9 + q, e = kap / 9, tap = kap % 9;
+        const int p = (wave + tap / 3) * T16_IW + px + tap % 3;
+        pbase[s9] = p * T16_CK + e;
+        pswz[s9] = (p >> 2) & 3;
     }
     const float* in_b = in + (size_t)b * H * W * CIN;
-    // packed weights [Cout/64][Cin/8][72][64]: this workgroup's 32 channels are half (ct & 1) of 64-tile ct >> 1; a stage = two 8-channel chunks
     const float* wp_ct = wp + (size_t)(ct >> 1) * (CIN / 8) * 72 * NT + (ct & 1) * T16_NC;
 
-    // staging slots: input = 108 haloed pixels x 4 channel quads (432 float4: two per thread for tid < 216), weights = 144 x 8 float4 (1152:
-    // five per thread, the last partial)
-    int i_goff[2], i_loff[2];
+    // weight copies: lane -> row lane >> 3, 16-byte piece lane & 7; 18 slots of 8 rows; wave w issues slots w, w + 4, .. -- five each, so that the
+    // vector-memory counter advances alike in every wave: the fifth of waves 2, 3 repeats their fourth (same data to the same place)
+    int w_off[5], w_slot[5];
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int idx = tid + it * 256;
-        const int cq = idx & 3, pix = idx >> 2;
-        const int py = pix / T16_IW, pxx = pix % T16_IW;
-        const int gyy = y0 - 1 + py, gxx = x0 - 1 + pxx;
-        const bool slot = pix < T16_PLANE;
-        i_loff[it] = slot ? (cq * 4) * T16_PLANE + py * T16_IW + pxx : -1;
-        i_goff[it] = (slot && gyy >= 0 && gyy < H && gxx >= 0 && gxx < W) ? (gyy * W + gxx) * CIN + cq * 4 : -1;
+    for (int u = 0; u < 5; ++u) {
+        w_slot[u] = wave + 4 * u < 18 ? wave + 4 * u : wave + 4 * (u - 1);
+        w_off[u] = (w_slot[u] * 8 + (lane >> 3)) * NT + (lane & 7) * 4;
     }
-    float4 ri[2], rw[5];
-    auto fetch = [&](int st) {
+    // input copies: lane -> pixel slot * 16 + (lane >> 2), physical granule lane & 3; wave w issues slots w, w + 4 (pixels >= 108: padding)
+    const float* i_src[2];
+    bool i_img[2];
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            ri[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i_goff[it] >= 0) ri[it] = *reinterpret_cast<const float4*>(in_b + i_goff[it] + st * T16_CK);
-        }
-        const float* src = wp_ct + (size_t)st * 2 * 72 * NT;       // two consecutive packed chunks = 144 rows of 64
+    for (int u = 0; u < 2; ++u) {
+        const int p = (wave + 4 * u) * 16 + (lane >> 2);
+        const int py = p / T16_IW, pxx = p % T16_IW;
+        const int gyy = y0 - 1 + py, gxx = x0 - 1 + pxx;
+        const int g = (lane & 3) ^ ((p >> 2) & 3);                             // global granule this LDS slot holds
+        i_img[u] = p < T16_PLANE && gyy >= 0 && gyy < H && gxx >= 0 && gxx < W;
+        i_src[u] = i_img[u] ? in_b + ((size_t)gyy * W + gxx) * CIN + g * 4 : t16d_zero_line + g * 4;
+    }
+    auto issue = [&](int st) {
+        const float* src = wp_ct + (size_t)st * 2 * 72 * NT;
+        float* wdst = lwr + (st % 3) * WST_W;
+        float* idst = lin + (st % 3) * IST_W;
 #pragma unroll
-        for (int it = 0; it < 5; ++it) {
-            const int idx = tid + it * 256;
-            if (idx < KCH * (T16_NC / 4)) rw[it] = *reinterpret_cast<const float4*>(src + (idx >> 3) * NT + (idx & 7) * 4);
-        }
+        for (int u = 0; u < 5; ++u)
+            __builtin_amdgcn_global_load_lds((conv_gptr_t)(src + w_off[u]), (conv_lds_ptr_t)(wdst + w_slot[u] * 256), 16, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            __builtin_amdgcn_global_load_lds((conv_gptr_t)(i_src[u] + (i_img[u] ? st * T16_CK : 0)), (conv_lds_ptr_t)(idst + (wave + 4 * u) * 256), 16, 0, 0);
     };
-    auto stash = [&](int buf) {
-        float* li = lds + buf * ST_W;
-        float* lw = li + IN_W;
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            if (i_loff[it] < 0) continue;
-            float* d = li + i_loff[it];
-            d[0] = ri[it].x; d[T16_PLANE] = ri[it].y; d[2 * T16_PLANE] = ri[it].z; d[3 * T16_PLANE] = ri[it].w;
-        }
-#pragma unroll
-        for (int it = 0; it < 5; ++it) {
-            const int idx = tid + it * 256;
-            if (idx < KCH * (T16_NC / 4)) reinterpret_cast<float4*>(lw)[idx] = rw[it];
-        }
-    };
-    // channel quads 0..3 of a stage hold channels 4 cq .. 4 cq + 3: slot (cq, pixel) -> planes 4 cq .. 4 cq + 3 (i_loff above)
-    fetch(0);
-    stash(0);
-    __syncthreads();
+    issue(0);
+    if (NST > 1) issue(1);
     for (int st = 0; st < NST; ++st) {
-        const int buf = st & 1;
-        if (st + 1 < NST) fetch(st + 1);
-        const float* li = lds + buf * ST_W;
-        const float* lw = li + IN_W + px;
+        // stage st has landed (this wave's copies: the 7 of stage st + 1 may still be in flight; everybody's: barrier), and every wave has left
+        // stage st - 1, whose buffers the next request reuses
+        if (st + 1 < NST) asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (st + 2 < NST) issue(st + 2);
+        const float* li = lin + (st % 3) * IST_W;
+        const float* lw = lwr + (st % 3) * WST_W + px;
 #pragma unroll
         for (int c4 = 0; c4 < T16_CK / 4; ++c4) {          // 4 input channels = 36 kappa = 9 k-steps
-            const float* ap = li + c4 * 4 * T16_PLANE;
             const float* bp = lw + (c4 * 36 + q) * T16_NC;
 #pragma unroll
             for (int s9 = 0; s9 < 9; ++s9) {
-                const float pv = ap[aoff[s9]];
+                const float pv = li[pbase[s9] + ((c4 ^ pswz[s9]) << 2)];
                 const float w0 = bp[4 * s9 * T16_NC], w1 = bp[4 * s9 * T16_NC + 16];
                 acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, pv, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, pv, acc[1], 0, 0, 0);
             }
         }
-        if (st + 1 < NST) stash(buf ^ 1);
-        __syncthreads();
     }
-    // D layout: lane (px, q) holds channels co0 + 16 nb + 4 q .. + 3 of pixel (y0 + wave, x0 + px)
     if (RELU) {
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) { acc[nb][0] = fmaxf(acc[nb][0], 0.f); acc[nb][1] = fmaxf(acc[nb][1], 0.f); acc[nb][2] = fmaxf(acc[nb][2], 0.f); acc[nb][3] = fmaxf(acc[nb][3], 0.f); }
-    }
-    if (POOL) {   // the 2 x 2 windows span two waves: exchange the tile through LDS ([row][column][channel], the stage buffers are free)
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) *reinterpret_cast<f32x4*>(lds + ((wave * T16_W + px) * T16_NC + nb * 16 + 4 * q)) = acc[nb];
-        __syncthreads();
-        const int Ho = H >> 1, Wo = W >> 1;
-        float* out_b = out + (size_t)b * Ho * Wo * COUT;
-        const int chn = tid & 31;
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int pp = (tid >> 5) + 8 * it, pr = pp >> 3, pc = pp & 7;
-            const int yo = (y0 >> 1) + pr, xo = (x0 >> 1) + pc;
-            if (yo >= Ho || xo >= Wo) continue;
-            const float* e = lds + ((2 * pr) * T16_W + 2 * pc) * T16_NC + chn;
-            out_b[((size_t)yo * Wo + xo) * COUT + co0 + chn] = fmaxf(fmaxf(e[0], e[T16_NC]), fmaxf(e[T16_W * T16_NC], e[T16_W * T16_NC + T16_NC]));
-        }
-        return;
     }
     const int y = y0 + wave, x = x0 + px;
     if (y < H && x < W) {
@@ -702,18 +690,24 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
     const bool ck8 = conv_ck() == 8;
     // latency regime: too few 8 x 32 x 64 tiles to occupy the chip -> 4 x 32 x 32 tiles (4x the workgroups)
     static const int small_thr = tune_int("RFE_CONV_SMALL", 512);   // 0 disables
-    // ... and, among those, the 1/8-resolution layers of ONE frame (conv4a / conv4b / convPa / convDa at batch 1: 60 x 80, 60 x 94): 16 x 16 x 4
-    // tiles.  Measured at 640 x 480 (profiles/r04_ab_notes.md): conv4a / 4b 45 -> 38 us, convPa / Da 54 -> 49 us; at two frames and on the
-    // 120 x 160 layers the 32-channel tiles re-read the weights too often (conv3b 74 -> 83 us, at two frames 110 -> 157 us) and stay with
-    // conv3x3_small_kernel.
-    static const int t16_px = tune_int("RFE_CONV_T16", 6000);   // pixel budget of the 16x16x4 variant; 0 disables (tuning build)
-    if (ck8 && relu && (long long)gx * gy * B * (cout / NT) < small_thr && (cin == 64 || cin == 128) && (long long)B * H * W <= t16_px && cout % T16_NC == 0) {
+    // ... and, among those, the layers WITHOUT a pool of up to 12 000 pixels (Cin = 128: conv4a / conv4b / convPa / convDa of one or two frames, 60 x 80 or
+    // 60 x 94 each) or 20 000 pixels (Cin = 64: conv3a of one frame): 16 x 16 x 4 tiles with LDS-DMA rings.  Measured at 640 x 480, event-timed stages
+    // (profiles/r04_ab_notes.md): one frame conv4a / 4b 39 -> 29 us, convPa / Da 49 -> 45, conv3a 41 -> 36; two frames conv4a / 4b 54 -> 45, convPa / Da
+    // 74 -> 68; beyond those budgets the 32-channel tiles re-read the weights too often (conv3a at two frames 60 -> 66 us) and conv3x3_small_kernel stays.
+    static const int t16_px = tune_int("RFE_CONV_T16", 12000), t16_px64 = tune_int("RFE_CONV_T16_64", 20000);   // pixel budgets; 0 disables (tuning build)
+    if (ck8 && relu && !pool && (long long)gx * gy * B * (cout / NT) < small_thr && (cin == 64 || cin == 128) &&
+        (long long)B * H * W <= (cin == 64 ? t16_px64 : t16_px) && cout % T16_NC == 0) {
         const int sx = (W + T16_W - 1) / T16_W, sy = (H + T16_H - 1) / T16_H;
         const dim3 gs(conv_grid(sx, sy, B, cout / T16_NC));
-        if (cin == 128 && pool) hipLaunchKernelGGL((conv3x3_t16_kernel<128, true, true>), gs, dim3(256), 0, s, in, wp, bias, out, H, W, cout, sx, sy, sx * sy * B);
-        else if (cin == 128) hipLaunchKernelGGL((conv3x3_t16_kernel<128, true, false>), gs, dim3(256), 0, s, in, wp, bias, out, H, W, cout, sx, sy, sx * sy * B);
-        else if (pool) hipLaunchKernelGGL((conv3x3_t16_kernel<64, true, true>), gs, dim3(256), 0, s, in, wp, bias, out, H, W, cout, sx, sy, sx * sy * B);
-        else hipLaunchKernelGGL((conv3x3_t16_kernel<64, true, false>), gs, dim3(256), 0, s, in, wp, bias, out, H, W, cout, sx, sy, sx * sy * B);
+        constexpr int bytes = 3 * (T16D_PIX * T16_CK + T16D_WROWS * T16_NC) * 4;   // 78 KB: two workgroups per CU
+        static bool ls_[2][64];
+        if (cin == 128) {
+            ensure_dynamic_lds((const void*)conv3x3_t16d_kernel<128, true>, bytes, ls_[0]);
+            hipLaunchKernelGGL((conv3x3_t16d_kernel<128, true>), gs, dim3(256), bytes, s, in, wp, bias, out, H, W, cout, sx, sy, sx * sy * B);
+        } else {
+            ensure_dynamic_lds((const void*)conv3x3_t16d_kernel<64, true>, bytes, ls_[1]);
+            hipLaunchKernelGGL((conv3x3_t16d_kernel<64, true>), gs, dim3(256), bytes, s, in, wp, bias, out, H, W, cout, sx, sy, sx * sy * B);
+        }
         return;
     }
     if (ck8 && (!pool || relu) && (long long)gx * gy * B * (cout / NT) < small_thr && (cin == 64 || cin == 128)) {

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised shape sweep of the C ABI against the oracle (GPU box; test infrastructure, not product code).
-SuperPoint: random H, W (multiples of 8), batch, Kmax -> every output bit-exact.  LightGlue: random pair counts and
+SuperPoint: random H, W (any size >= 48), batch, Kmax, u8 or float entry -> every output bit-exact.  LightGlue: random pair counts and
 ragged (m, n) incl. tiny sets -> match lists identical, scores within 1e-4 (small sets).  Stream mode: random B, K.
 usage: python tools/fuzz_parity.py [seconds=60] [seed=0]"""
 import os
@@ -37,10 +37,16 @@ def main(seconds=60.0, seed=0):
             c.set_weights(capi.KIND_SUPERPOINT, w)
             frames, _ = synth.make_frames(B, H, W, seed=int(rng.integers(1 << 30)))
             pad = int(rng.choice([0, 0, 3, 8, 40]))
-            n, kxy, score, desc = c.extract(frames, kmax=K, pad_cols=pad)
+            src = frames
+            if rng.random() < 0.3:        # the float entry (Extractor_Inference on CV_32F): values off the 1/255 lattice and outside [0, 1]
+                pad = -1
+                src = (frames.astype(np.float32) * np.float32(rng.uniform(0.002, 0.008)) + np.float32(rng.uniform(-0.3, 0.3))).astype(np.float32)
+                n, kxy, score, desc = c.extract_f32(src, kmax=K)
+            else:
+                n, kxy, score, desc = c.extract(frames, kmax=K, pad_cols=pad)
             ok = True
             for i in range(B):
-                r = O.superpoint(w, frames[i], kmax=K)
+                r = O.superpoint(w, src[i], kmax=K)
                 ok &= bool(n[i] == r["n"] and np.array_equal(kxy[i], r["kxy"]) and np.array_equal(score[i], r["score"]) and np.array_equal(desc[i], r["desc"]))
             tag = f"sp H={H} W={W} B={B} K={K} pad={pad}"
         elif kind == 1:                                           # ---- LightGlue, ragged batch
