@@ -1139,9 +1139,16 @@ extern "C" int rfe_stereo_frame_dev(rfe_ctx* c, const uint8_t* imgL, const uint8
     RFE_HIP(c, hipMemcpy2DAsync(d_img + (size_t)H * W, (size_t)W, imgR, (size_t)stride, (size_t)W, (size_t)H, hipMemcpyDeviceToDevice, s));
     if ((rc = sp_forward(c, d_img, H, W, W, 2, Kmax, thr, n, kxy, score, desc))) return rc;
     // Frame::ComputeStereoMatches (src/Frame.cc:1159-1446) on the device-resident features; counts stay on the device
-    { ProfScope ps(c, "stereo_match");
-      launch_stereo_match_counts(s, d_img, d_img + (size_t)H * W, H, W, W, kxy, kxy + (size_t)Kmax * 2, Kmax, n, desc,
+    // ... on the SIDE stream: the stereo kernels (45 us of small launches) and the temporal LightGlue match below only share their inputs, and
+    // the one-pair LightGlue is a chain of latency-bound kernels that leaves room next to it (with an event pair around every stage, full
+    // profiling pass, everything stays serial so that the stage times are clean)
+    const bool st_fork = c->st_have_prev && !(c->prof && c->prof_filter.empty()) && tune_env("RFE_ST_NO_FORK") == nullptr;
+    hipStream_t ss = st_fork ? c->side_stream : s;
+    if (st_fork) { RFE_HIP(c, hipEventRecord(c->ev_fork, s)); RFE_HIP(c, hipStreamWaitEvent(ss, c->ev_fork, 0)); }
+    { ProfScope ps(c, "stereo_match", ss);
+      launch_stereo_match_counts(ss, d_img, d_img + (size_t)H * W, H, W, W, kxy, kxy + (size_t)Kmax * 2, Kmax, n, desc,
                                  desc + (size_t)Kmax * 256, mb, mbf, uRight, depth, sadv); }
+    if (st_fork) RFE_HIP(c, hipEventRecord(c->ev_join, ss));
     // temporal match exactly as Tracking issues it: SearchBySP(mCurrentFrame, mLastFrame) (src/Tracking.cc:3465) ->
     // MatchingPoints_onnx(CurrentFrame, LastFrame, vnMatches1) (src/Matchers/SPmatcher.cc:1050-1054): THIS left view is set 0,
     // the previous left view set 1, so pairs are (current index, previous index) like vnMatches1[IdxCF] = IdxLF; true image
@@ -1160,6 +1167,7 @@ extern "C" int rfe_stereo_frame_dev(rfe_ctx* c, const uint8_t* imgL, const uint8
     }
     { ProfScope ps(c, "lg_misc");   // this left view becomes the previous one
       hipLaunchKernelGGL(st_save_kernel, dim3((Kmax + 3) / 4), dim3(256), 0, s, kn_cur, desc, n, Kmax, kn_prev, desc_prev, n_prev); }
+    if (st_fork) RFE_HIP(c, hipStreamWaitEvent(s, c->ev_join, 0));   // uRight / depth are complete when the ctx stream is
     c->st_have_prev = true;
     RFE_HIP(c, hipGetLastError());
     return RFE_OK;
