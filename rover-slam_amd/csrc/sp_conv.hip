@@ -689,7 +689,7 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
     const int gx = (W + TW - 1) / TW, gy = (H + TH - 1) / TH;
     const bool ck8 = conv_ck() == 8;
     // latency regime: too few 8 x 32 x 64 tiles to occupy the chip -> 4 x 32 x 32 tiles (4x the workgroups)
-    static const int small_thr = tune_int("RFE_CONV_SMALL", 512);   // 0 disables
+    static const int small_thr = tune_int("RFE_CONV_SMALL", 700);   // 0 disables; 700: conv2a / conv2b of two VGA frames (600 tiles) take the small tile (117 -> 111 us each), two 752 x 480 frames (720 tiles) do not (measured slower: 2.613 against 2.595 ms per stereo frame)
     // ... and, among those, the layers WITHOUT a pool of up to 12 000 pixels (Cin = 128: conv4a / conv4b / convPa / convDa of one or two frames, 60 x 80 or
     // 60 x 94 each) or 20 000 pixels (Cin = 64: conv3a of one frame): 16 x 16 x 4 tiles with LDS-DMA rings.  Measured at 640 x 480, event-timed stages
     // (profiles/r04_ab_notes.md): one frame conv4a / 4b 39 -> 29 us, convPa / Da 49 -> 45, conv3a 41 -> 36; two frames conv4a / 4b 54 -> 45, convPa / Da
