@@ -258,6 +258,18 @@ class Pool:
     def set_option(self, option, value):
         self._chk(lib.rfe_pool_set_option(self.h, option, int(value)))
 
+    def set_hparams(self, **kw):
+        """Change some graph hyper-parameters (keys of rfe_hparams) on EVERY member; the others keep member 0's current values."""
+        h = HParams()
+        rc = lib.rfe_get_hparams(lib.rfe_pool_ctx(self.h, 0), C.byref(h))
+        if rc < 0:
+            raise RfeError(f"rfe_get_hparams on pool member 0 failed ({rc})")
+        for k, v in kw.items():
+            if not hasattr(h, k):
+                raise KeyError(k)
+            setattr(h, k, v)
+        self._chk(lib.rfe_pool_set_hparams(self.h, C.byref(h)))
+
     def extract_match_stream(self, frames_u8, kmax=1024, thr=0.0005, filter_thr=0.1, transport=POOL_AUTO, with_desc=True):
         """frames_u8: host [F,H,W] uint8.  Returns dict n [F], kxy [F,K,2], score / desc (with_desc), S [F-1], pairs [F-1,K,2], ms [F-1,K]."""
         img = np.ascontiguousarray(frames_u8, np.uint8)

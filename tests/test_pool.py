@@ -188,6 +188,36 @@ def test_pool_three_members_on_one_device_copy_transport(wsets, oracle):
 
 
 @pytest.mark.gpu
+def test_pool_applies_hyper_parameters_to_every_member(wsets, oracle):
+    """rfe_pool_set_hparams (a graph exported with another NMS radius / border / top-k rule, include/rover_fe.h rfe_hparams): every member must
+    extract with the new values -- checked against the oracle on a frame of each member's shard -- and an invalid block must be refused."""
+    from rover_slam_amd import capi
+    F, kmax = 7, 300
+    frames, _ = synth.make_frames(F, 160, 208, seed=21)
+    pool = capi.Pool([0, 0, 0])
+    try:
+        pool.set_weights(capi.KIND_SUPERPOINT, wsets[0]); pool.set_weights(capi.KIND_LIGHTGLUE, wsets[1])
+        base = pool.extract_match_stream(frames, kmax=kmax)
+        pool.set_hparams(sp_nms_radius=3, sp_remove_borders=2, sp_topk_always=1)
+        for r in range(3):
+            h = capi.HParams()
+            assert capi.lib.rfe_get_hparams(capi.lib.rfe_pool_ctx(pool.h, r), h) == 0
+            assert (h.sp_nms_radius, h.sp_remove_borders, h.sp_topk_always) == (3, 2, 1)
+        got = pool.extract_match_stream(frames, kmax=kmax)
+        with pytest.raises(capi.RfeError):
+            pool.set_hparams(sp_nms_radius=9)
+    finally:
+        pool.close()
+    assert not np.array_equal(base["kxy"], got["kxy"])
+    for r in range(3):
+        first, nfr, own = capi.pool_shard(F, 3, r)
+        i = first + (nfr - 1 if r == 2 else own - 1)          # a frame this member owns
+        ref = oracle.superpoint(wsets[0], frames[i], kmax=kmax, nms_radius=3, border=2, topk_always=True)
+        assert got["n"][i] == ref["n"] > 20
+        assert np.array_equal(got["kxy"][i], ref["kxy"]) and np.array_equal(got["score"][i], ref["score"]) and np.array_equal(got["desc"][i], ref["desc"])
+
+
+@pytest.mark.gpu
 @pytest.mark.skipif(shutil.which("gcc") is None, reason="no gcc")
 def test_plain_c_host_runs_the_pool(tmp_path, wsets):
     """tests/cpp/pool_driver.c (C99, no Python in the process): two members on the box's one device, weights from RFEW files, results
