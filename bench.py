@@ -964,7 +964,20 @@ def main():
             latency["dropin"] = latency_dropin(synth, wsp, wlg, frames_np, steps=args.latency_steps, check=not args.no_cpu_baseline)
         except Exception as e:
             latency["dropin"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-        for k in ("resident", "dropin"):
+        # the same device-resident calls with RFE_OPT_LG_FP16X2 on (default off, never the headline): at one pair the Linears take the split form of
+        # the latency tiles (gemm_lat.hip, H2), the attention stays fp32.  SuperPoint (c2) is unaffected by the option and not repeated.
+        try:
+            ctx.set_option(capi.OPT_LG_FP16X2, 1)
+            r2 = latency_resident(ctx, capi, synth, sharding, torch, dev, frames, steps=args.latency_steps)
+            latency["resident_fp16x2"] = {"c3": r2["c3"], "c5": r2["c5"],
+                                          "note": "RFE_OPT_LG_FP16X2 = 1: LightGlue's Linears as fp16 hi + lo split products (three f16 matrix instructions per fp32 "
+                                                  "product, fp32 accumulation); match lists / scores of this configuration are oracle-checked by "
+                                                  "tests/test_gpu_throughput_parity.py::test_lightglue_one_pair_fp16x2_vs_oracle"}
+        except Exception as e:
+            latency["resident_fp16x2"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            ctx.set_option(capi.OPT_LG_FP16X2, 0)
+        for k in ("resident", "dropin", "resident_fp16x2"):
             if "error" in latency[k]:
                 print(f"bench.py: latency.{k} failed: {latency[k]['error']}", file=sys.stderr)
         step(); fence()      # the resident results are those of the bench batch again (cpu_baseline checks them)

@@ -29,9 +29,12 @@
 //   the K loop runs at 43.
 // Roofline: fp32 MFMA peak 157.3 TFLOP/s, algorithmic 2 M N K FLOP.
 #include "rfe_internal.h"
+#include "h2_split.h"
 
 namespace rfe {
 
+typedef _Float16 glat_f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t glat_u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* glat_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glat_gptr_t;
 
@@ -48,7 +51,12 @@ __device__ unsigned long long rfe_dbg_ts[2048 * 8];
 
 // WI x WJ: 16-column (n) x 16-row (m) blocks per wave; WGN x WGM: waves per workgroup along n and m (WGN * WGM == 4).
 // LSTAGES: depth of the LDS ring (LSTAGES - 1 stages in flight under the matrix instructions of one).
-template <int WI, int WJ, int WGN, int WGM, int LSTAGES, bool RES, bool ROPE>
+// H2 (RFE_OPT_LG_FP16X2, default off): the same tile, ring, block decode and epilogue with every product as a SPLIT product on the f16 matrix
+// pipe (h2_split.h: x = hi + lo in fp16, lo hi + hi lo + hi hi with fp32 accumulation): a weight row of a stage is [64 hi | 64 lo] fp16 =
+// 256 B copied from the load-time planes (GemmArgs::Bh / Bl) -- the same bytes, granules and swizzle as an fp32 row -- the activation rows
+// stay fp32 and are split as they are read from LDS; one v_mfma_f32_16x16x32_f16 consumes 32 k (lane group q holds k = 8 q .. 8 q + 7 of
+// both operands), three of them replace eight v_mfma_f32_16x16x4_f32.
+template <int WI, int WJ, int WGN, int WGM, int LSTAGES, bool RES, bool ROPE, bool H2 = false>
 __global__ __launch_bounds__(64 * WGN * WGM, 1) void gemm_lat_kernel(GemmArgs g, const float* __restrict__ rope_csn, int rope_cols, int MT, int abl) {
     constexpr int NW = WGN * WGM;                         // waves per workgroup: 4 (one per SIMD) or 8 (two per SIMD)
     static_assert(NW == 4 || NW == 8, "four or eight waves per workgroup");
@@ -60,6 +68,7 @@ __global__ __launch_bounds__(64 * WGN * WGM, 1) void gemm_lat_kernel(GemmArgs g,
 
     const int tid = threadIdx.x, lane = tid & 63;
     RFE_TS(0);
+    if (H2) h2_saturate_mode();                           // an activation past fp16's range saturates instead of turning its row into NaN (h2_split.h)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
     // all column tiles of one activation panel on one XCD (blocks are dealt round-robin over the 8 XCDs)
@@ -84,8 +93,16 @@ __global__ __launch_bounds__(64 * WGN * WGM, 1) void gemm_lat_kernel(GemmArgs g,
     for (int u = 0; u < NDMA; ++u) {
         const int R = (wave + NW * u) * 4 + (lane >> 4);
         const int sl = ((lane & 15) ^ (R & 15)) << 2;
-        if (R < BN) { src[u] = g.B + (size_t)(n0 + R) * g.ldb + sl; src2[u] = src[u]; }
-        else {
+        if (R < BN) {
+            if (H2) {   // granules 0..7 of a row: 8 fp16 each of the hi plane, 8..15: of the lo plane; kept as a float pointer advancing k0 / 2 floats per k0
+                const int gi = (lane & 15) ^ (R & 15);
+                const uint16_t* pl = (gi < 8 ? g.Bh : g.Bl) + (size_t)(n0 + R) * g.ldb + (gi & 7) * 8;
+                src[u] = reinterpret_cast<const float*>(pl);
+            } else {
+                src[u] = g.B + (size_t)(n0 + R) * g.ldb + sl;
+            }
+            src2[u] = src[u];
+        } else {
             int m = m0 + R - BN; m = m < M ? m : M - 1;      // rows past the edge are clamped (computed, never stored)
             src[u] = g.A + (size_t)m * g.lda + sl;
             src2[u] = g.A2 ? g.A2 + (size_t)m * g.lda2 + sl - g.K1 : src[u];
@@ -96,7 +113,8 @@ __global__ __launch_bounds__(64 * WGN * WGM, 1) void gemm_lat_kernel(GemmArgs g,
         const bool second = g.A2 && k0 >= g.K1;
 #pragma unroll
         for (int u = 0; u < NDMA; ++u) {
-            const float* p = (second ? src2[u] : src[u]) + k0;
+            const bool wrow = H2 && (wave + NW * u) * 4 < BN;          // a weight-row group of the split form: fp16 planes, k0 halves
+            const float* p = (second ? src2[u] : src[u]) + (wrow ? k0 / 2 : k0);
             __builtin_amdgcn_global_load_lds((glat_gptr_t)p, (glat_lds_ptr_t)(lds + st * STAGE_F + (wave + NW * u) * 4 * LBK), 16, 0, 0);
         }
     };
@@ -137,6 +155,37 @@ __global__ __launch_bounds__(64 * WGN * WGM, 1) void gemm_lat_kernel(GemmArgs g,
         if (t + LSTAGES - 1 < T && !(abl & 1)) issue(t + LSTAGES - 1, (t + LSTAGES - 1) % LSTAGES);
         const float* const ws = wfrag + st * STAGE_F;
         const float* const as = afrag + st * STAGE_F;
+        if constexpr (H2) {
+            // two 32-k groups per stage.  Weights: granule 4 g + q (hi) / 8 + 4 g + q (lo) of row n = the lane's 8 k; activations: the fp32
+            // granules 8 g + 2 q, + 1 of row m, split in registers.  (Requesting group 1's raw fragments ahead of group 0's products changes
+            // nothing: at 16 cycles per matrix instruction these kernels wait for the copies -- 8 MB per stage over the chip at ~10 TB/s.)
+#pragma unroll
+            for (int g32 = 0; g32 < LBK / 32; ++g32) {
+                glat_f16x8 wh[WI], wl[WI], ah[WJ], al[WJ];
+#pragma unroll
+                for (int i = 0; i < WI; ++i) {
+                    wh[i] = *reinterpret_cast<const glat_f16x8*>(ws + i * 16 * LBK + (((4 * g32 + q) ^ r) << 2));
+                    wl[i] = *reinterpret_cast<const glat_f16x8*>(ws + i * 16 * LBK + (((8 + 4 * g32 + q) ^ r) << 2));
+                }
+#pragma unroll
+                for (int j = 0; j < WJ; ++j) {
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(as + j * 16 * LBK + (((8 * g32 + 2 * q) ^ r) << 2));
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(as + j * 16 * LBK + (((8 * g32 + 2 * q + 1) ^ r) << 2));
+                    uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+                    h2_split2(x0[0], x0[1], h0, l0); h2_split2(x0[2], x0[3], h1, l1);
+                    h2_split2(x1[0], x1[1], h2, l2); h2_split2(x1[2], x1[3], h3, l3);
+                    ah[j] = __builtin_bit_cast(glat_f16x8, glat_u32x4{h0, h1, h2, h3}); al[j] = __builtin_bit_cast(glat_f16x8, glat_u32x4{l0, l1, l2, l3});
+                }
+#pragma unroll
+                for (int i = 0; i < WI; ++i)
+#pragma unroll
+                    for (int j = 0; j < WJ; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], ah[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], al[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], ah[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else {
         // fragments of k group kg + 1 are requested before the matrix instructions of group kg (the scheduler would otherwise sink the
         // reads to their first use and expose the LDS round trip four times per stage)
         f32x4 a4[WI], b4[WJ];
@@ -191,6 +240,7 @@ __global__ __launch_bounds__(64 * WGN * WGM, 1) void gemm_lat_kernel(GemmArgs g,
                 for (int j = 0; j < WJ; ++j) b4[j] = bn[j];
             }
         }
+            }
     }
 
     RFE_TS(2);
@@ -233,7 +283,8 @@ extern "C" int rfe_k_dbg_timeline(unsigned long long* host, int n) {   // tuning
 bool launch_gemm_lat(hipStream_t s, const GemmArgs& g, const float* rope_csn, int rope_cols) {
     const int batch = g.batch > 0 ? g.batch : 1;
     if (batch > 1 && (g.A2 || g.R || rope_csn || batch > 16)) return false;
-    if (!g.kperm || g.K % LBK || (g.A2 && g.K1 % LBK) || g.M > 8192 || g.M < 1 || g.Bh || g.stats_in || g.stats_out) return false;
+    if (!g.kperm || g.K % LBK || (g.A2 && g.K1 % LBK) || g.M > 8192 || g.M < 1 || g.stats_in || g.stats_out) return false;
+    const bool h2 = g.Bh && g.Bl && !g.relu && (g.ldb % 8) == 0;   // RFE_OPT_LG_FP16X2: the split form of the same tiles (weight planes from load time)
     if ((g.lda % 4) || (g.ldb % 4) || (g.ldc % 4) || (g.A2 && (g.lda2 % 4)) || (g.R && (g.ldr % 4))) return false;
     const bool res = g.R != nullptr, rope = rope_csn != nullptr;
 #ifdef RFE_TUNING
@@ -247,8 +298,8 @@ bool launch_gemm_lat(hipStream_t s, const GemmArgs& g, const float* rope_csn, in
     do {                                                                                                                         \
         constexpr int BN_ = 16 * WI_ * WGN_, BM_ = 16 * WJ_ * WGM_, BYTES_ = LS_ * (BN_ + BM_) * LBK * 4;                        \
         const int MT = (g.M + BM_ - 1) / BM_;                                                                                    \
-        auto kern = gemm_lat_kernel<WI_, WJ_, WGN_, WGM_, LS_, RES_, ROPE_>;                                                     \
-        static bool ls_[64]; ensure_dynamic_lds((const void*)kern, BYTES_, ls_);                                                 \
+        auto kern = h2 ? gemm_lat_kernel<WI_, WJ_, WGN_, WGM_, LS_, RES_, ROPE_, true> : gemm_lat_kernel<WI_, WJ_, WGN_, WGM_, LS_, RES_, ROPE_, false>; \
+        static bool ls_[2][64]; ensure_dynamic_lds((const void*)kern, BYTES_, ls_[h2 ? 1 : 0]);                                  \
         hipLaunchKernelGGL(kern, dim3((g.N / BN_) * ((MT + 7) / 8 * 8), batch), dim3(64 * WGN_ * WGM_), BYTES_, s, g, rope_csn, rope_cols, MT, abl); \
         return true;                                                                                                             \
     } while (0)

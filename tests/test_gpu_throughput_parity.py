@@ -233,17 +233,48 @@ def test_lightglue_batch16_fp16x2_vs_oracle(ctx, oracle):
         b.free()
 
 
-def test_ffn_block_ragged_rows_fp32_and_fp16x2_vs_float64(ctx):
+def test_lightglue_one_pair_fp16x2_vs_oracle(ctx, oracle):
+    """RFE_OPT_LG_FP16X2 at the reference's own shape, ONE pair per call: the Linears run the split form of the latency tiles (gemm_lat.hip, H2: the
+    same ring / tile / epilogue, three v_mfma_f32_16x16x32_f16 per 32 k), the attention stays on the fp32 latency kernel.  Same bar as the fp32
+    path (match list by the borderline rule, scores within LG_SCORE_TOL, final token states), the option must really change the arithmetic, and a
+    ragged pair must work as well."""
+    from rover_slam_amd import capi
+    K = 1024
+    for lens0, lens1, seed in (([1024], [1024], 93), ([701], [1003], 94)):
+        k0, k1, d0, d1 = _constructed_batch(1, K, seed, lens0, lens1)
+        dx0, dx1, dsc = ctx.alloc(K * 1024), ctx.alloc(K * 1024), ctx.alloc(K * K * 4)
+        S32, pairs32, ms32 = ctx.match(k0, k1, d0, d1, lens0, lens1)
+        ctx.set_option(capi.OPT_LG_FP16X2, 1)
+        try:
+            ctx._chk(capi.lib.rfe_k_set_lightglue_tap(ctx.h, 0, dx0.ptr, dx1.ptr, dsc.ptr))
+            S, pairs, ms = ctx.match(k0, k1, d0, d1, lens0, lens1)
+        finally:
+            ctx.set_option(capi.OPT_LG_FP16X2, 0)
+        m, n = lens0[0], lens1[0]
+        ref = oracle.lightglue(Wt.make_lightglue(seed=11), k0[0, :m], k1[0, :n], d0[0, :m], d1[0, :n], debug=True)
+        ok, dev, only = lists_agree_borderline(pairs[0, :S[0]], ms[0, :S[0]], ref["pairs"], ref["ms"], ref["scores"], K)
+        assert ok and dev < LG_SCORE_TOL and ref["S"] > 400, (int(S[0]), ref["S"], dev, only)
+        x0 = dx0.download((K, 256), np.float32)[:m]; x1 = dx1.download((K, 256), np.float32)[:n]
+        assert np.abs(x0 - ref["x0"]).max() < LG_STATE_TOL and np.abs(x1 - ref["x1"]).max() < LG_STATE_TOL
+        assert S[0] != S32[0] or not np.array_equal(ms[0, :S[0]], ms32[0, :S32[0]]), "the option did not change the arithmetic: the split tiles did not run"
+        print(f"one pair ({m} x {n}) fp16x2: {int(S[0])} matches, max |score dev| vs oracle {dev:.2e}")
+        for b in (dx0, dx1, dsc):
+            b.free()
+
+
+@pytest.mark.parametrize("rows", [34077, 2013])
+def test_ffn_block_ragged_rows_fp32_and_fp16x2_vs_float64(ctx, rows):
     """One FFN block (ffn.0 -> LayerNorm -> GELU -> ffn.3 + residual) on 34 077 token rows -- not a multiple of the 128-row tiles -- through the
     forward's own code (rfe_k_lightglue_ffn: throughput tiles, fused LayerNorm partials) with the fp32 kernels and with RFE_OPT_LG_FP16X2 (split
-    GEMMs: weight planes by LDS-DMA, clamped edge rows): both against a float64 evaluation on sampled rows including the last ones."""
+    GEMMs: weight planes by LDS-DMA, clamped edge rows): both against a float64 evaluation on sampled rows including the last ones.
+    2 013 rows: the one-pair latency tiles (gemm_lat.hip: 16 x 16 x 4 fp32 / 16 x 16 x 32 split-fp16 products behind the LDS-DMA ring, stand-alone
+    LayerNorm + GELU pass, residual epilogue), also not a multiple of the 64-row tile."""
     from rover_slam_amd import capi
     from scipy.special import erf
     w = Wt.make_lightglue(seed=11)
     man, _ = Wt.lg_manifest()
     t = {name: (off, shape) for name, off, shape in man}
     g = lambda name: w[t[name][0]:t[name][0] + int(np.prod(t[name][1]))].reshape(t[name][1]).astype(np.float64)
-    rows = 34077
     rng = np.random.default_rng(21)
     x = rng.standard_normal((rows, 256)).astype(np.float32)
     s = rng.standard_normal((rows, 256)).astype(np.float32)
@@ -264,7 +295,7 @@ def test_ffn_block_ragged_rows_fp32_and_fp16x2_vs_float64(ctx):
         out = dout.download((rows, 256), np.float32)
         assert np.isfinite(out).all()
         dev[opt] = float(np.abs(out[sel] - ref).max())
-    print(f"FFN block, 34 077 rows: max |out - float64|  fp32 kernels {dev[0]:.2e}   fp16x2 split kernels {dev[1]:.2e}  (|out| up to {np.abs(ref).max():.1f})")
+    print(f"FFN block, {rows} rows: max |out - float64|  fp32 kernels {dev[0]:.2e}   fp16x2 split kernels {dev[1]:.2e}  (|out| up to {np.abs(ref).max():.1f})")
     assert dev[0] < 1e-4 and dev[1] < 1e-4, dev
     for b in (dx, dsec, dout):
         b.free()
