@@ -111,8 +111,8 @@ int rfe_set_hparams(rfe_ctx* ctx, const rfe_hparams* in);
  *   (folded) / <= 2.0e-4 (unfolded) against the fp32 CPU oracle, which itself sits up to 2.6e-4 from a float64 evaluation
  *   of the same graph (HIP vs float64: 2.4e-4 / 1.8e-4) -- the stated tolerance is 5e-4 for both.
  * RFE_OPT_LG_FP16X2 (default 0 = every LightGlue matrix product on the fp32 matrix instructions): 1 = the Linears (every call: the throughput
- *   tiles of batched calls, gemm_h2.hip, and the one- / few-pair latency tiles, gemm_lat.hip) AND the fused attention of batched calls
- *   (>= 32 768 token rows; at one pair the attention stays on its fp32 latency kernel) run as SPLIT products on the f16 matrix pipe --
+ *   tiles of batched calls, gemm_h2.hip, and the one- / few-pair latency tiles, gemm_lat.hip) AND the fused attention (batched calls of
+ *   >= 32 768 token rows: lg_attention_h2.hip; one / few pairs: the split form of lg_attention_lat.hip) run as SPLIT products on the f16 matrix pipe --
  *   every fp32 operand as fp16 hi + fp16 lo (22 of 24 significand bits), three of the four cross products, fp32 accumulation, softmax
  *   and LayerNorm / GELU in fp32 as before (rover-slam_amd/csrc/gemm_h2.hip, lg_attention_h2.hip).  Stand-alone the Linears are
  *   2.2-2.8x and the attention 2.4-2.6x faster than the fp32 kernels; error against float64: Linears rms 3.2e-8 of sum|a||b| (fp32 fmaf
@@ -120,7 +120,7 @@ int rfe_set_hparams(rfe_ctx* ctx, const rfe_hparams* in);
  *   over the 40-case study the match lists are identical and the scores sit 1.6e-4 (Wo folded) / 2.6e-4 (unfolded) from float64, inside
  *   the spread of the fp32 evaluations of the same graph (1.8e-4 .. 2.6e-4, profiles/r03_lg_tolerance.md).  Valid while activations
  *   stay below fp16's 65504 in magnitude (LightGlue's are O(1..100)); past it the attention's operands saturate (finite results), the
- *   Linears' inputs too (MODE.FP16_OVFL).  One pair per call: 2.43 -> 2.24 ms incl. both extractions, a stereo frame 2.59 -> 2.44 ms
+ *   Linears' inputs too (MODE.FP16_OVFL).  One pair per call: 2.43 -> 2.06 ms incl. both extractions, a stereo frame 2.59 -> 2.25 ms
  *   (bench.py `latency.resident_fp16x2`).  The assignment and all of SuperPoint stay fp32; bench.py reports the throughput step as
  *   `variants.fp16x2`, never as the headline. */
 #define RFE_OPT_LG_FOLD_WO 1

@@ -19,9 +19,12 @@
 // The rotary encoding is NOT applied here: the one-pair qkv projection (gemm_lat.hip, ROPE epilogue) has already rotated q and k.
 // Roofline: fp32 MFMA peak; algorithmic 4 heads * 4 * 64 * sum n_q n_k FLOP.
 #include "rfe_internal.h"
+#include "h2_split.h"
 
 namespace rfe {
 
+typedef _Float16 alat_f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t alat_u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* alat_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* alat_gptr_t;
 
@@ -29,6 +32,15 @@ constexpr int AL_K = 32;                         // keys per tile
 constexpr int AL_TILE_F = AL_K * 64;             // floats of one K (or V) tile
 constexpr int AL_WAVE_F = 2 * AL_TILE_F;         // per wave: one K tile | one V tile
 constexpr float AL_DEFER = 16.0f;                // log2 units (lg_kernels.hip: AT_DEFER)
+constexpr float AL_DEFER_H2 = 11.0f;             // split form: P = 2^(S - ref) must stay below fp16's 65504 (lg_attention_h2.hip)
+
+// eight floats -> fp16 hi / lo operand registers of a v_mfma_f32_32x32x16_f16 (h2_split.h)
+__device__ __forceinline__ void alat_split8(const float (&t)[8], alat_f16x8& hi, alat_f16x8& lo) {
+    uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+    h2_split2(t[0], t[1], h0, l0); h2_split2(t[2], t[3], h1, l1); h2_split2(t[4], t[5], h2, l2); h2_split2(t[6], t[7], h3, l3);
+    hi = __builtin_bit_cast(alat_f16x8, alat_u32x4{h0, h1, h2, h3});
+    lo = __builtin_bit_cast(alat_f16x8, alat_u32x4{l0, l1, l2, l3});
+}
 
 #ifdef RFE_TUNING
 __device__ unsigned long long rfe_dbg_ts_att[2048 * 8];   // in-kernel timeline (tuning build, abl & 4), see gemm_lat.hip
@@ -37,7 +49,11 @@ __device__ unsigned long long rfe_dbg_ts_att[2048 * 8];   // in-kernel timeline 
 #define RFE_ATS(slot) do { } while (0)
 #endif
 
-template <int NW>
+// H2 (RFE_OPT_LG_FP16X2, default off): both products of a tile as SPLIT products on the f16 matrix pipe -- K, Q, V and P = 2^(S - ref) as fp16
+// hi + lo (h2_split.h), three v_mfma_f32_32x32x16_f16 per 32 x 32 x 16 block: 24 matrix instructions of 32 cycles per 32-key tile instead of 64
+// of 64.  Same tiles, copies, softmax and merge; the accumulator registers 8 s .. 8 s + 7 of S^T ARE the eight keys a lane owes the B operand
+// of PV's k-step s, and the V values are read in exactly that key order, so P never moves (lg_attention_h2.hip).
+template <int NW, bool H2 = false>
 __global__ __launch_bounds__(64 * NW, 1) void lg_attention_lat_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld, float* __restrict__ out,
     int Lq, int Lk, int nqb, const int* __restrict__ qlen, const int* __restrict__ klen, const int* __restrict__ kv_map, int nseq_total, int abl) {
@@ -66,7 +82,17 @@ __global__ __launch_bounds__(64 * NW, 1) void lg_attention_lat_kernel(
     const size_t qrow_c = (size_t)seq * Lq + (qrow < Lq ? qrow : Lq - 1);
     constexpr float kScale = 0.125f * 1.44269504088896341f;   // 1 / sqrt(64) * log2(e): softmax in base 2, folded into Q
     float qreg[32];   // qreg[4 g + e] = Q[query][8 g + 4 h + e] * scale  (the k order of the swizzled K image, lg_attention_dma_kernel)
-    {
+    alat_f16x8 qh[4], ql[4];   // H2: k-step s holds head dimensions 16 s + 8 h .. + 7 of this lane's query, as fp16 hi / lo
+    if constexpr (H2) {
+        h2_saturate_mode();
+        const f32x4* qp4 = reinterpret_cast<const f32x4*>(q + qrow_c * ld + head * 64);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const f32x4 t0 = qp4[4 * s4 + 2 * h], t1 = qp4[4 * s4 + 2 * h + 1];
+            const float t[8] = {t0[0] * kScale, t0[1] * kScale, t0[2] * kScale, t0[3] * kScale, t1[0] * kScale, t1[1] * kScale, t1[2] * kScale, t1[3] * kScale};
+            alat_split8(t, qh[s4], ql[s4]);
+        }
+    } else {
         const f32x4* qp4 = reinterpret_cast<const f32x4*>(q + qrow_c * ld + head * 64) + h;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
@@ -150,11 +176,14 @@ __global__ __launch_bounds__(64 * NW, 1) void lg_attention_lat_kernel(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const float* const Kt = Kr;
         const float* const Vt = Vr;
-        f32x4 kf[8];
+        f32x4 kf[8];   // fp32: granule 2 g + h of key row j; H2: granules 4 s + 2 h, + 1 (k-step s = kf[2 s], kf[2 s + 1])
         {
             const float* ka = Kt + j * 64;
 #pragma unroll
-            for (int g = 0; g < 8; ++g) kf[g] = *reinterpret_cast<const f32x4*>(ka + (((2 * g + h) ^ jsw) << 2));
+            for (int g = 0; g < 8; ++g) {
+                const int gran = H2 ? 4 * (g >> 1) + 2 * h + (g & 1) : 2 * g + h;
+                kf[g] = *reinterpret_cast<const f32x4*>(ka + ((gran ^ jsw) << 2));
+            }
         }
         float vf[32];
         {
@@ -178,10 +207,22 @@ __global__ __launch_bounds__(64 * NW, 1) void lg_attention_lat_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[r] = init;
         }
+        if constexpr (H2) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const float t[8] = {kf[2 * s4][0], kf[2 * s4][1], kf[2 * s4][2], kf[2 * s4][3], kf[2 * s4 + 1][0], kf[2 * s4 + 1][1], kf[2 * s4 + 1][2], kf[2 * s4 + 1][3]};
+                alat_f16x8 kh, kl;
+                alat_split8(t, kh, kl);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s4], st, 0, 0, 0);   // small terms first
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s4], st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s4], st, 0, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int g = 0; g < 8; ++g)
 #pragma unroll
             for (int e = 0; e < 4; ++e) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[g][e], qreg[4 * g + e], st, 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         const int k0 = kbeg + t * AL_K;
         if (k0 + AL_K > nk) {      // only the last tile of the sequence can hold keys >= nk
@@ -197,7 +238,7 @@ __global__ __launch_bounds__(64 * NW, 1) void lg_attention_lat_kernel(
 #pragma unroll
             for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, st[r]), st[r + 1]);
             mx = fmaxf(mx, st[15]);
-            if (__any(first || mx > AL_DEFER)) {
+            if (__any(first || mx > (H2 ? AL_DEFER_H2 : AL_DEFER))) {
                 mx = fmaxf(mx, __shfl_xor(mx, 32));
                 const float ref = first ? 0.f : m_run;
                 const float m_new = fmaxf(m_run, mx + ref);
@@ -214,10 +255,35 @@ __global__ __launch_bounds__(64 * NW, 1) void lg_attention_lat_kernel(
             l_run += ps;
         }
         // ---- O^T[d][query] += sum_key V[key][d] P[key][query]; k-step r uses key (r & 3) + 8 (r >> 2) + 4 h
+        if constexpr (H2) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {      // k-step s2: keys 16 s2 + 8 (e >> 2) + 4 h + (e & 3) = accumulator registers 8 s2 + e
+                alat_f16x8 ph, pl, v0h, v0l, v1h, v1l;
+                {
+                    const float t[8] = {st[8 * s2], st[8 * s2 + 1], st[8 * s2 + 2], st[8 * s2 + 3], st[8 * s2 + 4], st[8 * s2 + 5], st[8 * s2 + 6], st[8 * s2 + 7]};
+                    alat_split8(t, ph, pl);
+                }
+                {
+                    const float t[8] = {vf[8 * s2], vf[8 * s2 + 1], vf[8 * s2 + 2], vf[8 * s2 + 3], vf[8 * s2 + 4], vf[8 * s2 + 5], vf[8 * s2 + 6], vf[8 * s2 + 7]};
+                    alat_split8(t, v0h, v0l);
+                }
+                {
+                    const float t[8] = {vf[16 + 8 * s2], vf[17 + 8 * s2], vf[18 + 8 * s2], vf[19 + 8 * s2], vf[20 + 8 * s2], vf[21 + 8 * s2], vf[22 + 8 * s2], vf[23 + 8 * s2]};
+                    alat_split8(t, v1h, v1l);
+                }
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0l, ph, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1l, ph, o1, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, pl, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, pl, o1, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, ph, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, ph, o1, 0, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r], st[r], o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[16 + r], st[r], o1, 0, 0, 0);
+        }
         }
     }
     l_run += __shfl_xor(l_run, 32);          // the two half-waves' partial sums
@@ -275,7 +341,7 @@ extern "C" int rfe_k_dbg_timeline_att(unsigned long long* host, int n) {
 // one (or a few) pairs: at most 8192 query rows, 16-byte aligned rows, no rotary (applied by the projection).  Returns false when the
 // shape is not served (the caller falls back to lg_kernels.hip).
 bool launch_lg_attention_lat(hipStream_t s, const float* q, const float* k, const float* v, int ld, float* out, int nseq, int Lq, int Lk,
-                             const int* qlen, const int* klen, const int* kv_map) {
+                             const int* qlen, const int* klen, const int* kv_map, bool h2) {
     if ((size_t)nseq * Lq > 8192 || (ld % 4) || Lq < 1 || Lk < 1) return false;
     const int nqb = (Lq + 31) / 32;
     const int units8 = (4 * nseq + 7) / 8 * 8;    // (sequence, head) units padded to a multiple of 8: the block decode stays bijective
@@ -285,17 +351,18 @@ bool launch_lg_attention_lat(hipStream_t s, const float* q, const float* k, cons
 #else
     constexpr int abl = 0;
 #endif
-#define RFE_ALAT_GO(NW_)                                                                                                                  \
+#define RFE_ALAT_GO(NW_, H2_)                                                                                                             \
     do {                                                                                                                                  \
         constexpr int bytes = (NW_ * AL_WAVE_F > NW_ * 32 * 68 ? NW_ * AL_WAVE_F : NW_ * 32 * 68) * 4;   /* tiles, later the merge */        \
         static bool ls_[64];                                                                                                              \
-        ensure_dynamic_lds((const void*)lg_attention_lat_kernel<NW_>, bytes, ls_);                                                        \
-        hipLaunchKernelGGL(lg_attention_lat_kernel<NW_>, dim3(nqb * units8), dim3(64 * NW_), bytes, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, nseq, abl); \
+        ensure_dynamic_lds((const void*)lg_attention_lat_kernel<NW_, H2_>, bytes, ls_);                                                   \
+        hipLaunchKernelGGL((lg_attention_lat_kernel<NW_, H2_>), dim3(nqb * units8), dim3(64 * NW_), bytes, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, nseq, abl); \
     } while (0)
 #ifdef RFE_TUNING
-    if (nw == 8) { RFE_ALAT_GO(8); return true; }
+    if (nw == 8) { RFE_ALAT_GO(8, false); return true; }
 #endif
-    RFE_ALAT_GO(4);
+    if (h2) { RFE_ALAT_GO(4, true); return true; }
+    RFE_ALAT_GO(4, false);
 #undef RFE_ALAT_GO
     return true;
 }

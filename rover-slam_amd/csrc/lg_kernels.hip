@@ -439,14 +439,14 @@ size_t lg_attention_part_bytes(int nseq, int Lq) {   // scratch of the split-key
 
 void launch_lg_attention(hipStream_t s, const float* q, const float* k, const float* v, int ld, float* out, int nseq, int Lq,
                          int Lk, const int* qlen, const int* klen, const int* kv_map, float* part, const float* rope_csn, bool fp16x2) {
-    if (fp16x2 && (size_t)nseq * Lq >= 32768 && (ld % 4) == 0) {   // RFE_OPT_LG_FP16X2, throughput shapes only (the Linears' rule, gemm.hip)
+    if (fp16x2 && (size_t)nseq * Lq >= 32768 && (ld % 4) == 0) {   // RFE_OPT_LG_FP16X2, throughput shapes (one / few pairs: the split form of the latency kernel below)
         launch_lg_attention_h2(s, q, k, v, ld, out, nseq, Lq, Lk, qlen, klen, kv_map, rope_csn);
         return;
     }
     // latency regime (one / few pairs, the shapes the reference itself runs), keys and queries already rotated by the projection: the
     // in-workgroup key split (lg_attention_lat.hip) -- no partial sums in HBM, no combine launch
     static const bool lat_on = tune_int("RFE_LAT", 1) != 0;
-    if (lat_on && !rope_csn && (size_t)nseq * Lq <= AT_SPLIT_MAX_ROWS && launch_lg_attention_lat(s, q, k, v, ld, out, nseq, Lq, Lk, qlen, klen, kv_map)) return;
+    if (lat_on && !rope_csn && (size_t)nseq * Lq <= AT_SPLIT_MAX_ROWS && launch_lg_attention_lat(s, q, k, v, ld, out, nseq, Lq, Lk, qlen, klen, kv_map, fp16x2)) return;
     const int nqb = (Lq + AT_Q - 1) / AT_Q;
     // (sequence, head) units, padded to a multiple of 8: the kernels deal their blocks round-robin over the 8 XCDs and map
     // block -> (unit, query block) by unit = (t / nqb) * 8 + xcd, which is a bijection only for a multiple of 8 units

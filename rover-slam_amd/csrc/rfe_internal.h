@@ -194,7 +194,7 @@ inline bool gemm_latency_regime(const GemmArgs& g) {
 bool launch_gemm_lat(hipStream_t s, const GemmArgs& g, const float* rope_csn, int rope_cols);
 // lg_attention_lat.hip: one-/few-pair attention without rotary (q, k rotated by the projection); false = shape not served.
 bool launch_lg_attention_lat(hipStream_t s, const float* q, const float* k, const float* v, int ld, float* out, int nseq, int Lq, int Lk,
-                             const int* qlen, const int* klen, const int* kv_map);
+                             const int* qlen, const int* klen, const int* kv_map, bool h2 = false /*RFE_OPT_LG_FP16X2: split products*/);
 // sp_post.hip
 void launch_softmax65_d2s(hipStream_t s, const float* logits, int ld, int B, int Hc, int Wc, float* score);
 constexpr int NMS_MAX_RADIUS = 8;

@@ -102,12 +102,14 @@ def test_attention_throughput_shape_vs_float64(ctx, kind):
     assert errs[0] < ATT_TOL and errs[1] < ATT_TOL, errs
 
 
+@pytest.mark.parametrize("fp16x2", [0, 1])
 @pytest.mark.parametrize("kind,nseq,L", [("self", 2, 1024), ("cross", 2, 1024), ("cross", 6, 152), ("self", 4, 1000), ("cross", 8, 1024), ("cross", 2, 36)])
-def test_attention_latency_shape_vs_float64(ctx, kind, nseq, L):
+def test_attention_latency_shape_vs_float64(ctx, kind, nseq, L, fp16x2):
     """The shapes the reference itself runs (one / few pairs per call, src/Matchers/lightglue_onnx.cpp:168-172): at most 8192 query rows and
     no rotary table (the one-pair projection has rotated q and k) take lg_attention_lat_kernel -- the key split inside the workgroup,
     self-pipelined waves, partial sums merged through LDS.  Ragged lengths put partial tiles first, last and alone in a wave's key
-    quarter, leave waves without keys and sequences shorter than one tile."""
+    quarter, leave waves without keys and sequences shorter than one tile.  fp16x2 = 1: the same kernel's split form (RFE_OPT_LG_FP16X2:
+    K, Q, V and P as fp16 hi + lo, three v_mfma_f32_32x32x16_f16 per block), same bar."""
     from rover_slam_amd import capi
     rng = np.random.default_rng(nseq * 1000 + L)
     lens = np.full(nseq, L, np.int32)
@@ -123,7 +125,7 @@ def test_attention_latency_shape_vs_float64(ctx, kind, nseq, L):
     x[::7, 3] += 6.0                                     # dominant keys / queries: the softmax reference moves late in a key range
     x[L // 2::11, 5] += 9.0
     xs = x.reshape(nseq, L, ld)
-    out = _run(ctx, capi, x, offs, ld, nseq, L, lens, kvmap, None, 0)
+    out = _run(ctx, capi, x, offs, ld, nseq, L, lens, kvmap, None, fp16x2)
     assert np.isfinite(out).all()
     worst = 0.0
     for s in range(nseq):
@@ -131,7 +133,7 @@ def test_attention_latency_shape_vs_float64(ctx, kind, nseq, L):
         ref = _attention_f64(xs[s][:, offs[0]:offs[0] + 256], xs[t][:, offs[1]:offs[1] + 256], xs[t][:, offs[2]:offs[2] + 256], int(lens[s]), int(lens[t]))
         worst = max(worst, float(np.abs(out[s] - ref).max()))
         assert not out[s][lens[s]:].any(), "context rows past the sequence length must be zero"
-    print(f"attention latency shape {kind} nseq={nseq} L={L}: max |context - float64| {worst:.2e}")
+    print(f"attention latency shape {kind} nseq={nseq} L={L} fp16x2={fp16x2}: max |context - float64| {worst:.2e}")
     assert worst < ATT_TOL
 
 
