@@ -63,7 +63,12 @@ def main(seconds=60.0, seed=0):
                 if m:
                     d1[p, :m] = d0[p, :m] + 0.05 * rng.standard_normal((m, 256)).astype(np.float32)
                     d1[p, :m] /= np.linalg.norm(d1[p, :m], axis=1, keepdims=True); k1[p, :m] = k0[p, :m] + 0.01
-            S, pairs, msc = c.match(k0, k1, d0, d1, ms_, ns_)
+            h2 = rng.random() < 0.3          # RFE_OPT_LG_FP16X2: the split forms of the one- / few-pair kernels, same bars
+            c.set_option(capi.OPT_LG_FP16X2, 1 if h2 else 0)
+            try:
+                S, pairs, msc = c.match(k0, k1, d0, d1, ms_, ns_)
+            finally:
+                c.set_option(capi.OPT_LG_FP16X2, 0)
             ok = True
             for p in range(P):
                 if ms_[p] == 0 or ns_[p] == 0:
@@ -82,7 +87,7 @@ def main(seconds=60.0, seed=0):
                     print(f"  pair {p}: S {S[p]} vs {r['S']}, symmetric difference {len(gp ^ rp)} (all borderline: {near}), max |dms| on common {dmax:.2e}", flush=True)
                     good = near and dmax < 5e-4
                 ok &= good
-            tag = f"lg P={P} Mmax={Mmax} Nmax={Nmax} m={ms_} n={ns_}"
+            tag = f"lg P={P} Mmax={Mmax} Nmax={Nmax} m={ms_} n={ns_} fp16x2={int(h2)}"
         elif kind == 3:                                           # ---- sparse stereo matching on extracted features
             H, W = 8 * int(rng.integers(12, 40)) + int(rng.integers(0, 8)) * int(rng.random() < 0.4), 8 * int(rng.integers(16, 60)) + int(rng.integers(0, 8)) * int(rng.random() < 0.4)
             disp = int(rng.integers(0, 30))
