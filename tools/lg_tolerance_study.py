@@ -151,6 +151,14 @@ def main():
         for fold in (0, 1):
             r[f"same{fold}"], r[f"dev{fold}"] = score_dev(got[fold][0], got[fold][1], ref["pairs"], ref["ms"])
             r[f"same{fold}_64"], r[f"dev{fold}_64"] = score_dev(got[fold][0], got[fold][1], p64, m64)
+        # one pair per call with RFE_OPT_LG_FP16X2 = 1: the split forms of the latency kernels (gemm_lat.hip / lg_attention_lat.hip, H2), default fold
+        ctx.set_option(capi.OPT_LG_FP16X2, 1)
+        try:
+            S, pairs, ms = ctx.match(k0[None], k1[None], d0[None], d1[None], [n[0]], [n[1]])
+        finally:
+            ctx.set_option(capi.OPT_LG_FP16X2, 0)
+        r["sameh"], r["devh"] = score_dev(pairs[0, :S[0]], ms[0, :S[0]], ref["pairs"], ref["ms"])
+        r["sameh_64"], r["devh_64"] = score_dev(pairs[0, :S[0]], ms[0, :S[0]], p64, m64)
         r["same_o64"], r["dev_o64"] = score_dev(ref["pairs"], ref["ms"], p64, m64)
         r["_in"] = (k0, k1, d0, d1, ref, p64, m64)
         rows.append(r)
@@ -201,6 +209,12 @@ def main():
               f"| {r['dev_o64']:.2e} | {yn(r['same_o64'])} | {r['dev0_64']:.2e} | {r['dev1_64']:.2e} |")
     print(f"| **max** | | | | | **{mx('dev0'):.2e}** | {yn(al('same0'))} | **{mx('dev1'):.2e}** | {yn(al('same1'))} | **{mx('dev_o64'):.2e}** "
           f"| {yn(al('same_o64'))} | **{mx('dev0_64'):.2e}** | **{mx('dev1_64'):.2e}** |")
+    print("\n## One pair per call with RFE_OPT_LG_FP16X2 = 1 (split forms of the latency kernels: Linears AND attention; RFE_OPT_LG_FOLD_WO at its default 1)\n")
+    print("| case | S | fp16x2 vs oracle | lists | fp16x2 vs f64 | lists |")
+    print("|---:|---:|---:|:-:|---:|:-:|")
+    for r in rows:
+        print(f"| {r['case']} | {r['S']} | {r['devh']:.2e} | {yn(r['sameh'])} | {r['devh_64']:.2e} | {yn(r['sameh_64'])} |")
+    print(f"| **max** | | **{mx('devh'):.2e}** | {yn(al('sameh'))} | **{mx('devh_64'):.2e}** | {yn(al('sameh_64'))} |")
     if args.batched:
         print("\n## The same cases inside 16-pair calls (throughput tiling: >= 32 768 token rows per call)\n")
         print("| case | S | gpu0 batched vs oracle | lists | gpu1 batched vs oracle | lists | gpu0 batched vs f64 | lists | gpu1 batched vs f64 | lists |")
@@ -210,7 +224,7 @@ def main():
                   f"| {r['bdev1_64']:.2e} | {yn(r['bsame1_64'])} |")
         print(f"| **max** | | **{mx('bdev0'):.2e}** | {yn(al('bsame0'))} | **{mx('bdev1'):.2e}** | {yn(al('bsame1'))} | **{mx('bdev0_64'):.2e}** | {yn(al('bsame0_64'))} "
               f"| **{mx('bdev1_64'):.2e}** | {yn(al('bsame1_64'))} |")
-        print("\n## ... with RFE_OPT_LG_FP16X2 = 1 (Linears as fp16 hi + lo split GEMMs on the f16 matrix pipe, rover-slam_amd/csrc/gemm_h2.hip; default off)\n")
+        print("\n## ... with RFE_OPT_LG_FP16X2 = 1 (16-pair calls: Linears and attention as fp16 hi + lo split products on the f16 matrix pipe, gemm_h2.hip / lg_attention_h2.hip; default off)\n")
         print("| case | S | gpu0 fp16x2 vs oracle | lists | gpu1 fp16x2 vs oracle | lists | gpu0 fp16x2 vs f64 | lists | gpu1 fp16x2 vs f64 | lists |")
         print("|---:|---:|---:|:-:|---:|:-:|---:|:-:|---:|:-:|")
         for r in rows:
