@@ -37,6 +37,13 @@ if [ -z "$QUICK" ]; then
   python3 tools/rocpd_pmc.py $(find $OUT/pmc_sq_fp16x2 -name "*_results.db" | head -1) > $OUT/pmc_sq_fp16x2.md
   rm -rf $OUT/trace_fp16x2 $OUT/pmc_sq_fp16x2
   bash tools/pmc_wait.sh ${TAG}_wait_fp16x2 --steps 2 --warmup 1 --lg-fp16x2 1 > /dev/null 2>&1
+  # ... and at the reference's own shape: one pair per call with the option on (split forms of the latency kernels)
+  for w in c3 c5; do
+    python bench.py --workload $w --steps 100 --warmup 10 --lg-fp16x2 1 > $OUT/lat_${w}_fp16x2.json 2>> $OUT/bench.err
+  done
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/trace_c3_fp16x2 -o t -- python3 $R/bench.py --workload c3 --steps 30 --warmup 5 --lg-fp16x2 1 > $OUT/trace_c3_fp16x2.log 2>&1)
+  python3 tools/rocpd_stats.py $(find $OUT/trace_c3_fp16x2 -name "*_results.db" | head -1) --gaps > $OUT/stats_c3_fp16x2.md
+  rm -rf $OUT/trace_c3_fp16x2
 fi
 find $OUT -name "*_results.db" | head
 cat $OUT/bench.json | cut -c1-1500

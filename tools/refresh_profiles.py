@@ -100,6 +100,18 @@ SQ rows are per XCD/SE slice: MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (32 
                 lat.append(tl[0] + f"\n\n(= {float(m.group(1)) / steps_traced:.3f} ms per traced step with at least one kernel running, against the UNTRACED wall time above: the ~10 us gaps are the "
                            "profiler's per-dispatch completion handling, the untraced stream has none of that size -- a kernel boundary costs 2.4-4.3 us all in, "
                            f"profiles/{rnd}_grid_barrier.md.)\n")
+    # one pair / one stereo frame with RFE_OPT_LG_FP16X2 on (same binary, same box)
+    for w in ("c3", "c5"):
+        f = os.path.join(O, f"lat_{w}_fp16x2.json")
+        if os.path.exists(f) and open(f).read().strip():
+            x = json.loads(open(f).read().strip().splitlines()[-1])
+            lat.append(f"## {w} with RFE_OPT_LG_FP16X2 = 1 (default off): {x['ms_per_step']} ms per step ({x['value']} {x['unit']}); with an event pair around every stage "
+                       f"{x.get('ms_per_step_with_stage_events')} ms\n")
+            lat.append("stage table (ms per step, events around every stage): " + ", ".join(f"{k} {v}" for k, v in x.get("stages_ms_per_step", {}).items()) + "\n")
+    g = os.path.join(O, "stats_c3_fp16x2.md")
+    if os.path.exists(g):
+        lat.append("kernel trace of c3 with the option on (`gemm_lat_kernel<..., true>` / `lg_attention_lat_kernel<4, true>` = the split forms):\n")
+        lat.append("\n".join(open(g).read().replace(ROOT + "/", "").splitlines()[:24]) + "\n")
     open(os.path.join(P, f"{rnd}_latency_kernel_stats.md"), "w").write("\n".join(lat))
     # ---- RFE_OPT_LG_FP16X2 diagnostic configuration (same binary, same box, same call)
     fb = os.path.join(O, "bench_fp16x2.json")
