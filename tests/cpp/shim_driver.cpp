@@ -113,6 +113,25 @@ int main(int argc, char** argv) {
         if (n1.channels() != 1 || n1.ptr<float>(0)[0] != (float)raw[0] * (float)(1.0 / 255.0)) return 7;
     }
 
+    // the runner's float entry exactly as the reference drives it (superpoint_onnx.cc:88-162 on NormalizeImage's CV_32F output, then
+    // Extractor_PostProcess): the same keypoints, responses and descriptors as operator() on the u8 frame, bit for bit
+    {
+        Configuration cfg;
+        cv::Mat g0(H, W, CV_8UC1, raw.data());
+        cv::Mat nf = NormalizeImage(g0);
+        SuperPointOnnxRunner* run = ext.featureExtractor;
+        if (run->Extractor_Inference(cfg, nf) != EXIT_SUCCESS || run->extractor_outputtensors.empty()) return 10;
+        std::vector<cv::KeyPoint> kf;
+        cv::Mat df;
+        run->Extractor_PostProcess(cfg, std::move(run->extractor_outputtensors[0]), kf, df);
+        if (kf.size() != f[0].mvKeys.size() || df.rows != (int)kf.size()) return 10;
+        for (size_t i = 0; i < kf.size(); ++i) {
+            if (kf[i].pt.x != f[0].mvKeys[i].pt.x || kf[i].pt.y != f[0].mvKeys[i].pt.y || kf[i].response != f[0].mvKeys[i].response) return 10;
+            for (int c = 0; c < 256; c += 17)
+                if (df.ptr<float>((int)i)[c] != f[0].mDescriptors.ptr<float>((int)i)[c]) return 10;
+        }
+    }
+
     // the two frames again as the left / right views of one stereo frame
     MockStereoFrame sf;
     sf.mvKeys = f[0].mvKeys; sf.mvKeysRight = f[1].mvKeys; sf.mDescriptors = f[0].mDescriptors; sf.mDescriptorsRight = f[1].mDescriptors;
