@@ -60,11 +60,12 @@ def _fields(buf):
         yield fn, wt, v
 
 
-_DT = {1: np.float32, 7: np.int64, 6: np.int32, 11: np.float64, 10: np.float16}
+_DT = {1: np.float32, 2: np.uint8, 3: np.int8, 5: np.int16, 6: np.int32, 7: np.int64, 9: np.bool_, 10: np.float16, 11: np.float64,
+       12: np.uint32, 13: np.uint64}
 
 
 def _tensor(buf):
-    dims, dtype, name, raw, floats, int64s = [], 1, "", None, [], []
+    dims, dtype, name, raw, floats, int64s, int32s, doubles = [], 1, "", None, [], [], [], []
     for fn, wt, v in _fields(buf):
         if fn == 1:      # dims
             if wt == 2:
@@ -90,19 +91,35 @@ def _tensor(buf):
                     int64s.append(d - (1 << 64) if d >= (1 << 63) else d)
             else:
                 int64s.append(v - (1 << 64) if v >= (1 << 63) else v)
+        elif fn == 5:    # int32_data (also carries bool / int8 / int16 / uint8 / float16 bit patterns)
+            if wt == 2:
+                j, vv = 0, bytes(v)
+                while j < len(vv):
+                    d, j = _varint(vv, j)
+                    int32s.append(d - (1 << 64) if d >= (1 << 63) else d)
+            else:
+                int32s.append(v - (1 << 64) if v >= (1 << 63) else v)
+        elif fn == 10:   # double_data
+            doubles.append(np.frombuffer(bytes(v), "<f8"))
         elif fn == 13:
             raise ValueError(f"tensor {name!r}: external data is not supported")
     if dtype not in _DT:
         return name, None
     if raw is not None:
-        arr = np.frombuffer(raw, np.dtype(_DT[dtype]).newbyteorder("<")).astype(_DT[dtype])
+        arr = np.frombuffer(raw, np.dtype(_DT[dtype]).newbyteorder("<") if dtype != 9 else np.uint8).astype(_DT[dtype])
     elif floats:
         arr = np.concatenate(floats).astype(np.float32)
     elif int64s:
         arr = np.array(int64s, np.int64)
+    elif int32s and dtype != 10:
+        arr = np.array(int32s, np.int64).astype(_DT[dtype])
+    elif doubles:
+        arr = np.concatenate(doubles).astype(np.float64)
     else:
         arr = np.zeros(0, _DT[dtype])
-    return name, arr.reshape(dims) if dims else arr
+    if not dims:         # no dims: a rank-0 tensor when it holds one element (Constant scalars), an empty one otherwise
+        return name, arr.reshape(()) if arr.size == 1 else arr
+    return name, arr.reshape(dims)
 
 
 def _attribute(buf):
@@ -168,6 +185,35 @@ def read_model(path):
                             node["attrs"][aname] = aval
                 nodes.append(node)
     return inits, nodes
+
+
+def read_graph_io(path):
+    """-> dict(inputs=[names the caller feeds, initializers excluded], outputs=[names], opset=int or None): the tensor names the
+    reference binds by string (src/Extractors/superpoint_onnx.cc:100,133-134; src/Matchers/lightglue_onnx.cpp:168-172,210-211)."""
+    data = memoryview(open(path, "rb").read())
+    ins, outs, init_names, opset = [], [], set(), None
+    for fn, wt, v in _fields(data):
+        if fn == 8 and wt == 2:         # ModelProto.opset_import: OperatorSetIdProto{domain = 1, version = 2}
+            dom, ver = "", None
+            for ofn, owt, ov in _fields(v):
+                if ofn == 1:
+                    dom = bytes(ov).decode()
+                elif ofn == 2:
+                    ver = ov
+            if dom in ("", "ai.onnx") and ver is not None:
+                opset = int(ver)
+        if fn != 7 or wt != 2:
+            continue
+        for gfn, gwt, gv in _fields(v):
+            if gfn in (11, 12) and gwt == 2:     # GraphProto.input / output: ValueInfoProto{name = 1}
+                for vfn, _, vv in _fields(gv):
+                    if vfn == 1:
+                        (ins if gfn == 11 else outs).append(bytes(vv).decode())
+            elif gfn == 5 and gwt == 2:
+                for tfn, _, tv in _fields(gv):
+                    if tfn == 8:
+                        init_names.add(bytes(tv).decode())
+    return dict(inputs=[n for n in ins if n not in init_names], outputs=outs, opset=opset)
 
 
 def _linears_from_graph(inits, nodes):

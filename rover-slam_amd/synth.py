@@ -21,9 +21,13 @@ def make_scene(rng, H, W, margin=16):
     return img
 
 
-def make_frames(n, H=480, W=640, seed=20240314, max_shift=8):
-    """Returns uint8 [n,H,W] and the per-frame integer (dx,dy) offsets into the scene."""
+def make_frames(n, H=480, W=640, seed=20240314, max_shift=8, shift_step=1):
+    """Returns uint8 [n,H,W] and the per-frame integer (dx,dy) offsets into the scene.
+    shift_step = 8 (with max_shift = 16): consecutive frames differ by multiples of SuperPoint's 8-px cell, so that the same scene
+    point lands on the same place of a cell and even an untrained (seeded) extractor repeats its keypoints and descriptors --
+    what gives the bench's self-check hundreds of matches per pair.  shift_step = 1 is the stream of rounds 1-4, bit for bit."""
     rng = np.random.default_rng(seed)
+    assert max_shift % shift_step == 0
     margin = 2 * max_shift
     scene = make_scene(rng, H, W, margin)
     frames = np.empty((n, H, W), np.uint8)
@@ -31,8 +35,8 @@ def make_frames(n, H=480, W=640, seed=20240314, max_shift=8):
     ox = oy = margin
     for i in range(n):
         if i:
-            ox = int(np.clip(ox + rng.integers(-max_shift, max_shift + 1), 0, 2 * margin))
-            oy = int(np.clip(oy + rng.integers(-max_shift, max_shift + 1), 0, 2 * margin))
+            ox = int(np.clip(ox + shift_step * rng.integers(-(max_shift // shift_step), max_shift // shift_step + 1), 0, 2 * margin))
+            oy = int(np.clip(oy + shift_step * rng.integers(-(max_shift // shift_step), max_shift // shift_step + 1), 0, 2 * margin))
         offs[i] = (ox, oy)
         f = scene[oy:oy + H, ox:ox + W] + rng.integers(0, 16, (H, W)).astype(np.float32)
         frames[i] = np.clip(f, 0, 255).astype(np.uint8)

@@ -17,63 +17,23 @@ import numpy as np
 import pytest
 
 torch = pytest.importorskip("torch")
-nn = torch.nn
 
 from rover_slam_amd import onnx_weights as OW, weights as Wt  # noqa: E402
+import onnx_export as X  # noqa: E402  (tools/, on sys.path through conftest.py)
+from onnx_export import SuperPointPublished, LightGluePublished  # noqa: E402,F401
+
+_load_sp, _load_lg, _lg_inputs = X.load_sp, X.load_lg, X.lg_inputs
 
 
-def _serialise(model, args, input_names, output_names, fold, dynamic_axes=None):
+def _serialise(*a, **k):
     """ModelProto bytes from torch's own C++ serialiser, or skip when this torch build lacks the internals."""
     try:
-        import importlib
-        from torch.onnx._internal.torchscript_exporter import utils as U
-        from torch.onnx._internal.torchscript_exporter._globals import GLOBALS
-        from torch.onnx import OperatorExportTypes
-        for v in range(9, 18):      # the symbolic functions register on import: without opset >= 11 in-place slice assignment has no export
-            importlib.import_module(f"torch.onnx._internal.torchscript_exporter.symbolic_opset{v}")
-        GLOBALS.export_onnx_opset_version = 17
-    except Exception as e:                                    # pragma: no cover
-        pytest.skip(f"torch TorchScript ONNX exporter internals not available: {e}")
-    with torch.no_grad():
-        graph, params, _ = U._model_to_graph(model, args, do_constant_folding=fold, input_names=input_names,
-                                             output_names=output_names, dynamic_axes=dynamic_axes or {})
-        out = graph._export_onnx(params, 17, dynamic_axes or {}, False, OperatorExportTypes.ONNX, True, True, {}, True, "", {})
-    proto = out[0]
-    assert isinstance(proto, (bytes, bytearray)) and len(proto) > 1000
-    return bytes(proto)
+        return X.serialise(*a, **k)
+    except X.ExporterUnavailable as e:                       # pragma: no cover
+        pytest.skip(str(e))
 
 
 # ---------------------------------------------------------------------------------------------- published SuperPoint
-class SuperPointPublished(nn.Module):
-    """Layer list / names of the published SuperPoint (reference include/SuperPoint.h:24-41); forward up to the dense maps."""
-
-    def __init__(self):
-        super().__init__()
-        for name, cin, cout, k in Wt.SP_LAYERS:
-            setattr(self, name, nn.Conv2d(cin, cout, k, padding=k // 2))
-
-    def forward(self, image):
-        r, pool = torch.relu, lambda t: torch.nn.functional.max_pool2d(t, 2, 2)
-        x = r(self.conv1a(image)); x = pool(r(self.conv1b(x)))
-        x = r(self.conv2a(x)); x = pool(r(self.conv2b(x)))
-        x = r(self.conv3a(x)); x = pool(r(self.conv3b(x)))
-        x = r(self.conv4a(x)); x = r(self.conv4b(x))
-        s = torch.softmax(self.convPb(r(self.convPa(x))), 1)[:, :-1]
-        b, _, h, w = s.shape
-        scores = s.permute(0, 2, 3, 1).reshape(b, h, w, 8, 8).permute(0, 1, 3, 2, 4).reshape(b, h * 8, w * 8)
-        d = self.convDb(r(self.convDa(x)))
-        desc = torch.nn.functional.normalize(d, p=2, dim=1)
-        kp = torch.nonzero(scores[0] > 0.5)                   # stands in for the NMS / top-k tail (int64 keypoints output)
-        return kp, scores, desc
-
-
-def _load_sp(m, blob):
-    man, _ = Wt.sp_manifest()
-    with torch.no_grad():
-        for name, off, shape in man:
-            layer, leaf = name.split(".")
-            getattr(getattr(m, layer), leaf).copy_(torch.from_numpy(blob[off:off + int(np.prod(shape))].reshape(shape).copy()))
-    return m.eval()
 
 
 @pytest.mark.parametrize("fold", [True, False])
@@ -102,162 +62,6 @@ def test_superpoint_published_forward_matches_oracle(oracle):
     r = oracle.superpoint(wsp, img, kmax=16, debug=True)
     assert np.abs(scores[0].numpy() - r["scoremap"]).max() < 2e-5
     assert np.abs(desc[0].permute(1, 2, 0).numpy() - r["descmap"]).max() < 1e-5
-
-
-# ---------------------------------------------------------------------------------------------- published LightGlue
-def _rotate_half(x):          # published: x.unflatten(-1, (-1, 2)); spelled with reshape like the ONNX-exportable forks (TorchScript has no unflatten)
-    x = x.reshape(x.shape[:-1] + (-1, 2))
-    x1, x2 = x[..., 0], x[..., 1]
-    return torch.stack((-x2, x1), dim=-1).flatten(start_dim=-2)
-
-
-def _apply_rotary(freqs, t):
-    return t * freqs[0] + _rotate_half(t) * freqs[1]
-
-
-class _PosEnc(nn.Module):
-    def __init__(self):
-        super().__init__()
-        self.Wr = nn.Linear(2, 32, bias=False)
-
-    def forward(self, x):
-        p = self.Wr(x)
-        emb = torch.stack([torch.cos(p), torch.sin(p)], 0).unsqueeze(2)       # published: .unsqueeze(-3)
-        return torch.stack([emb, emb], -1).flatten(4)   # published: emb.repeat_interleave(2, dim=-1) (the TorchScript exporter mis-infers its rank)
-
-
-def _ffn():
-    return nn.Sequential(nn.Linear(512, 512), nn.LayerNorm(512, elementwise_affine=True), nn.GELU(), nn.Linear(512, 256))
-
-
-def _attend(q, k, v):
-    s = torch.matmul(q, k.transpose(2, 3)) * 0.125          # [b, heads, n, 64]; 64 ** -0.5
-    return torch.matmul(torch.softmax(s, -1), v)
-
-
-class _SelfBlock(nn.Module):
-    def __init__(self):
-        super().__init__()
-        self.Wqkv = nn.Linear(256, 768)
-        self.out_proj = nn.Linear(256, 256)
-        self.ffn = _ffn()
-
-    def forward(self, x, enc):
-        y = self.Wqkv(x)
-        qkv = y.reshape(y.shape[0], y.shape[1], 4, 64, 3).transpose(1, 2)     # published: .unflatten(-1, (heads, -1, 3)): interleaved (head, dim, q|k|v)
-        q, k, v = qkv[..., 0], qkv[..., 1], qkv[..., 2]
-        ctx = _attend(_apply_rotary(enc, q), _apply_rotary(enc, k), v)
-        msg = self.out_proj(ctx.transpose(1, 2).flatten(start_dim=-2))
-        return x + self.ffn(torch.cat([x, msg], -1))
-
-
-class _CrossBlock(nn.Module):
-    def __init__(self):
-        super().__init__()
-        self.to_qk = nn.Linear(256, 256)
-        self.to_v = nn.Linear(256, 256)
-        self.to_out = nn.Linear(256, 256)
-        self.ffn = _ffn()
-
-    def forward(self, x0, x1):
-        hd = lambda t: t.reshape(t.shape[0], t.shape[1], 4, 64).transpose(1, 2)
-        qk0, qk1, v0, v1 = hd(self.to_qk(x0)), hd(self.to_qk(x1)), hd(self.to_v(x0)), hd(self.to_v(x1))
-        m0 = self.to_out(_attend(qk0, qk1, v1).transpose(1, 2).flatten(start_dim=-2))
-        m1 = self.to_out(_attend(qk1, qk0, v0).transpose(1, 2).flatten(start_dim=-2))
-        return x0 + self.ffn(torch.cat([x0, m0], -1)), x1 + self.ffn(torch.cat([x1, m1], -1))
-
-
-class _Layer(nn.Module):
-    def __init__(self):
-        super().__init__()
-        self.self_attn = _SelfBlock()
-        self.cross_attn = _CrossBlock()
-
-    def forward(self, d0, d1, e0, e1):
-        return self.cross_attn(self.self_attn(d0, e0), self.self_attn(d1, e1))
-
-
-class _Assign(nn.Module):
-    def __init__(self):
-        super().__init__()
-        self.matchability = nn.Linear(256, 1)
-        self.final_proj = nn.Linear(256, 256)
-
-    def forward(self, d0, d1):
-        md0, md1 = self.final_proj(d0) / 256 ** 0.25, self.final_proj(d1) / 256 ** 0.25
-        sim = torch.matmul(md0, md1.transpose(1, 2))
-        ls = torch.nn.functional.logsigmoid
-        z0, z1 = self.matchability(d0), self.matchability(d1)
-        return torch.log_softmax(sim, 2) + torch.log_softmax(sim, 1) + ls(z0) + ls(z1).transpose(1, 2)
-
-
-class LightGluePublished(nn.Module):
-    """Module tree / parameter names of the published LightGlue (input_proj = identity at 256-d SuperPoint descriptors); the fused
-    export has no early exit, so only the last log_assignment head is live (the others never reach the file)."""
-
-    def __init__(self, n_layers=Wt.LG_LAYERS, filter_threshold=0.1):
-        super().__init__()
-        self.filter_threshold = filter_threshold
-        self.posenc = _PosEnc()
-        self.transformers = nn.ModuleList([_Layer() for _ in range(n_layers)])
-        self.log_assignment = nn.ModuleList([_Assign() for _ in range(n_layers)])
-
-    def forward(self, kpts0, kpts1, desc0, desc1):
-        e0, e1 = self.posenc(kpts0), self.posenc(kpts1)
-        d0, d1 = desc0, desc1
-        for layer in self.transformers:
-            d0, d1 = layer(d0, d1, e0, e1)
-        scores = self.log_assignment[-1](d0, d1)
-        m0 = scores.max(2)
-        m1 = scores.max(1)
-        idx = torch.arange(scores.shape[1])[None]
-        mutual = m1.indices.gather(1, m0.indices) == idx
-        ms = torch.where(mutual, m0.values.exp(), torch.zeros_like(m0.values))
-        valid = ms[0] > self.filter_threshold
-        i = torch.nonzero(valid)[:, 0]
-        return torch.stack([i, m0.indices[0][i]], -1), ms[0][i], d0, d1, scores
-
-
-def _interleave_qkv(w, b):
-    """canonical rows t*256 + h*64 + d  ->  published rows h*192 + d*3 + t (inverse of onnx_weights._deinterleave_qkv)"""
-    return (np.ascontiguousarray(w.reshape(3, 4, 64, 256).transpose(1, 2, 0, 3).reshape(768, 256)),
-            np.ascontiguousarray(b.reshape(3, 4, 64).transpose(1, 2, 0).reshape(768)))
-
-
-def _load_lg(m, blob):
-    man, _ = Wt.lg_manifest()
-    t = {name: blob[off:off + int(np.prod(shape))].reshape(shape).copy() for name, off, shape in man}
-    cp = lambda p, a: p.copy_(torch.from_numpy(np.ascontiguousarray(a)))
-    with torch.no_grad():
-        cp(m.posenc.Wr.weight, t["posenc.Wr"])
-        for l, L in enumerate(m.transformers):
-            p, s, c = f"layers.{l}.", L.self_attn, L.cross_attn
-            w, b = _interleave_qkv(t[p + "self.Wqkv"], t[p + "self.bqkv"])
-            cp(s.Wqkv.weight, w); cp(s.Wqkv.bias, b)
-            for mod, wn, bn in ((s.out_proj, "self.Wo", "self.bo"), (s.ffn[0], "self.W1", "self.b1"), (s.ffn[1], "self.ln_g", "self.ln_b"),
-                                (s.ffn[3], "self.W2", "self.b2"), (c.to_qk, "cross.Wqk", "cross.bqk"), (c.to_v, "cross.Wv", "cross.bv"),
-                                (c.to_out, "cross.Wo", "cross.bo"), (c.ffn[0], "cross.W1", "cross.b1"), (c.ffn[1], "cross.ln_g", "cross.ln_b"),
-                                (c.ffn[3], "cross.W2", "cross.b2")):
-                cp(mod.weight, t[p + wn]); cp(mod.bias, t[p + bn])
-        for a in m.log_assignment[:-1]:                     # dead heads: anything but the live weights
-            for q in a.parameters():
-                q.fill_(0.5)
-        a = m.log_assignment[-1]
-        cp(a.final_proj.weight, t["final_proj.W"]); cp(a.final_proj.bias, t["final_proj.b"])
-        cp(a.matchability.weight, t["matchability.w"].reshape(1, 256)); cp(a.matchability.bias, t["matchability.b"])
-    return m.eval()
-
-
-def _lg_inputs(n0, n1, seed):
-    rng = np.random.default_rng(seed)
-    d0 = rng.standard_normal((n0, 256)).astype(np.float32); d0 /= np.linalg.norm(d0, axis=1, keepdims=True)
-    d1 = rng.standard_normal((n1, 256)).astype(np.float32); d1 /= np.linalg.norm(d1, axis=1, keepdims=True)
-    m = min(n0, n1)
-    d1[:m] = d0[:m] + 0.02 * rng.standard_normal((m, 256)).astype(np.float32)
-    d1[:m] /= np.linalg.norm(d1[:m], axis=1, keepdims=True)
-    k0 = rng.uniform(-0.9, 0.9, (n0, 2)).astype(np.float32)
-    k1 = rng.uniform(-0.9, 0.9, (n1, 2)).astype(np.float32); k1[:m] = k0[:m] + 0.01
-    return k0, k1, d0, d1
 
 
 @pytest.mark.parametrize("fold", [True, False])

@@ -22,77 +22,16 @@ F = torch.nn.functional
 
 from rover_slam_amd import onnx_weights as OW, weights as Wt, synth  # noqa: E402
 from test_onnx_exporter import SuperPointPublished, LightGluePublished, _serialise, _load_sp, _load_lg, _lg_inputs  # noqa: E402
-
-SETTINGS = [dict(max_keypoints=1024, detection_threshold=0.0005, nms_radius=4, remove_borders=4),
-            dict(max_keypoints=2048, detection_threshold=0.005, nms_radius=3, remove_borders=2)]
-
-
-def simple_nms(scores, r):
-    """published SuperPoint / LightGlue simple_nms"""
-    mp = lambda x: F.max_pool2d(x, kernel_size=r * 2 + 1, stride=1, padding=r)
-    zeros = torch.zeros_like(scores)
-    max_mask = scores == mp(scores)
-    for _ in range(2):
-        supp_mask = mp(max_mask.float()) > 0
-        supp_scores = torch.where(supp_mask, zeros, scores)
-        new_max_mask = supp_scores == mp(supp_scores)
-        max_mask = max_mask | (new_max_mask & (~supp_mask))
-    return torch.where(max_mask, scores, zeros)
+import onnx_export as X  # noqa: E402
+from onnx_export import SETTINGS, sp_tail  # noqa: E402
 
 
-def sp_tail(scores, dmap, hp, topk="min"):
-    """published tail on a [1,H,W] score map and a [1,256,Hc,Wc] normalised descriptor map -> keypoints (x, y) i64 [K,2], scores [K],
-    descriptors [K,256].  topk = "min": torch.topk(scores, min(k, n)) as trace-friendly exports write it; "const": a constant k
-    (the published top_k_keypoints when more than k candidates exist at trace time)."""
-    scores = simple_nms(scores, hp["nms_radius"])
-    pad = hp["remove_borders"]
-    if pad > 0:
-        scores[:, :pad] = -1
-        scores[:, :, :pad] = -1
-        scores[:, -pad:] = -1
-        scores[:, :, -pad:] = -1
-    best = torch.where(scores > hp["detection_threshold"])
-    sc = scores[best]
-    kp = torch.stack(best[1:3], dim=-1)
-    if topk == "min":
-        k = torch.minimum(torch.tensor(hp["max_keypoints"]), torch.tensor(sc.shape[0]))
-    else:
-        k = hp["max_keypoints"]
-    sc, idx = torch.topk(sc, k, dim=0)
-    kp = torch.flip(kp[idx], [1]).float()                                      # (y, x) -> (x, y)
-    _, c, hc, wc = dmap.shape
-    g = (kp - 8 / 2 + 0.5) / torch.tensor([wc * 8 - 8 / 2 - 0.5, hc * 8 - 8 / 2 - 0.5])
-    d = F.grid_sample(dmap, (g * 2 - 1).view(1, 1, -1, 2), mode="bilinear", align_corners=True)
-    d = F.normalize(d.reshape(1, c, -1), p=2, dim=1)
-    return kp.long(), sc, d[0].transpose(0, 1)
+def _export_sp(tmp_path, *a, **k):
+    try:
+        return X.export_sp(tmp_path, *a, **k)
+    except X.ExporterUnavailable as e:                       # pragma: no cover
+        pytest.skip(str(e))
 
-
-class SuperPointWithTail(SuperPointPublished):
-    def __init__(self, hp, topk="min"):
-        super().__init__()
-        self.hp, self.topk = hp, topk
-
-    def forward(self, image):
-        r, pool = torch.relu, lambda t: F.max_pool2d(t, 2, 2)
-        x = r(self.conv1a(image)); x = pool(r(self.conv1b(x)))
-        x = r(self.conv2a(x)); x = pool(r(self.conv2b(x)))
-        x = r(self.conv3a(x)); x = pool(r(self.conv3b(x)))
-        x = r(self.conv4a(x)); x = r(self.conv4b(x))
-        s = torch.softmax(self.convPb(r(self.convPa(x))), 1)[:, :-1]
-        b, _, h, w = s.shape
-        scores = s.permute(0, 2, 3, 1).reshape(b, h, w, 8, 8).permute(0, 1, 3, 2, 4).reshape(b, h * 8, w * 8)
-        dmap = F.normalize(self.convDb(r(self.convDa(x))), p=2, dim=1)
-        kp, sc, d = sp_tail(scores, dmap, self.hp, self.topk)
-        return kp[None], sc[None], d[None]
-
-
-def _export_sp(tmp_path, hp, topk="min", seed=5, size=(64, 80)):
-    blob = Wt.make_superpoint(seed=seed)
-    m = _load_sp(SuperPointWithTail(hp, topk), blob)
-    proto = _serialise(m, (torch.rand(1, 1, *size),), ["image"], ["keypoints", "scores", "descriptors"], True, {"image": {2: "h", 3: "w"}})
-    path = tmp_path / "superpoint.onnx"
-    path.write_bytes(proto)
-    return str(path), blob
 
 
 @pytest.mark.parametrize("hp", SETTINGS)
