@@ -7,6 +7,9 @@ onnxmodel/superpoint.onnx and onnxmodel/lightglue_sim.onnx through `Session::Run
 
 --backend ort  (default): onnxruntime's CPUExecutionProvider -- the TRUE reference arithmetic.  Neither onnxruntime nor the two blobs
                exist in the build image (.MISSING_LARGE_BLOBS:4-5); exit code 2 says so.
+--backend replay --replay FILE.npz : the graph outputs a previous `--backend mini|ort --save FILE.npz` run wrote, replayed call by call (the feeds
+               must be the saved ones) -- how the committed fixtures tests/golden/onnx_s*.npz (tools/gen_onnx_golden.py) reach the GPU box,
+               where `-m gpu` tests run this harness with --gpu.
 --backend mini : tools/mini_onnx.py, a numpy / torch-CPU interpreter of the same graph file (build container only).  With graphs written
                by torch's ONNX exporter from the published modules (tools/onnx_export.py) this executes EVERY line of this harness and
                pins the oracle against graph execution -- keypoint order, int64 layout, the (y, x) -> (x, y) flip, TopK ties, border,
@@ -32,8 +35,46 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
-def _session_factory(backend):
+class _Arg:
+    def __init__(self, name):
+        self.name = name
+
+
+class _ReplaySession:
+    """Saved graph outputs behind the InferenceSession surface: run() hands back what the recorded execution returned for the SAME feed."""
+
+    def __init__(self, z, kind):
+        self.z, self.kind, self.calls = z, kind, 0
+
+    def get_inputs(self):
+        return [_Arg(n) for n in self.z[self.kind + "_inputs"].tolist()]
+
+    def get_outputs(self):
+        return [_Arg(n) for n in self.z[self.kind + "_outputs"].tolist()]
+
+    def run(self, names, feeds):
+        i, self.calls = self.calls, self.calls + 1
+        if self.kind == "sp":
+            want = (self.z["frames"][i].astype(np.float32) / 255.0)[None, None]
+            if not np.array_equal(feeds["image"], want):
+                raise ValueError(f"replay: frame {i} is not the recorded feed")
+            return [self.z[f"sp{i}_{n}"][None] for n in names]
+        want = {"kpts0": self.z[f"lg{i}_kpts0"], "kpts1": self.z[f"lg{i}_kpts1"],             # pair i = frames i, i + 1: the descriptors are the
+                "desc0": self.z[f"sp{i}_descriptors"][None], "desc1": self.z[f"sp{i + 1}_descriptors"][None]}   # extractor graph's own outputs
+        for k in want:
+            if not np.array_equal(feeds[k], want[k]):
+                raise ValueError(f"replay: pair {i} input {k} is not the recorded feed")
+        return [self.z[f"lg{i}_{n}"] for n in names]
+
+
+def _session_factory(backend, replay=None):
     """-> (make_session(path), description) or (None, reason)"""
+    if backend == "replay":
+        if not replay or not os.path.exists(replay):
+            return None, f"--backend replay needs --replay FILE.npz ({replay!r} not found)"
+        z = np.load(replay)
+        return (lambda p: _ReplaySession(z, "sp" if "superpoint" in os.path.basename(p) else "lg")), \
+            f"replay of {replay} (recorded from: {str(z['recorded_from'])})"
     if backend == "mini":
         import mini_onnx
         return (lambda p: mini_onnx.InferenceSession(p)), "tools/mini_onnx.py (numpy / torch-CPU graph interpreter; NOT the reference runtime)"
@@ -42,6 +83,18 @@ def _session_factory(backend):
     except ImportError:
         return None, "onnxruntime is not installed; parity against the reference runtime stays unpinned (use --backend mini for graph-execution parity)"
     return (lambda p: ort.InferenceSession(p, providers=["CPUExecutionProvider"])), f"onnxruntime {ort.__version__} CPUExecutionProvider"
+
+
+def weights_sha256(path):
+    """sha256 over every float initializer of a graph file (name-sorted): identifies the weights a recording was made with"""
+    import hashlib
+    from rover_slam_amd import onnx_weights
+    inits, _ = onnx_weights.read_model(path)
+    h = hashlib.sha256()
+    for k in sorted(inits):
+        if inits[k].dtype == np.float32:
+            h.update(np.ascontiguousarray(inits[k]).tobytes())
+    return h.hexdigest()
 
 
 def compare_keypoints(k_ref, s_ref, d_ref, n, kxy, sc, de, score_tol):
@@ -76,7 +129,8 @@ def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--superpoint", required=True)
     ap.add_argument("--lightglue")
-    ap.add_argument("--backend", default="ort", choices=["ort", "mini"])
+    ap.add_argument("--backend", default="ort", choices=["ort", "mini", "replay"])
+    ap.add_argument("--replay", metavar="FILE.npz")
     ap.add_argument("--frames", type=int, default=4)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
@@ -92,7 +146,7 @@ def main(argv=None):
     ap.add_argument("--assume-lg", action="append", metavar="KEY=VALUE", help="the same for LightGlue")
     ap.add_argument("--save", metavar="FILE.npz", help="write inputs and every graph output (fixture format of tools/gen_onnx_golden.py)")
     a = ap.parse_args(argv)
-    make_session, what = _session_factory(a.backend)
+    make_session, what = _session_factory(a.backend, a.replay)
     if make_session is None:
         print(f"ort_parity: {what}", file=sys.stderr)
         return 2
@@ -106,6 +160,14 @@ def main(argv=None):
     print(f"graph execution: {what}")
     H, W = a.height, a.width
     frames, _ = synth.make_frames(a.frames, H, W, seed=a.frame_seed, max_shift=16 if a.shift_step == 8 else 8, shift_step=a.shift_step)
+    if a.backend == "replay":
+        z = np.load(a.replay)
+        frames = z["frames"]
+        H, W = frames.shape[1:]
+        for key, path in (("sp_onnx_weights_sha256", a.superpoint), ("lg_onnx_weights_sha256", a.lightglue)):
+            if path and str(z[key]) != weights_sha256(path):
+                print(f"ort_parity: {path} does not hold the weights the recording was made with ({key})", file=sys.stderr)
+                return 2
     # the graph's baked-in hyper-parameters first: a deviation below must be arithmetic, not a silently different K / radius / threshold
     read, problems = onnx_weights.read_superpoint_hparams(a.superpoint)
     print(f"{a.superpoint}: hyper-parameters read from the graph: {read}" + (f"; unresolved: {problems}" if problems else ""))
@@ -134,7 +196,8 @@ def main(argv=None):
         assert (got["sp_max_keypoints"], got["sp_nms_radius"], got["sp_remove_borders"], got["sp_topk_always"]) == \
                (hp["max_keypoints"], hp["nms_radius"], hp["remove_borders"], hp["topk_always"]), "rfe_load_weights lost the file's hyper-parameters"
     bad = False
-    feats, saved = [], {"frames": frames, "sp_hparams": np.array([hp[k] for k in Wt.SP_HPARAMS], np.float64)}
+    feats, saved = [], {"frames": frames, "sp_hparams": np.array([hp[k] for k in Wt.SP_HPARAMS], np.float64), "recorded_from": what,
+                        "sp_inputs": np.array(in_names), "sp_outputs": np.array(out_names), "sp_onnx_weights_sha256": weights_sha256(a.superpoint)}
     for i, img in enumerate(frames):
         x = (img.astype(np.float32) / 255.0)[None, None]                       # NormalizeImage, transform.cpp:3-17
         k_ref, s_ref, d_ref = sp.run(["keypoints", "scores", "descriptors"], {"image": x})
@@ -170,7 +233,8 @@ def main(argv=None):
         if in_names != ["kpts0", "kpts1", "desc0", "desc1"] or out_names[:2] != ["matches0", "mscores0"]:   # lightglue_onnx.cpp:168-172,210-211
             print(f"ort_parity: {a.lightglue}: inputs {in_names} / outputs {out_names} are not the names the reference binds", file=sys.stderr)
             return 1
-        saved["lg_hparams"] = np.array([hpl[k] for k in Wt.LG_HPARAMS], np.float64)
+        saved.update({"lg_hparams": np.array([hpl[k] for k in Wt.LG_HPARAMS], np.float64), "lg_inputs": np.array(in_names), "lg_outputs": np.array(out_names),
+                      "lg_onnx_weights_sha256": weights_sha256(a.lightglue)})
         if ctx is not None:
             lg_rfew = os.path.join(tmpdir.name, "lightglue_sim.rfew")
             Wt.save(lg_rfew, wlg, 2, hpl)
@@ -184,7 +248,7 @@ def main(argv=None):
             if m_ref.dtype != np.int64 or m_ref.ndim != 2 or m_ref.shape[1] != 2 or ms_ref.shape != m_ref.shape[:1]:   # lightglue_onnx.cpp:404-409
                 print(f"ort_parity: pair {i}: output layout {m_ref.dtype}{m_ref.shape} / {ms_ref.shape} is not int64 [S,2] / [S]", file=sys.stderr)
                 return 1
-            saved.update({f"lg{i}_matches0": m_ref, f"lg{i}_mscores0": ms_ref})
+            saved.update({f"lg{i}_matches0": m_ref, f"lg{i}_mscores0": ms_ref, f"lg{i}_kpts0": k0n[None], f"lg{i}_kpts1": k1n[None]})
             o = oracle.lightglue(wlg, k0n, k1n, d0, d1, filter_thr=hpl["filter_threshold"])
             cands = [("oracle", o["pairs"], o["ms"])]
             if ctx is not None:
