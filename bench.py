@@ -201,9 +201,11 @@ def torch_cpu_baseline(frames, wsp, wlg, budget_s=10.0):
                       f"({torch.__version__}, {nthr} threads), same synthetic weights and frames, {dt:.1f} s"}
 
 
-def cpu_baseline(frames, wsp, wlg, gpu=None):
+def cpu_baseline(frames, wsp, wlg, gpu=None, tol=None, verify_budget_s=90.0):
     """The CPU oracle (a port, not the reference's ONNXRuntime path -- that cannot run here: no
-    onnxruntime, no .onnx blobs) on a bounded sample of the bench frames (about 12 s of CPU work)."""
+    onnxruntime, no .onnx blobs) on a bounded sample of the bench frames (about 12 s of CPU work).  The oracle doubles as the checker of
+    what the timed GPU loop produced: every frame / pair of the sample, and -- untimed, after the sample's clock has stopped -- the
+    remaining pairs of the batch too (bounded by `verify_budget_s`), so that the match lists are compared on thousands of matches."""
     from oracle import oracle as O
     O.build()
     # bounded sample: frames are extracted and matched to their predecessor one by one until ~12 s of CPU work are spent
@@ -214,20 +216,21 @@ def cpu_baseline(frames, wsp, wlg, gpu=None):
     alt = gpu.get("alt") if gpu is not None else None      # match lists of the same pairs from variants.fp16x2 (RFE_OPT_LG_FP16X2 on): same oracle, same rule
     alt_stat = {"ok": True, "identical": True, "dev": 0.0, "matches": 0, "one_sided": 0}
     from tolerances import LG_SCORE_TOL, lists_agree_borderline
+    LG_TOL = LG_SCORE_TOL if tol is None else tol
 
     def check_pair(idx, lg):
         """the tests' own rule (tests/tolerances.py): lists equal up to borderline flips (score within tol of the 0.1 filter, or
         the two best candidates of a row / column closer than 2 tol), common scores within LG_SCORE_TOL"""
         nonlocal lg_ok, lg_identical, ms_dev, n_matches, one_sided
         Sg = int(gpu["S"][idx])
-        ok, dev, only = lists_agree_borderline(gpu["pairs"][idx, :Sg], gpu["ms"][idx, :Sg], lg["pairs"], lg["ms"], lg["scores"], KMAX)
-        lg_ok &= bool(ok and dev < LG_SCORE_TOL)
+        ok, dev, only = lists_agree_borderline(gpu["pairs"][idx, :Sg], gpu["ms"][idx, :Sg], lg["pairs"], lg["ms"], lg["scores"], KMAX, tol=LG_TOL)
+        lg_ok &= bool(ok and dev < LG_TOL)
         lg_identical &= bool(only == 0 and Sg == lg["S"])
         ms_dev, n_matches, one_sided = max(ms_dev, float(dev)), n_matches + Sg, one_sided + only
         if alt is not None:
             Sa = int(alt["S"][idx])
-            ok2, dev2, only2 = lists_agree_borderline(alt["pairs"][idx, :Sa], alt["ms"][idx, :Sa], lg["pairs"], lg["ms"], lg["scores"], KMAX)
-            alt_stat["ok"] &= bool(ok2 and dev2 < LG_SCORE_TOL)
+            ok2, dev2, only2 = lists_agree_borderline(alt["pairs"][idx, :Sa], alt["ms"][idx, :Sa], lg["pairs"], lg["ms"], lg["scores"], KMAX, tol=LG_TOL)
+            alt_stat["ok"] &= bool(ok2 and dev2 < LG_TOL)
             alt_stat["identical"] &= bool(only2 == 0 and Sa == lg["S"])
             alt_stat["dev"], alt_stat["matches"], alt_stat["one_sided"] = max(alt_stat["dev"], float(dev2)), alt_stat["matches"] + Sa, alt_stat["one_sided"] + only2
 
@@ -248,22 +251,32 @@ def cpu_baseline(frames, wsp, wlg, gpu=None):
     dt = time.perf_counter() - t0
     verified = None
     if gpu is not None:
-        extra = 0
-        if nf < len(frames):   # untimed: the last pair of the batch too (the batch edges are where indexing slips show)
-            a, b = O.superpoint(wsp, frames[-2], kmax=KMAX), O.superpoint(wsp, frames[-1], kmax=KMAX)
-            lg = O.lightglue(wlg, O.normalize_keypoints(a["kxy"][:a["n"]].astype(np.float32), H, W),
-                             O.normalize_keypoints(b["kxy"][:b["n"]].astype(np.float32), H, W), a["desc"][:a["n"]], b["desc"][:b["n"]], debug=True)
-            sp_ok &= bool(np.array_equal(gpu["kxy"][-1], b["kxy"]) and np.array_equal(gpu["desc"][-1], b["desc"]))
-            check_pair(len(gpu["S"]) - 1, lg)
-            extra = 1
-        verified = {"ok": bool(sp_ok and lg_ok), "frames": nf + 2 * extra, "pairs": nf - 1 + extra, "superpoint_bit_exact": sp_ok,
+        # untimed: the REST of the batch (the sample's clock has stopped) -- every remaining frame and pair while the budget lasts, and in any
+        # case the last pair (the batch edges are where indexing slips show)
+        extra_f, extra_p, t1 = 0, 0, time.perf_counter()
+        k = nf
+        while k < len(frames):
+            if time.perf_counter() - t1 > verify_budget_s and k < len(frames) - 1:
+                prev, k = O.superpoint(wsp, frames[-2], kmax=KMAX), len(frames) - 1     # budget spent: jump to the last pair
+                continue
+            cur = O.superpoint(wsp, frames[k], kmax=KMAX)
+            sp_ok &= bool(gpu["n"][k] == cur["n"] and np.array_equal(gpu["kxy"][k], cur["kxy"]) and np.array_equal(gpu["score"][k], cur["score"])
+                          and np.array_equal(gpu["desc"][k], cur["desc"]))
+            lg = O.lightglue(wlg, O.normalize_keypoints(prev["kxy"][:prev["n"]].astype(np.float32), H, W),
+                             O.normalize_keypoints(cur["kxy"][:cur["n"]].astype(np.float32), H, W), prev["desc"][:prev["n"]], cur["desc"][:cur["n"]], debug=True)
+            check_pair(k - 1, lg)
+            prev, k, extra_f, extra_p = cur, k + 1, extra_f + 1, extra_p + 1
+        verified = {"ok": bool(sp_ok and lg_ok), "frames": nf + extra_f, "pairs": nf - 1 + extra_p, "pairs_in_batch": len(gpu["S"]), "superpoint_bit_exact": sp_ok,
                     "match_lists_agree": lg_ok, "match_lists_identical": lg_identical, "matches_compared": n_matches,
-                    "one_sided_borderline_matches": one_sided, "match_score_max_dev": ms_dev, "match_score_tolerance": LG_SCORE_TOL,
-                    "lg_fold_wo": gpu.get("fold"),
+                    "matches_per_pair_mean": round(n_matches / max(nf - 1 + extra_p, 1), 1),
+                    "one_sided_borderline_matches": one_sided, "match_score_max_dev": ms_dev, "match_score_tolerance": LG_TOL,
+                    "lg_fold_wo": gpu.get("fold"), "untimed_seconds_beyond_the_sample": round(time.perf_counter() - t1, 1),
                     "rule": "tests/tolerances.py lists_agree_borderline: a match only one side reports must sit within tol of the 0.1 filter or "
                             "on a row / column whose two best probabilities are closer than 2 tol; common scores within tol",
-                    "tolerance_note": "stated fp32 tolerance of LightGlue match scores at K = 1024 (tests/tolerances.py, profiles/r02_lg_tolerance.md: "
-                                      "any two fp32 evaluations of the graph differ by 1-3e-4, oracle vs float64 2.6e-4)"}
+                    "tolerance_note": ("north_star's 1e-4 on the calibrated LightGlue weight set (tests/tolerances.py LG_SCORE_TOL_CALIBRATED: log-assignment peaks at "
+                                       "52-63, independent fp32 evaluations agree to ~6e-6)" if LG_TOL <= 1e-4 else
+                                       "stated fp32 tolerance of LightGlue match scores at K = 1024 on the ill-conditioned seeded weight set (tests/tolerances.py, "
+                                       "profiles/r02_lg_tolerance.md: any two fp32 evaluations of the graph differ by 1-3e-4, oracle vs float64 2.6e-4)")}
         if alt is not None:
             verified["fp16x2_variant"] = {"ok": alt_stat["ok"], "match_lists_identical": alt_stat["identical"], "matches_compared": alt_stat["matches"],
                                           "one_sided_borderline_matches": alt_stat["one_sided"], "match_score_max_dev": alt_stat["dev"],
@@ -276,6 +289,11 @@ def cpu_baseline(frames, wsp, wlg, gpu=None):
             "sample": f"{nf} frames 640x480 extracted + {nf - 1} consecutive pairs matched (K<=1024) by oracle/rfe_oracle.c, "
                       f"OpenMP on {O.threads()} threads (= the CPUs this process may use: {os.cpu_count()} logical CPUs, affinity and "
                       f"cgroup quota applied), {dt:.1f} s; {nf - 1} frames counted"}
+
+
+class AuxMismatch(RuntimeError):
+    """an auxiliary run (variants / PCIe pipeline / pool) produced RESULTS that differ from the resident path: a correctness failure, reported
+    as out["invalid_aux"] with a non-zero exit status -- unlike infrastructure failures (OOM, missing driver), which only leave an `error` string"""
 
 
 def stereo_frames(synth, T=8):
@@ -378,7 +396,7 @@ def latency_resident(ctx, capi, synth, sharding, torch, dev, frames, steps=50, w
     return out
 
 
-def latency_dropin(synth, wsp, wlg, pair_np, steps=50, warmup=5, check=True):
+def latency_dropin(synth, wsp, wlg, pair_np, steps=50, warmup=5, check=True, tol=None):
     """`latency.dropin`: the same three configurations through the C++ drop-in classes with HOST pointers in and out -- what a
     Rover-SLAM Tracking thread sees (SPextractor::operator(), src/Extractors/SPextractor.cc:516-617; SPmatcher::MatchingPoints_onnx(Frame&,
     Frame&), src/Matchers/SPmatcher.cc:457-542; stereo pair of extractor threads, src/Frame.cc:142-147) -- timed by a compiled driver
@@ -435,7 +453,7 @@ def latency_dropin(synth, wsp, wlg, pair_np, steps=50, warmup=5, check=True):
                          O.normalize_keypoints(ob["kxy"][:ob["n"]].astype(np.float32), rows, cols), oa["desc"][:oa["n"]], ob["desc"][:ob["n"]], debug=True)
         sref = {(int(i), int(j)): float(m) for (i, j), m in zip(lg["pairs"], lg["ms"])}
         got = [(i, int(j)) for i, j in enumerate(vn) if j >= 0]
-        ok, _, only = lists_agree_borderline(np.array(got).reshape(-1, 2), [sref.get(k, 0.0) for k in got], lg["pairs"], lg["ms"], lg["scores"], KMAX)
+        ok, _, only = lists_agree_borderline(np.array(got).reshape(-1, 2), [sref.get(k, 0.0) for k in got], lg["pairs"], lg["ms"], lg["scores"], KMAX, tol=tol)
         return bool(ok and s == len(got)), only, lg["S"]
 
     f0, f1 = take_frame(), take_frame()
@@ -579,6 +597,9 @@ def main():
                          "c2 = SuperPoint only, batch 1 (latency); c3 = one 640x480 pair, SuperPoint x2 + LightGlue (latency); "
                          "c5 = stereo 752x480 stream: per stereo frame 2 extractions + sparse stereo match + 1 LightGlue match "
                          "of the left image against the previous left image (latency)")
+    ap.add_argument("--pairing", default="calibrated", choices=["calibrated", "r04"],
+                    help="synthetic weight / frame pairing: calibrated (default; centred descriptor head, calibrated LightGlue law, cell-aligned shifts: hundreds of "
+                         "matches per pair, 1e-4 self-check) or r04 (the plain seeded laws and arbitrary shifts of rounds 1-4, 5e-4 self-check)")
     ap.add_argument("--kmax", type=int, default=KMAX, help="keypoint capacity per frame (default 1024)")
     ap.add_argument("--frames-per-gpu", type=int, default=FRAMES_PER_GPU,
                     help="frames (= pairs) each GPU owns per step; 32 = BASELINE configs[3] (256 frames over 8 GPUs), other values are exploratory")
@@ -644,7 +665,17 @@ def main():
 
     from rover_slam_amd import capi, weights as Wt, synth, sharding
     ctx = capi.Context(dev_index)
-    wsp, wlg = Wt.make_superpoint(seed=7), Wt.make_lightglue(seed=11)
+    # Weight / frame pairing (round 5).  `calibrated` (default): SuperPoint seed 7 with the centred descriptor head, LightGlue seed 11 with the calibrated
+    # law (log-assignment in the range trained weights live in -> the self-check runs at north_star's 1e-4), frames shifted by multiples of the 8-px cell
+    # so that an untrained extractor repeats its keypoints: 150-200 matches per pair instead of 3.  `r04`: the pairing of rounds 1-4 (plain seeded laws,
+    # arbitrary shifts, ill-conditioned LightGlue logits, 5e-4 bar).  The arithmetic per step is the same (K saturates Kmax either way;
+    # `variants.r04_pairing` times the other pairing next to the headline).
+    calibrated = args.pairing == "calibrated"
+    wsp = Wt.make_superpoint(seed=7, desc_center="auto" if calibrated else None)
+    wlg = Wt.make_lightglue(seed=11, calibrated=calibrated)
+    from tolerances import LG_SCORE_TOL, LG_SCORE_TOL_CALIBRATED
+    lg_tol = LG_SCORE_TOL_CALIBRATED if calibrated else LG_SCORE_TOL
+    frame_kw = dict(max_shift=16, shift_step=8) if calibrated else {}
     ctx.set_weights(capi.KIND_SUPERPOINT, wsp)
     ctx.set_weights(capi.KIND_LIGHTGLUE, wlg)
     if args.lg_fold is not None:
@@ -672,7 +703,7 @@ def main():
     # ONE common stream of world * owned + 1 frames (configs[3]: 257 for 8 x 32), the same on every rank (seeded, 0.6 s to synthesise);
     # rank r takes frames [owned r, owned r + owned]: its overlap frame IS rank r + 1's first frame, no inter-GPU dependency.
     # At N = 1 this is the 33-frame stream of every earlier round.
-    stream_np, _ = synth.make_frames(world * shard.owned + 1, H, W, seed=20240314)
+    stream_np, _ = synth.make_frames(world * shard.owned + 1, H, W, seed=20240314, **frame_kw)
     frames_np = np.ascontiguousarray(stream_np[shard.start:shard.start + B])
     del stream_np
     frames = torch.from_numpy(frames_np).to(dev)
@@ -792,6 +823,7 @@ def main():
     # variable-K batching"): the same 33-frame / 32-pair step at other keypoint budgets, short runs, never the headline
     variants = None
     fp16x2_out = None
+    aux_mismatch = []      # CORRECTNESS mismatches of auxiliary runs (never swallowed like infrastructure failures): -> out["invalid_aux"], exit status 5
     if world == 1 and not args.no_variants and args.workload == "c4" and not args.lg_fp16x2:
         variants = {}
         try:
@@ -815,6 +847,47 @@ def main():
                 variants[tag] = {"value": round(FRAMES_PER_GPU * nst / dtv, 2), "unit": "frames/s", "kmax": kmax, "steps": nst,
                                  "ms_per_step": round(dtv / nst * 1e3, 3), "keypoints_per_frame": {"mean": float(kk.mean()), "min": int(kk.min()), "max": int(kk.max())},
                                  "matches_per_pair_mean": float(vp.S.float().mean().item()), "note": note}
+            # the pairing of rounds 1-4 next to the headline: same arithmetic, other weights / frames -> the step time must not move
+            if calibrated:
+                fr_keep = frames.clone()
+                ctx.set_weights(capi.KIND_SUPERPOINT, Wt.make_superpoint(seed=7)); ctx.set_weights(capi.KIND_LIGHTGLUE, Wt.make_lightglue(seed=11))
+                old_np, _ = synth.make_frames(world * shard.owned + 1, H, W, seed=20240314)
+                frames.copy_(torch.from_numpy(np.ascontiguousarray(old_np[shard.start:shard.start + B])).to(dev))
+                run_variant(KMAX, "r04_pairing", "the weight / frame pairing of rounds 1-4 (plain seeded laws, shifts of -8..8 px): same step, 2-4 matches per pair")
+                frames.copy_(fr_keep); del fr_keep
+                ctx.set_weights(capi.KIND_SUPERPOINT, wsp); ctx.set_weights(capi.KIND_LIGHTGLUE, wlg)
+                head_ms = dt / args.steps * 1e3
+                variants["r04_pairing"]["headline_ms_per_step"] = round(head_ms, 3)
+                variants["r04_pairing"]["step_time_ratio_to_headline"] = round(variants["r04_pairing"]["ms_per_step"] / head_ms, 4)
+                if not 0.97 <= variants["r04_pairing"]["step_time_ratio_to_headline"] <= 1.03:
+                    aux_mismatch.append(f"variants.r04_pairing: step time {variants['r04_pairing']['ms_per_step']} ms vs headline {head_ms:.3f} ms (the pairing must not change the throughput)")
+            # configs[3] under STRONG scaling at N = 1: all 257 frames of the node's batch in ONE call (what `--scaling strong --gpus 1` times), next to the
+            # weak-scaling headline: the 1-GPU number must not depend on the 33-frame batch
+            try:
+                nF = STRONG_TOTAL_FRAMES + 1
+                big_np, _ = synth.make_frames(nF, H, W, seed=20240314, **frame_kw)
+                big = torch.from_numpy(big_np).to(dev)
+                bp = sharding.ResultPack(nF, KMAX, dev)
+                def bstep():
+                    ctx._chk(capi.lib.rfe_extract_match_stream_dev(ctx.h, big.data_ptr(), H, W, W, nF, KMAX, 0.0005, 0.1, bp.n.data_ptr(), bp.kxy.data_ptr(),
+                                                                   bp.score.data_ptr(), bp.desc.data_ptr(), bp.S.data_ptr(), bp.pairs.data_ptr(), bp.ms.data_ptr()))
+                bstep(); fence()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    bstep()
+                fence()
+                dtb = (time.perf_counter() - t1) / 3
+                # the first 33 frames ARE the headline batch: same keypoints, descriptors and match lists bit for bit
+                same = bool(torch.equal(bp.n[:B], n) and torch.equal(bp.kxy[:B], kxy) and torch.equal(bp.desc[:B], desc) and torch.equal(bp.S[:B - 1], S[:B - 1])
+                            and all(torch.equal(bp.pairs[q, :int(S[q])], pairs[q, :int(S[q])]) and torch.equal(bp.ms[q, :int(S[q])], ms[q, :int(S[q])]) for q in range(B - 1)))
+                variants["strong_n1"] = {"value": round(STRONG_TOTAL_FRAMES / dtb, 2), "unit": "frames/s", "frames_per_call": nF, "pairs_per_call": nF - 1, "ms_per_step": round(dtb * 1e3, 3),
+                                         "first_33_frames_equal_headline_batch": same, "workspace_bytes": int(ctx.workspace_bytes()),
+                                         "note": "configs[3] with --scaling strong at N = 1: 257 frames extracted + 256 pairs matched by ONE rfe_extract_match_stream_dev call"}
+                if not same:
+                    aux_mismatch.append("variants.strong_n1: the first 33 frames of the 257-frame call differ from the headline batch")
+                del big, bp
+            except capi.RfeError as e:
+                variants["strong_n1"] = {"error": str(e)[:300]}
             run_variant(512, "kmax512", "same frames and weights, keypoint budget 512")
             run_variant(256, "kmax256", "same frames and weights, keypoint budget 256")
             # bias chosen on the bench frames with the oracle: +9 still saturates Kmax = 1024 on every frame, +9.5 leaves 700-900 keypoints
@@ -842,6 +915,8 @@ def main():
                 Sh, ph, mh = S.cpu().numpy(), pairs.cpu().numpy(), ms.cpu().numpy()
                 same = bool(np.array_equal(Sh, S32) and all(np.array_equal(ph[q, :S32[q]], p32[q, :S32[q]]) for q in range(B - 1)))
                 devh = max([float(np.abs(mh[q, :S32[q]] - m32[q, :S32[q]]).max()) for q in range(B - 1) if S32[q] > 0 and Sh[q] == S32[q]] or [0.0]) if same else None
+                if not same:     # informational for the option (its own oracle check follows in cpu_baseline), but never silent
+                    print("bench.py: variants.fp16x2 match lists differ from the fp32 path's", file=sys.stderr)
                 variants["fp16x2"].update({"match_lists_identical_to_fp32_path": same, "match_score_max_dev_vs_fp32_path": devh,
                                                    "matches_total": int(S32.sum())})
                 fp16x2_out = {"S": Sh.copy(), "pairs": ph.copy(), "ms": mh.copy()}
@@ -898,8 +973,13 @@ def main():
             for si, (dv_, hv_, *_e) in enumerate(sets):               # same results as the resident path
                 for nm, h_, t_ in zip(("n", "kxy", "score", "desc", "S", "pairs", "ms"), hv_, (n, kxy, score, desc, S, pairs, ms)):
                     if not torch.equal(h_, t_.cpu()):
-                        raise RuntimeError(f"PCIe pipeline: {nm} of buffer set {si} differs from the resident path "
-                                           f"({int((h_ != t_.cpu()).sum())} elements)")
+                        raise AuxMismatch(f"PCIe pipeline: {nm} of buffer set {si} differs from the resident path "
+                                          f"({int((h_ != t_.cpu()).sum())} elements)")
+        except AuxMismatch as e:
+            pcie = {"error": str(e)[:300], "mismatch": True}
+            aux_mismatch.append(f"pcie_inclusive: {e}"[:300])
+            print(f"bench.py: {e}", file=sys.stderr)
+            fence()
         except Exception as e:
             pcie = {"error": f"{type(e).__name__}: {e}"[:300]}
             print(f"bench.py: PCIe-inclusive run failed: {pcie['error']}", file=sys.stderr)
@@ -938,6 +1018,7 @@ def main():
                          "note": "rfe_pool_extract_match_stream: frames from pageable host memory, counts / keypoints / matches back to host arrays, "
                                  "calls not overlapped; the C-ABI route to configs[3], not the headline value"}
             if not same:
+                aux_mismatch.append("pool_c_abi: the pool call's results differ from the resident path")
                 print("bench.py: the pool call's results differ from the resident path", file=sys.stderr)
         except Exception as e:
             pool_line = {"error": f"{type(e).__name__}: {e}"[:300]}
@@ -961,17 +1042,19 @@ def main():
         except Exception as e:
             latency["resident"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         try:
-            latency["dropin"] = latency_dropin(synth, wsp, wlg, frames_np, steps=args.latency_steps, check=not args.no_cpu_baseline)
+            # >= 500 calls each, per-call samples: a Tracking thread sees single calls (p50 / p95 / max), not a mean
+            latency["dropin"] = latency_dropin(synth, wsp, wlg, frames_np, steps=max(args.latency_steps, 500), warmup=20, check=not args.no_cpu_baseline,
+                                               tol=lg_tol)
         except Exception as e:
             latency["dropin"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         # the same device-resident calls with RFE_OPT_LG_FP16X2 on (default off, never the headline): at one pair the Linears take the split form of
-        # the latency tiles (gemm_lat.hip, H2), the attention stays fp32.  SuperPoint (c2) is unaffected by the option and not repeated.
+        # the latency tiles (gemm_lat.hip, H2) and the attention the split form of lg_attention_lat.hip.  SuperPoint (c2) is unaffected and not repeated.
         try:
             ctx.set_option(capi.OPT_LG_FP16X2, 1)
             r2 = latency_resident(ctx, capi, synth, sharding, torch, dev, frames, steps=args.latency_steps)
             latency["resident_fp16x2"] = {"c3": r2["c3"], "c5": r2["c5"],
-                                          "note": "RFE_OPT_LG_FP16X2 = 1: LightGlue's Linears as fp16 hi + lo split products (three f16 matrix instructions per fp32 "
-                                                  "product, fp32 accumulation); match lists / scores of this configuration are oracle-checked by "
+                                          "note": "RFE_OPT_LG_FP16X2 = 1: LightGlue's Linears AND the one-pair attention as fp16 hi + lo split products (three f16 matrix "
+                                                  "instructions per fp32 product, fp32 accumulation); match lists / scores of this configuration are oracle-checked by "
                                                   "tests/test_gpu_throughput_parity.py::test_lightglue_one_pair_fp16x2_vs_oracle"}
         except Exception as e:
             latency["resident_fp16x2"] = {"error": f"{type(e).__name__}: {e}"[:300]}
@@ -1010,9 +1093,10 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"configs[3] per GPU: {FRAMES_PER_GPU + 1} synthetic 640x480 u8 frames resident in HBM, SuperPoint extract "
                                    f"(Kmax={KMAX}, thr=0.0005) + LightGlue match of {FRAMES_PER_GPU} consecutive pairs (9 layers, filter 0.1); "
-                                   f"{FRAMES_PER_GPU} frames counted per GPU per step; seeded synthetic weights; the same resident frames every step "
+                                   f"{FRAMES_PER_GPU} frames counted per GPU per step; seeded synthetic weights ({'centred descriptor head + calibrated LightGlue law, frames shifted by multiples of 8 px' if calibrated else 'plain laws of rounds 1-4, arbitrary shifts'}); the same resident frames every step "
                                    "(compute-bound path, no data-dependent control flow besides the keypoint counts)",
-                       "frames_per_gpu": FRAMES_PER_GPU, "kmax": KMAX, "mean_keypoints": float(lens.mean()), "lg_fold_wo": fold,
+                       "frames_per_gpu": FRAMES_PER_GPU, "kmax": KMAX, "mean_keypoints": float(lens.mean()), "lg_fold_wo": fold, "pairing": args.pairing,
+                       "matches_per_pair_mean": float(S.float().mean().item()),
                        "sharding": f"frames sharded over {world} GPU(s), 1 overlap frame per rank"
                                    + ("; ONE gather per step of counts/keypoints/matches to rank 0 over RCCL" if world > 1 else "")},
             "ranks": world,
@@ -1055,7 +1139,7 @@ def main():
             gpu["fold"] = fold
             if fp16x2_out is not None:
                 gpu["alt"] = fp16x2_out
-            out["cpu_baseline"] = cpu_baseline(frames_np, wsp, wlg, gpu)
+            out["cpu_baseline"] = cpu_baseline(frames_np, wsp, wlg, gpu, tol=lg_tol)
             vf = (out["cpu_baseline"].get("verified_against_gpu") or {}).pop("fp16x2_variant", None)
             if vf is not None and variants is not None and "fp16x2" in variants:
                 variants["fp16x2"]["verified_against_oracle"] = vf
@@ -1075,6 +1159,9 @@ def main():
             out["invalid"] = "outputs of the timed loop differ from the CPU oracle beyond the stated tolerance (cpu_baseline.verified_against_gpu)"
             out["value_unverified"], out["value"] = out["value"], None
             bad_exit = 4
+        if aux_mismatch:
+            out["invalid_aux"] = aux_mismatch
+            bad_exit = bad_exit or 5
         print(json.dumps(out), flush=True)
     ctx.close()
     if pg:

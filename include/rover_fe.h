@@ -79,8 +79,10 @@ uint64_t rfe_weights_id(rfe_ctx* ctx, int kind);
  * radius and the border width are baked into onnxmodel/superpoint.onnx at export time (src/Extractors/SPextractor.cc:92-94),
  * and the matcher reads whatever matches0 / mscores0 hold (src/Matchers/lightglue_onnx.cpp:404-409) because depth, heads and the
  * in-graph filter threshold are baked into onnxmodel/lightglue_sim.onnx (lightglue_onnx.cpp:38).  rover-slam_amd/onnx_weights.py
- * reads them from the graphs and writes them into the RFEW v2 header; rfe_load_weights applies them to the ctx.  Version-1 files
- * and rfe_set_weights (bare blobs) leave the defaults below.
+ * reads them from the graphs and writes them into the RFEW v2 header; rfe_load_weights applies them to the ctx.  Hyper-parameters belong
+ * to a weight set: version-1 files and rfe_set_weights (bare blobs) carry none and RESET the loaded kind's values to the defaults below
+ * (so a v2 load followed by rfe_set_weights does not keep the earlier file's radius / border / top-k rule); call rfe_set_hparams AFTER
+ * the weights to state other values.
  *   sp_max_keypoints / sp_detection_threshold / lg_filter_threshold are what a drop-in caller passes as Kmax / thr / filter_thr
  *     (the C++ shims do exactly that); the entry points themselves keep taking them as arguments.
  *   sp_nms_radius (1..8) and sp_remove_borders (0..64) act inside rfe_extract_* (simple_nms window 2r+1, border set to -1).
@@ -133,6 +135,8 @@ int rfe_set_stream(rfe_ctx* ctx, void* hip_stream); /* NULL -> ctx's own stream 
 int rfe_synchronize(rfe_ctx* ctx);
 int rfe_malloc(rfe_ctx* ctx, size_t bytes, void** dev_ptr);
 int rfe_free(rfe_ctx* ctx, void* dev_ptr);
+/* bytes of device workspace the ctx holds right now (grow-only: the high-water mark of every call so far; weights not included) */
+int64_t rfe_workspace_bytes(rfe_ctx* ctx);
 int rfe_memcpy_h2d(rfe_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int rfe_memcpy_d2h(rfe_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 
@@ -350,6 +354,10 @@ int rfe_k_attention(rfe_ctx* ctx, const float* q_dev, const float* k_dev, const 
  * pair's keypoint counts are padding) and its log-assignment matrix to scores_dev ([L,L], row stride L; only the m x n block is
  * written).  Any pointer may be NULL; pair < 0 disarms.  A pair index >= P of the next forward is ignored. */
 int rfe_k_set_lightglue_tap(rfe_ctx* ctx, int pair, float* x0_dev, float* x1_dev, float* scores_dev);
+/* Fault injection for the pool's RCCL gather: the NEXT gather of `member` fails inside its ncclGroup (as a refused ncclSend would).  The
+ * failing member aborts every member's communicator, nobody is left waiting in a collective, and the call delivers its results through
+ * the COPY transport (RFE_POOL_AUTO) or reports the failure (RFE_POOL_RCCL); later calls use COPY.  tests/test_pool.py. */
+int rfe_k_pool_inject_gather_failure(rfe_pool* pool, int member);
 
 #ifdef __cplusplus
 }

@@ -406,7 +406,23 @@ extern "C" int rfe_set_weights(rfe_ctx* c, int kind, const float* blob, int64_t 
     RFE_HIP(c, hipSetDevice(c->device));
     if (count != rfe_weight_count(kind)) return fail(c, RFE_ERR_INVALID, "rfe_set_weights: wrong float count for this model kind");
     RFE_HIP(c, hipStreamSynchronize(c->stream));
-    return kind == RFE_KIND_SUPERPOINT ? set_sp(c, blob) : set_lg(c, blob);
+    const int rc = kind == RFE_KIND_SUPERPOINT ? set_sp(c, blob) : set_lg(c, blob);
+    if (rc == RFE_OK) {
+        // hyper-parameters belong to a weight set: a bare blob (and a version-1 file) carries none, so this kind's values go back to the published
+        // defaults -- a v2 load followed by rfe_set_weights must not keep the earlier file's radius / border / top-k rule silently (rover_fe.h)
+        const rfe_hparams d = rfe_default_hparams();
+        if (kind == RFE_KIND_SUPERPOINT) {
+            c->hp.sp_max_keypoints = d.sp_max_keypoints; c->hp.sp_detection_threshold = d.sp_detection_threshold; c->hp.sp_nms_radius = d.sp_nms_radius;
+            c->hp.sp_remove_borders = d.sp_remove_borders; c->hp.sp_topk_always = d.sp_topk_always;
+        } else {
+            c->hp.lg_layers = d.lg_layers; c->hp.lg_heads = d.lg_heads; c->hp.lg_filter_threshold = d.lg_filter_threshold;
+        }
+    }
+    return rc;
+}
+
+extern "C" int64_t rfe_workspace_bytes(rfe_ctx* c) {
+    return c ? (int64_t)(c->ws_sp_bytes + c->ws_lg_bytes + c->ws_io_bytes + c->ws_tmp_bytes + c->ws_st_bytes) : 0;
 }
 
 extern "C" uint64_t rfe_weights_id(rfe_ctx* c, int kind) {
@@ -461,8 +477,15 @@ static int load_rfew(rfe_ctx* c, const char* path, int want_kind) {
     size_t got = fread(blob.data(), sizeof(float), cnt, f);
     fclose(f);
     if (got != cnt) return fail(c, RFE_ERR_IO, std::string("short read on ") + path);
-    const int rc = rfe_set_weights(c, want_kind, blob.data(), (int64_t)cnt);
-    if (rc == RFE_OK) c->hp = hp;     // the file's hyper-parameters travel with its weights
+    const int rc = rfe_set_weights(c, want_kind, blob.data(), (int64_t)cnt);      // resets this kind's hyper-parameters to the defaults
+    if (rc == RFE_OK && ver == 2) {                                               // the file's hyper-parameters travel with its weights
+        if (want_kind == RFE_KIND_SUPERPOINT) {
+            c->hp.sp_max_keypoints = hp.sp_max_keypoints; c->hp.sp_detection_threshold = hp.sp_detection_threshold; c->hp.sp_nms_radius = hp.sp_nms_radius;
+            c->hp.sp_remove_borders = hp.sp_remove_borders; c->hp.sp_topk_always = hp.sp_topk_always;
+        } else {
+            c->hp.lg_layers = hp.lg_layers; c->hp.lg_heads = hp.lg_heads; c->hp.lg_filter_threshold = hp.lg_filter_threshold;
+        }
+    }
     return rc;
 }
 
@@ -1149,6 +1172,9 @@ extern "C" int rfe_stereo_frame_dev(rfe_ctx* c, const uint8_t* imgL, const uint8
       launch_stereo_match_counts(ss, d_img, d_img + (size_t)H * W, H, W, W, kxy, kxy + (size_t)Kmax * 2, Kmax, n, desc,
                                  desc + (size_t)Kmax * 256, mb, mbf, uRight, depth, sadv); }
     if (st_fork) RFE_HIP(c, hipEventRecord(c->ev_join, ss));
+    // every exit below -- the error returns of ensure_ws / lg_stage / lg_forward included -- joins the side stream first: the caller's NEXT call
+    // rewrites d_img / uRight / depth on the ctx stream, which must not overtake stereo kernels still reading or writing them
+    struct JoinGuard { rfe_ctx* c; hipStream_t s; bool on; ~JoinGuard() { if (on) (void)hipStreamWaitEvent(s, c->ev_join, 0); } } join_guard{c, s, st_fork};
     // temporal match exactly as Tracking issues it: SearchBySP(mCurrentFrame, mLastFrame) (src/Tracking.cc:3465) ->
     // MatchingPoints_onnx(CurrentFrame, LastFrame, vnMatches1) (src/Matchers/SPmatcher.cc:1050-1054): THIS left view is set 0,
     // the previous left view set 1, so pairs are (current index, previous index) like vnMatches1[IdxCF] = IdxLF; true image
@@ -1167,7 +1193,7 @@ extern "C" int rfe_stereo_frame_dev(rfe_ctx* c, const uint8_t* imgL, const uint8
     }
     { ProfScope ps(c, "lg_misc");   // this left view becomes the previous one
       hipLaunchKernelGGL(st_save_kernel, dim3((Kmax + 3) / 4), dim3(256), 0, s, kn_cur, desc, n, Kmax, kn_prev, desc_prev, n_prev); }
-    if (st_fork) RFE_HIP(c, hipStreamWaitEvent(s, c->ev_join, 0));   // uRight / depth are complete when the ctx stream is
+    if (st_fork) { join_guard.on = false; RFE_HIP(c, hipStreamWaitEvent(s, c->ev_join, 0)); }   // uRight / depth are complete when the ctx stream is
     c->st_have_prev = true;
     RFE_HIP(c, hipGetLastError());
     return RFE_OK;

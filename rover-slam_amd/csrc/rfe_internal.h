@@ -100,6 +100,9 @@ struct GemmArgs {
 
 }  // namespace rfe
 
+// the published LightGlue-style export settings (include/rover_fe.h: rfe_hparams defaults)
+inline rfe_hparams rfe_default_hparams() { return rfe_hparams{1024, 0.0005f, 4, 4, 0, rfe::LG_LAYERS, 4, 0.1f}; }
+
 struct rfe_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -110,7 +113,7 @@ struct rfe_ctx {
     bool has_sp = false, has_lg = false;
     bool opt_lg_fold = true;             // RFE_OPT_LG_FOLD_WO
     bool opt_lg_fp16x2 = false;          // RFE_OPT_LG_FP16X2
-    rfe_hparams hp = {1024, 0.0005f, 4, 4, 0, rfe::LG_LAYERS, 4, 0.1f};   // graph hyper-parameters (RFEW v2 header / rfe_set_hparams)
+    rfe_hparams hp = rfe_default_hparams();   // graph hyper-parameters (RFEW v2 header / rfe_set_hparams)
     rfe::SpWeightsDev sp;                // views into *sp_hold / *lg_hold
     rfe::LgWeightsDev lg;
     std::shared_ptr<void> sp_hold, lg_hold;   // device copies, shared by every ctx of the process that loaded the same blob on the same device

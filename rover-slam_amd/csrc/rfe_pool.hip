@@ -16,6 +16,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <thread>
+#include <shared_mutex>
 #include "rfe_internal.h"
 
 namespace {
@@ -86,6 +87,8 @@ struct rfe_pool {
     RcclApi api;
     bool rccl_up = false;
     std::atomic<bool> rccl_broken{false};                 // a member's gather failed: communicators are torn down, the pool continues on COPY
+    std::shared_mutex comm_mu;                            // shared: a member is posting its group (uses its comm handle); exclusive: every communicator is being aborted
+    std::atomic<int> inject_fail{-1};                     // test hook (rfe_k_pool_inject_gather_failure): this member's next gather fails inside its group
     std::string rccl_why;                                 // why the RCCL transport is unavailable
     void* root = nullptr; size_t root_bytes = 0;          // gathered results in global order on member 0's device
     // job hand-off to the persistent workers
@@ -164,40 +167,59 @@ static int run_member(rfe_pool* p, int r) {
         // matching operations and would wait for ever.  The first failure is recorded, the remaining operations of the group are
         // skipped, GroupEnd is ALWAYS called, and on any failure this member aborts its communicator (ncclCommAbort: the peers'
         // pending operations with it fail instead of hanging; the pool then falls back to the COPY transport, see rfe_pool_extract_match_stream).
-        ncclResult_t first = p->api.GroupStart();
+        // A PARTIAL failure must not strand the healthy members either: they have closed their groups and sit in hipStreamSynchronize on
+        // transfer kernels that wait for the failed peer, and the main thread waits for them before it looks at rccl_broken.  So the failing
+        // member aborts EVERY member's communicator (exclusive comm_mu: no peer is between GroupStart and GroupEnd, i.e. nobody is using
+        // a handle); the peers' kernels then end, their synchronisations return, and the call falls back to COPY.
+        ncclResult_t first = ncclSuccess;
         const char* where = "ncclGroupStart";
-        const bool opened = first == ncclSuccess;
-        auto rows_of = [&](int q, int i, int* first_row) {   // rows of array i that member q contributes, and where they start globally
-            int fq, frq, oq;
-            rfe_pool_shard(j.F, n, q, &fq, &frq, &oq);
-            *first_row = fq;
-            if (f[i].per_pair) return oq;
-            int last = -1;                                   // the last member with frames also contributes its overlap frame
-            for (int t = 0; t < n; ++t) { int a, b, c; rfe_pool_shard(j.F, n, t, &a, &b, &c); if (b > 0) last = t; }
-            return frq == 0 ? 0 : (q == last ? frq : oq);
-        };
-        for (int i = 0; i < F_COUNT && first == ncclSuccess; ++i) {
-            if ((i == F_SCORE && !j.with_score) || (i == F_DESC && !j.with_desc)) continue;
-            int fr;
-            const int rows = rows_of(r, i, &fr);
-            if (rows > 0 && (first = p->api.Send((char*)mb.pack + off[i], (size_t)rows * f[i].row, ncclUint8, 0, mb.comm, s)) != ncclSuccess) { where = "ncclSend"; break; }
-            if (r == 0)
-                for (int q = 0; q < n && first == ncclSuccess; ++q) {
-                    int fq;
-                    const int rq = rows_of(q, i, &fq);
-                    if (rq > 0 && (first = p->api.Recv((char*)p->root + goff[i] + (size_t)fq * f[i].row, (size_t)rq * f[i].row, ncclUint8, q, mb.comm, s)) != ncclSuccess) where = "ncclRecv";
-                }
-        }
-        if (opened) {
-            const ncclResult_t e = p->api.GroupEnd();
-            if (first == ncclSuccess && e != ncclSuccess) { first = e; where = "ncclGroupEnd"; }
+        {
+            std::shared_lock<std::shared_mutex> posting(p->comm_mu);
+            if (!mb.comm) { mb.err = "communicator aborted by a failing peer"; return RFE_ERR_HIP; }
+            first = p->api.GroupStart();
+            const bool opened = first == ncclSuccess;
+            auto rows_of = [&](int q, int i, int* first_row) {   // rows of array i that member q contributes, and where they start globally
+                int fq, frq, oq;
+                rfe_pool_shard(j.F, n, q, &fq, &frq, &oq);
+                *first_row = fq;
+                if (f[i].per_pair) return oq;
+                int last = -1;                                   // the last member with frames also contributes its overlap frame
+                for (int t = 0; t < n; ++t) { int a, b, c; rfe_pool_shard(j.F, n, t, &a, &b, &c); if (b > 0) last = t; }
+                return frq == 0 ? 0 : (q == last ? frq : oq);
+            };
+            if (opened && p->inject_fail.load() == r) { p->inject_fail.store(-1); first = ncclInternalError; where = "ncclSend (injected by rfe_k_pool_inject_gather_failure)"; }
+            for (int i = 0; i < F_COUNT && first == ncclSuccess; ++i) {
+                if ((i == F_SCORE && !j.with_score) || (i == F_DESC && !j.with_desc)) continue;
+                int fr;
+                const int rows = rows_of(r, i, &fr);
+                if (rows > 0 && (first = p->api.Send((char*)mb.pack + off[i], (size_t)rows * f[i].row, ncclUint8, 0, mb.comm, s)) != ncclSuccess) { where = "ncclSend"; break; }
+                if (r == 0)
+                    for (int q = 0; q < n && first == ncclSuccess; ++q) {
+                        int fq;
+                        const int rq = rows_of(q, i, &fq);
+                        if (rq > 0 && (first = p->api.Recv((char*)p->root + goff[i] + (size_t)fq * f[i].row, (size_t)rq * f[i].row, ncclUint8, q, mb.comm, s)) != ncclSuccess) where = "ncclRecv";
+                    }
+            }
+            if (opened) {
+                const ncclResult_t e = p->api.GroupEnd();
+                if (first == ncclSuccess && e != ncclSuccess) { first = e; where = "ncclGroupEnd"; }
+            }
         }
         if (first != ncclSuccess) {
             mb.err = std::string(where) + ": " + p->api.GetErrorString(first);
-            if (p->api.CommAbort && mb.comm) { (void)p->api.CommAbort(mb.comm); mb.comm = nullptr; }
             p->rccl_broken.store(true);
+            std::unique_lock<std::shared_mutex> all(p->comm_mu);
+            for (auto& q : p->m)
+                if (q.comm) { (void)hipSetDevice(q.device); (void)(p->api.CommAbort ? p->api.CommAbort(q.comm) : p->api.CommDestroy(q.comm)); q.comm = nullptr; }
+            (void)hipSetDevice(mb.device);
             return RFE_ERR_HIP;
         }
+        if (hipStreamSynchronize(s) != hipSuccess || p->rccl_broken.load()) {   // a peer failed and aborted the communicators under this member's transfers
+            (void)hipGetLastError();
+            mb.err = "gather aborted by a failing peer";
+            return RFE_ERR_HIP;
+        }
+        return RFE_OK;
     }
     POOL_HIP(mb, hipStreamSynchronize(s));
     return RFE_OK;
@@ -274,6 +296,12 @@ extern "C" int rfe_pool_create(const int* devices, int n, rfe_pool** out) {
     }
     for (int r = 0; r < n; ++r) p->m[r].th = std::thread(worker, p, r);
     *out = p;
+    return RFE_OK;
+}
+
+extern "C" int rfe_k_pool_inject_gather_failure(rfe_pool* p, int member) {
+    if (!p || member < 0 || member >= (int)p->m.size()) return RFE_ERR_INVALID;
+    p->inject_fail.store(member);
     return RFE_OK;
 }
 

@@ -10,9 +10,11 @@
 // interface forces, and what the device-resident entry points (bench.py `latency.resident`) avoid.
 // usage: lat_driver <pair.u8: 2 x 480x640> <stereo.u8: T x 2 x 480x752> T steps warmup <out.bin>
 // weights via $RFE_SP_WEIGHTS / $RFE_LG_WEIGHTS; prints ONE JSON line; out.bin holds the last results for bench.py's oracle check.
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <thread>
 #include <vector>
 #include "Extractors/SPextractor.h"
@@ -27,6 +29,25 @@ struct MockFrame {                      // the members SPmatcher::MatchingPoints
 };
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// per-call samples -> {"mean": .., "p50": .., "p95": .., "p99": .., "min": .., "max": .., "first": ..} (ms): a Tracking thread sees single calls, not a mean
+struct Samples {
+    std::vector<double> v;
+    double t = 0;
+    void start() { t = now_ms(); }
+    void stop() { v.push_back(now_ms() - t); }
+    std::string json() const {
+        std::vector<double> s(v);
+        std::sort(s.begin(), s.end());
+        auto q = [&](double p) { return s.empty() ? 0.0 : s[std::min(s.size() - 1, (size_t)(p * (s.size() - 1) + 0.5))]; };
+        double sum = 0;
+        for (double x : s) sum += x;
+        char b[256];
+        snprintf(b, sizeof(b), "{\"mean\": %.4f, \"p50\": %.4f, \"p95\": %.4f, \"p99\": %.4f, \"min\": %.4f, \"max\": %.4f, \"first\": %.4f, \"calls\": %d}",
+                 s.empty() ? 0.0 : sum / s.size(), q(0.5), q(0.95), q(0.99), s.empty() ? 0.0 : s.front(), s.empty() ? 0.0 : s.back(), v.empty() ? 0.0 : v.front(), (int)s.size());
+        return b;
+    }
+    double mean() const { double sum = 0; for (double x : v) sum += x; return v.empty() ? 0.0 : sum / v.size(); }
+};
 static void put(FILE* f, const void* p, size_t n) { fwrite(p, 1, n, f); }
 static void put_frame(FILE* f, const std::vector<cv::KeyPoint>& k, const cv::Mat& d) {
     const int32_t n = (int32_t)k.size();
@@ -56,26 +77,43 @@ int main(int argc, char** argv) {
     MockFrame f0, f1;
     f0.imgLeft = cv::Mat(H, W, CV_8UC1, pair.data());
     f1.imgLeft = cv::Mat(H, W, CV_8UC1, pair.data() + (size_t)H * W);
-    double t0 = 0;
+    Samples q2, q2abi, q3, q3x, q3m, q5;
     for (int i = -warm; i < steps; ++i) {
-        if (i == 0) t0 = now_ms();
+        if (i >= 0) q2.start();
         f0.mvKeys.clear();
         extL(f0.imgLeft, f0.mvKeys, f0.mDescriptors);
+        if (i >= 0) q2.stop();
     }
-    const double c2 = (now_ms() - t0) / steps;
+    const double c2 = q2.mean();
+    // the C-ABI host entry alone on the same frame, caller-owned (reused) host buffers: c2 minus this = what the class shim adds per call
+    // (tensor set-up, int64 keypoints, std::vector<cv::KeyPoint>, the K x 256 cv::Mat); this minus latency.resident c2 = staging + PCIe + the final sync
+    {
+        rfe_ctx* cx = extL.featureExtractor->ExtractorSession;
+        const int K = extL.featureExtractor->max_keypoints;
+        std::vector<int32_t> kxy((size_t)K * 2);
+        std::vector<float> sc((size_t)K), de((size_t)K * 256);
+        int32_t nn = 0;
+        for (int i = -warm; i < steps; ++i) {
+            if (i >= 0) q2abi.start();
+            if (rfe_extract_u8(cx, pair.data(), H, W, W, 1, K, extL.featureExtractor->detection_threshold, &nn, kxy.data(), sc.data(), de.data()) != RFE_OK) return 6;
+            if (i >= 0) q2abi.stop();
+        }
+    }
 
     // ---- c3: a pair = two extractions + one LightGlue match (Frame overload: true image size)
     std::vector<int> vn;
     int s3 = 0;
     for (int i = -warm; i < steps; ++i) {
-        if (i == 0) t0 = now_ms();
+        if (i >= 0) { q3.start(); q3x.start(); }
         f0.mvKeys.clear(); f1.mvKeys.clear();
         extL(f0.imgLeft, f0.mvKeys, f0.mDescriptors);
         extL(f1.imgLeft, f1.mvKeys, f1.mDescriptors);
+        if (i >= 0) { q3x.stop(); q3m.start(); }
         vn.clear();                                           // callers hand over a fresh vector (resize(M, -1) keeps old entries, SPmatcher.cc:460)
         s3 = matcher.MatchingPoints_onnx(f0, f1, vn);
+        if (i >= 0) { q3m.stop(); q3.stop(); }
     }
-    const double c3 = (now_ms() - t0) / steps;
+    const double c3 = q3.mean();
 
     // ---- c5: stereo stream
     MockFrame cur, prev;
@@ -83,7 +121,7 @@ int main(int argc, char** argv) {
     int s5 = 0, last_t = 0;
     bool have_prev = false;
     for (int i = -warm; i < steps; ++i) {
-        if (i == 0) t0 = now_ms();
+        if (i >= 0) q5.start();
         const int t = ((i + warm) % T);
         cur.imgLeft = cv::Mat(Hs, Ws, CV_8UC1, stereo.data() + (size_t)(2 * t) * Hs * Ws);
         cur.imgRight = cv::Mat(Hs, Ws, CV_8UC1, stereo.data() + (size_t)(2 * t + 1) * Hs * Ws);
@@ -99,8 +137,9 @@ int main(int argc, char** argv) {
             have_prev = true;
         }
         last_t = t;
+        if (i >= 0) q5.stop();
     }
-    const double c5 = (now_ms() - t0) / steps;
+    const double c5 = q5.mean();
 
     FILE* fo = fopen(argv[6], "wb");
     if (!fo) return 4;
@@ -116,7 +155,9 @@ int main(int argc, char** argv) {
     put(fo, &s5, 4); put(fo, &m, 4); put(fo, vt.data(), (size_t)m * 4);
     fclose(fo);
     printf("{\"c2_ms\": %.4f, \"c3_ms\": %.4f, \"c5_ms\": %.4f, \"steps\": %d, \"warmup\": %d, \"c2_keypoints\": %d, \"c3_matches\": %d, "
-           "\"c5_left_keypoints\": %d, \"c5_temporal_matches\": %d}\n",
-           c2, c3, c5, steps, warm, (int)f0.mvKeys.size(), s3, (int)cur.mvKeys.size(), s5);
+           "\"c5_left_keypoints\": %d, \"c5_temporal_matches\": %d, \"per_call_ms\": {\"c2\": %s, \"c2_c_abi_only\": %s, \"c3\": %s, "
+           "\"c3_two_extractions\": %s, \"c3_match\": %s, \"c5\": %s}}\n",
+           c2, c3, c5, steps, warm, (int)f0.mvKeys.size(), s3, (int)cur.mvKeys.size(), s5,
+           q2.json().c_str(), q2abi.json().c_str(), q3.json().c_str(), q3x.json().c_str(), q3m.json().c_str(), q5.json().c_str());
     return 0;
 }

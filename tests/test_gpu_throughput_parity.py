@@ -235,7 +235,7 @@ def test_lightglue_batch16_fp16x2_vs_oracle(ctx, oracle):
 
 def test_lightglue_one_pair_fp16x2_vs_oracle(ctx, oracle):
     """RFE_OPT_LG_FP16X2 at the reference's own shape, ONE pair per call: the Linears run the split form of the latency tiles (gemm_lat.hip, H2: the
-    same ring / tile / epilogue, three v_mfma_f32_16x16x32_f16 per 32 k), the attention stays on the fp32 latency kernel.  Same bar as the fp32
+    same ring / tile / epilogue, three v_mfma_f32_16x16x32_f16 per 32 k), the attention runs the split form of lg_attention_lat.hip (launch_lg_attention passes the option on, as rover_fe.h says).  Same bar as the fp32
     path (match list by the borderline rule, scores within LG_SCORE_TOL, final token states), the option must really change the arithmetic, and a
     ragged pair must work as well."""
     from rover_slam_amd import capi

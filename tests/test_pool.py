@@ -248,3 +248,46 @@ def test_plain_c_host_runs_the_pool(tmp_path, wsets):
         pool.close()
     assert ref["S"].sum() > 0
     assert np.array_equal(got["n"], ref["n"]) and np.array_equal(got["kxy"], ref["kxy"]) and _same_matches(got, ref)
+
+
+@pytest.mark.gpu
+def test_pool_gather_failure_falls_back_to_copy(wsets):
+    """a member whose gather fails inside its ncclGroup aborts EVERY member's communicator, so that no healthy member is left in
+    hipStreamSynchronize on transfers that wait for the failed peer; the call then delivers through COPY (AUTO) or reports the failure (RCCL
+    requested) and later calls stay on COPY.  One member on a 1-GPU box; with >= 2 GPUs the partial failure (member 1 of 2) runs as well."""
+    import torch
+    from rover_slam_amd import capi
+    frames, _ = synth.make_frames(5, 160, 208, seed=5)
+    kmax = 256
+    ctx = capi.Context(0)
+    ctx.set_weights(capi.KIND_SUPERPOINT, wsets[0]); ctx.set_weights(capi.KIND_LIGHTGLUE, wsets[1])
+    ref = _single_ctx_stream(ctx, frames, kmax)
+    ctx.close()
+    layouts = [([0], 0)] + ([([0, 1], 1)] if torch.cuda.device_count() >= 2 else [])
+    for devices, victim in layouts:
+        pool = capi.Pool(devices)
+        try:
+            assert pool.has_rccl
+            pool.set_weights(capi.KIND_SUPERPOINT, wsets[0]); pool.set_weights(capi.KIND_LIGHTGLUE, wsets[1])
+            ok = pool.extract_match_stream(frames, kmax=kmax, transport=capi.POOL_RCCL)
+            assert capi.lib.rfe_k_pool_inject_gather_failure(pool.h, victim) == 0
+            with pytest.raises(capi.RfeError, match="injected"):
+                pool.extract_match_stream(frames, kmax=kmax, transport=capi.POOL_RCCL)      # explicit RCCL: the failure is reported, nothing hangs
+            assert not pool.has_rccl                                                         # communicators are gone for good
+            after = pool.extract_match_stream(frames, kmax=kmax)                             # AUTO -> COPY
+        finally:
+            pool.close()
+        for got in (ok, after):
+            for k in ("n", "kxy", "score", "desc"):
+                assert np.array_equal(got[k], ref[k]), k
+            assert _same_matches(got, ref)
+    # AUTO with more than one member takes RCCL by itself: the injected failure must be absorbed inside the call
+    if torch.cuda.device_count() >= 2:
+        pool = capi.Pool([0, 1])
+        try:
+            pool.set_weights(capi.KIND_SUPERPOINT, wsets[0]); pool.set_weights(capi.KIND_LIGHTGLUE, wsets[1])
+            capi.lib.rfe_k_pool_inject_gather_failure(pool.h, 1)
+            got = pool.extract_match_stream(frames, kmax=kmax)
+            assert not pool.has_rccl and _same_matches(got, ref)
+        finally:
+            pool.close()

@@ -17,6 +17,10 @@ i.e. any two fp32 evaluation orders of this graph differ by 1-3e-4 (the case wit
 one where the ORACLE sits 2.6e-4 from float64 and the HIP path 7e-5): 1e-4 is below the noise floor of fp32 itself at this
 size, and the fold does not change the picture.  Final token states agree to 1e-5 (bar 1e-4).
 """
+LG_SCORE_TOL_CALIBRATED = 1e-4   # north_star's figure, on the CALIBRATED weight set (weights.make_lightglue(calibrated=True): token norms O(1), log-assignment
+                            # peaks at 52-63 -- the range trained LightGlue logits live in).  Measured there: oracle vs torch modules vs graph execution
+                            # 5-7e-6, HIP vs oracle 1.3-1.5e-5 (profiles/r04_weight_scale.md rows ffn.3 x 0.25 / final_proj x 0.25).  Every bar below
+                            # is for the ILL-CONDITIONED seeded default set (log-assignment up to |850|, one fp32 ulp there = 6e-5 in the log domain).
 LG_SCORE_TOL = 5e-4         # |match score difference|, any keypoint count up to 1024
 LG_SCORE_TOL_SMALL = 2e-4   # <= 256 keypoints per side.  Round 4 (profiles/r04_lg_tolerance_k256.md, 20 cases at K <= 256): the ORACLE sits up to 1.19e-4
                             # from the float64 evaluation of the same graph, the HIP path 1.27e-4 from the oracle and 1.54e-4 from float64 (match lists
@@ -49,22 +53,23 @@ def _top2_gap(logscores):
     return float(np.exp(t[-1]) - np.exp(t[0])) if len(t) == 2 else float("inf")
 
 
-def borderline(sc, i, j, keypoints, filter_thr=0.1):
+def borderline(sc, i, j, keypoints, filter_thr=0.1, tol=None):
     """A match that only one side reports is legitimate when fp32 noise can produce it: match probabilities agree to
     tol = LG_SCORE_TOL_SMALL (<= 256 keypoints) / LG_SCORE_TOL, so the filter can flip within tol of its threshold and a
     row / column argmax can flip when the two best probabilities are closer than 2 tol (each moves by up to tol).
     sc: the reference's log-assignment matrix [M,N]."""
     import numpy as np
-    tol = LG_SCORE_TOL_SMALL if keypoints <= 256 else LG_SCORE_TOL
+    if tol is None:
+        tol = LG_SCORE_TOL_SMALL if keypoints <= 256 else LG_SCORE_TOL
     return abs(float(np.exp(sc[i, j])) - filter_thr) < tol or _top2_gap(sc[i]) < 2 * tol or _top2_gap(sc[:, j]) < 2 * tol
 
 
-def lists_agree_borderline(pairs_a, ms_a, pairs_b, ms_b, scores_ref, keypoints, filter_thr=0.1):
+def lists_agree_borderline(pairs_a, ms_a, pairs_b, ms_b, scores_ref, keypoints, filter_thr=0.1, tol=None):
     """Match lists equal up to borderline flips (see `borderline`).  Returns (ok, max |score difference| over the common
     matches, number of one-sided matches)."""
     da = {(int(i), int(j)): float(s) for (i, j), s in zip(pairs_a, ms_a)}
     db = {(int(i), int(j)): float(s) for (i, j), s in zip(pairs_b, ms_b)}
     only = da.keys() ^ db.keys()
-    ok = all(borderline(scores_ref, i, j, keypoints, filter_thr) for (i, j) in only)
+    ok = all(borderline(scores_ref, i, j, keypoints, filter_thr, tol) for (i, j) in only)
     dev = max((abs(da[k] - db[k]) for k in da.keys() & db.keys()), default=0.0)
     return ok, dev, len(only)
