@@ -125,6 +125,21 @@ def gpu_clocks(dev_index):
     return out or None
 
 
+def gpu_numa(dev_index):
+    """NUMA node and local CPU list of the GPU from sysfs (None when unreadable): which host cores sit next to the device"""
+    try:
+        cards = sorted(d for d in os.listdir("/sys/class/drm") if d.startswith("card") and d[4:].isdigit())
+        card = cards[dev_index] if dev_index < len(cards) else cards[0]
+        out = {}
+        for key in ("numa_node", "local_cpulist"):
+            with open(f"/sys/class/drm/{card}/device/{key}") as f:
+                out[key] = f.read().strip()
+        out["process_affinity_cpus"] = len(os.sched_getaffinity(0))
+        return out
+    except (OSError, IndexError):
+        return None
+
+
 def cpu_model():
     """CPU model string of the host (core count AND model next to the CPU baseline)."""
     try:
@@ -415,11 +430,15 @@ def latency_dropin(synth, wsp, wlg, pair_np, steps=50, warmup=5, check=True, tol
         np.ascontiguousarray(pair_np[:2]).tofile(os.path.join(d, "pair.u8"))
         np.stack([np.stack([l, r]) for l, r in zip(lefts, rights)]).tofile(os.path.join(d, "stereo.u8"))
         env = dict(os.environ, RFE_SP_WEIGHTS=os.path.join(d, "sp.rfew"), RFE_LG_WEIGHTS=os.path.join(d, "lg.rfew"))
+        numa = gpu_numa(0)
+        if numa and numa.get("local_cpulist") and "RFE_LAT_CPULIST" not in env and os.environ.get("RFE_LAT_NO_PIN") != "1":
+            env["RFE_LAT_CPULIST"] = numa["local_cpulist"]       # the driver runs on the CPUs local to the GPU (see lat_driver.cpp)
         r = subprocess.run([exe, os.path.join(d, "pair.u8"), os.path.join(d, "stereo.u8"), str(T), str(steps), str(warmup), os.path.join(d, "out.bin")],
                            env=env, capture_output=True, text=True, timeout=600)
         if r.returncode != 0:
             return {"error": f"lat_driver exit {r.returncode}: {(r.stdout + r.stderr)[-300:]}"}
         out = json.loads(r.stdout.strip().splitlines()[-1])
+        out["gpu_numa"] = numa
         buf = open(os.path.join(d, "out.bin"), "rb").read()
     out["driver"] = ("tests/cpp/lat_driver.cpp (child process): SPextractor::operator() / SPmatcher::MatchingPoints_onnx(Frame&, Frame&) / left + right "
                      "extractor threads + ComputeStereoMatches_rfe + MatchingPoints_onnx(current, previous); pageable host memory in and out on every call")

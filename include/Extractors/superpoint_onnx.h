@@ -19,6 +19,7 @@
 #include <iostream>
 #include <string>
 #include <utility>
+#include <mutex>
 #include <vector>
 #include "../rover_fe.h"
 #include "../rfe/cv_compat.h"
@@ -133,7 +134,9 @@ private:
         std::vector<rfe::Tensor> out;
         out.emplace_back(std::vector<int64_t>{1, K, 2}, sizeof(int64_t));
         out.emplace_back(std::vector<int64_t>{1, K}, sizeof(float));
-        out.emplace_back(std::vector<int64_t>{1, K, 256}, sizeof(float));
+        // the K x 256 descriptor tensor lives in a pooled PINNED block (rfe_host_malloc): rfe_extract_* DMAs the descriptors straight into it, and
+        // the block returns to the pool when the caller drops the tensor -- no 1 MB allocation and no 1 MB host copy per frame
+        out.emplace_back(std::vector<int64_t>{1, K, 256}, pool_->take((size_t)K * 256 * sizeof(float)));
         float* sc = out[1].GetTensorMutableData<float>();
         float* desc = out[2].GetTensorMutableData<float>();
         int32_t n = 0;
@@ -152,4 +155,31 @@ private:
         return EXIT_SUCCESS;
     }
     std::vector<int32_t> stage_kxy_;
+
+    // blocks of one size, handed out as shared_ptr whose deleter puts them back; the pool outlives the runner while tensors are in flight
+    struct PinnedPool : std::enable_shared_from_this<PinnedPool> {
+        std::mutex mu;
+        std::vector<std::pair<unsigned char*, size_t>> free_;
+        std::shared_ptr<unsigned char> take(size_t bytes) {
+            unsigned char* p = nullptr;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                for (size_t i = 0; i < free_.size(); ++i)
+                    if (free_[i].second == bytes) { p = free_[i].first; free_.erase(free_.begin() + i); break; }
+            }
+            if (!p) {
+                void* q = nullptr;
+                if (rfe_host_malloc(bytes, &q) != RFE_OK)        // no pinned memory left: an ordinary block (the library then stages and copies)
+                    return std::shared_ptr<unsigned char>(new unsigned char[bytes], std::default_delete<unsigned char[]>());
+                p = (unsigned char*)q;
+            }
+            std::shared_ptr<PinnedPool> self = shared_from_this();
+            return std::shared_ptr<unsigned char>(p, [self, bytes](unsigned char* b) {
+                std::lock_guard<std::mutex> lk(self->mu);
+                if (self->free_.size() < 8) self->free_.push_back({b, bytes}); else rfe_host_free(b);
+            });
+        }
+        ~PinnedPool() { for (auto& b : free_) rfe_host_free(b.first); }
+    };
+    std::shared_ptr<PinnedPool> pool_ = std::make_shared<PinnedPool>();
 };

@@ -19,6 +19,8 @@ public:
         for (auto d : shape_) n *= (size_t)d;
         buf_ = std::shared_ptr<unsigned char>(new unsigned char[n ? n : 1], std::default_delete<unsigned char[]>());
     }
+    // a tensor over a caller-provided buffer (the runner's pooled pinned blocks); `buf` keeps it alive
+    Tensor(std::vector<int64_t> shape, std::shared_ptr<unsigned char> buf) : shape_(std::move(shape)), buf_(std::move(buf)) {}
     TensorShapeInfo GetTensorTypeAndShapeInfo() const { return TensorShapeInfo{shape_}; }
     template <typename T> T* GetTensorMutableData() { return (T*)buf_.get(); }
     template <typename T> const T* GetTensorData() const { return (const T*)buf_.get(); }

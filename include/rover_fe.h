@@ -135,6 +135,12 @@ int rfe_set_stream(rfe_ctx* ctx, void* hip_stream); /* NULL -> ctx's own stream 
 int rfe_synchronize(rfe_ctx* ctx);
 int rfe_malloc(rfe_ctx* ctx, size_t bytes, void** dev_ptr);
 int rfe_free(rfe_ctx* ctx, void* dev_ptr);
+/* Pinned (page-locked, portable) host memory.  Optional: every host entry point takes ANY host pointer.  When the descriptor output of
+ * rfe_extract_u8 / rfe_extract_f32 / rfe_extract_u8_bin lies inside a block from rfe_host_malloc, the K x 256 floats are DMA'd straight into it
+ * (otherwise they are staged through the ctx's pinned block and copied on the host: ~1 MB per 1024-keypoint frame).  The C++ runner shim
+ * keeps its output tensors in such blocks.  Not tied to a ctx; rfe_host_free(NULL) is a no-op. */
+int rfe_host_malloc(size_t bytes, void** host_ptr);
+void rfe_host_free(void* host_ptr);
 /* bytes of device workspace the ctx holds right now (grow-only: the high-water mark of every call so far; weights not included) */
 int64_t rfe_workspace_bytes(rfe_ctx* ctx);
 int rfe_memcpy_h2d(rfe_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);

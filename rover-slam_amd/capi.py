@@ -16,7 +16,7 @@ OPT_LG_FP16X2 = 2   # LightGlue Linears + attention of batched calls as split pr
 
 EXPORTS = [
     "rfe_init", "rfe_destroy", "rfe_last_error", "rfe_version", "rfe_load_weights", "rfe_set_weights",
-    "rfe_weight_count", "rfe_weights_id", "rfe_get_hparams", "rfe_set_hparams", "rfe_set_option", "rfe_get_option", "rfe_set_stream", "rfe_synchronize", "rfe_malloc", "rfe_free", "rfe_workspace_bytes", "rfe_memcpy_h2d",
+    "rfe_weight_count", "rfe_weights_id", "rfe_get_hparams", "rfe_set_hparams", "rfe_set_option", "rfe_get_option", "rfe_set_stream", "rfe_synchronize", "rfe_malloc", "rfe_free", "rfe_host_malloc", "rfe_host_free", "rfe_workspace_bytes", "rfe_memcpy_h2d",
     "rfe_memcpy_d2h", "rfe_extract_u8", "rfe_extract_u8_dev", "rfe_extract_f32", "rfe_extract_f32_dev", "rfe_extract_u8_bin", "rfe_extract_u8_bin_dev", "rfe_match", "rfe_match_dev", "rfe_match_fused",
     "rfe_extract_match_stream_dev", "rfe_stereo_match", "rfe_stereo_match_dev", "rfe_stereo_frame_dev", "rfe_l2_distance_matrix", "rfe_binarize_descriptors",
     "rfe_search_candidates", "rfe_distinctive_descriptors",
@@ -120,6 +120,9 @@ lib.rfe_pool_ctx.argtypes = [C.c_void_p, C.c_int]
 lib.rfe_pool_ctx.restype = C.c_void_p
 lib.rfe_pool_has_rccl.argtypes = [C.c_void_p]
 lib.rfe_k_pool_inject_gather_failure.argtypes = [C.c_void_p, C.c_int]
+lib.rfe_host_malloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+lib.rfe_host_free.argtypes = [C.c_void_p]
+lib.rfe_host_free.restype = None
 lib.rfe_workspace_bytes.argtypes = [C.c_void_p]
 lib.rfe_workspace_bytes.restype = C.c_int64
 lib.rfe_pool_set_weights.argtypes = [C.c_void_p, C.c_int, _fp, C.c_int64]

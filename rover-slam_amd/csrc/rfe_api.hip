@@ -48,6 +48,17 @@ int ensure_pin(rfe_ctx* c, size_t need) {
     return RFE_OK;
 }
 
+// Host blocks handed out by rfe_host_malloc (pinned, portable): a host entry whose descriptor output lies inside one of them lets the DMA engine write
+// the K x 256 floats straight into the caller's memory instead of staging them through h_pin and copying 1 MB on the host afterwards.
+static std::mutex g_pin_mu;
+static std::vector<std::pair<char*, size_t>> g_pin_blocks;
+bool is_lib_pinned(const void* p, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (const auto& b : g_pin_blocks)
+        if ((const char*)p >= b.first && (const char*)p + bytes <= b.first + b.second) return true;
+    return false;
+}
+
 ProfScope::ProfScope(rfe_ctx* ctx, const char* name, hipStream_t on) : c(ctx), idx(-1), st(on ? on : ctx->stream) {
     if (!c->prof) return;
     if (!c->prof_filter.empty() && c->prof_filter != name) return;
@@ -421,6 +432,25 @@ extern "C" int rfe_set_weights(rfe_ctx* c, int kind, const float* blob, int64_t 
     return rc;
 }
 
+extern "C" int rfe_host_malloc(size_t bytes, void** out) {
+    if (!out || bytes == 0) return RFE_ERR_INVALID;
+    *out = nullptr;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return RFE_ERR_OOM; }
+    { std::lock_guard<std::mutex> lk(g_pin_mu); g_pin_blocks.push_back({(char*)p, bytes}); }
+    *out = p;
+    return RFE_OK;
+}
+extern "C" void rfe_host_free(void* p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        for (size_t i = 0; i < g_pin_blocks.size(); ++i)
+            if (g_pin_blocks[i].first == (char*)p) { g_pin_blocks.erase(g_pin_blocks.begin() + i); break; }
+    }
+    (void)hipHostFree(p);
+}
+
 extern "C" int64_t rfe_workspace_bytes(rfe_ctx* c) {
     return c ? (int64_t)(c->ws_sp_bytes + c->ws_lg_bytes + c->ws_io_bytes + c->ws_tmp_bytes + c->ws_st_bytes) : 0;
 }
@@ -697,12 +727,20 @@ extern "C" int rfe_extract_u8_bin(rfe_ctx* c, const uint8_t* img, int H, int W, 
     for (size_t r = 0; r < (size_t)B * H; ++r) memcpy(hp + r * W, img + r * stride, (size_t)W);
     RFE_HIP(c, hipMemcpyAsync(d_img, hp, (size_t)B * H * W, hipMemcpyHostToDevice, c->stream));
     if ((rc = sp_forward(c, d_img, H, W, W, B, Kmax, thr, d_n, d_k, d_s, d_d, d_b))) return rc;
-    RFE_HIP(c, hipMemcpyAsync(hp + ib, p + ib, nb + kb + sb + db + bb, hipMemcpyDeviceToHost, c->stream));   // [n | kxy | score | desc | bin] in one DMA
+    // descriptors in rfe_host_malloc'ed memory (the class shims' tensors are): the DMA engine writes them where the caller wants them
+    const bool direct = is_lib_pinned(desc, (size_t)B * Kmax * 1024);
+    if (direct) {
+        RFE_HIP(c, hipMemcpyAsync(hp + ib, p + ib, nb + kb + sb, hipMemcpyDeviceToHost, c->stream));           // [n | kxy | score]
+        RFE_HIP(c, hipMemcpyAsync(desc, d_d, (size_t)B * Kmax * 1024, hipMemcpyDeviceToHost, c->stream));
+        if (desc_bin) RFE_HIP(c, hipMemcpyAsync(hp + ib + nb + kb + sb + db, d_b, (size_t)B * Kmax * 256, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        RFE_HIP(c, hipMemcpyAsync(hp + ib, p + ib, nb + kb + sb + db + bb, hipMemcpyDeviceToHost, c->stream));   // [n | kxy | score | desc | bin] in one DMA
+    }
     RFE_HIP(c, hipStreamSynchronize(c->stream));
     memcpy(n, hp + ib, (size_t)B * 4);
     memcpy(kxy, hp + ib + nb, (size_t)B * Kmax * 8);
     memcpy(score, hp + ib + nb + kb, (size_t)B * Kmax * 4);
-    memcpy(desc, hp + ib + nb + kb + sb, (size_t)B * Kmax * 1024);
+    if (!direct) memcpy(desc, hp + ib + nb + kb + sb, (size_t)B * Kmax * 1024);
     if (desc_bin) memcpy(desc_bin, hp + ib + nb + kb + sb + db, (size_t)B * Kmax * 256);
     prof_collect(c);
     return RFE_OK;
@@ -736,12 +774,18 @@ extern "C" int rfe_extract_f32(rfe_ctx* c, const float* img, int H, int W, int s
     for (size_t r = 0; r < (size_t)B * H; ++r) memcpy(hp + r * W * 4, img + r * stride, (size_t)W * 4);
     RFE_HIP(c, hipMemcpyAsync(d_img, hp, (size_t)B * H * W * 4, hipMemcpyHostToDevice, c->stream));
     if ((rc = sp_forward(c, d_img, H, W, W, B, Kmax, thr, d_n, d_k, d_s, d_d, nullptr, true))) return rc;
-    RFE_HIP(c, hipMemcpyAsync(hp + ib, p + ib, nb + kb + sb + db, hipMemcpyDeviceToHost, c->stream));
+    const bool direct = is_lib_pinned(desc, (size_t)B * Kmax * 1024);
+    if (direct) {
+        RFE_HIP(c, hipMemcpyAsync(hp + ib, p + ib, nb + kb + sb, hipMemcpyDeviceToHost, c->stream));
+        RFE_HIP(c, hipMemcpyAsync(desc, d_d, (size_t)B * Kmax * 1024, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        RFE_HIP(c, hipMemcpyAsync(hp + ib, p + ib, nb + kb + sb + db, hipMemcpyDeviceToHost, c->stream));
+    }
     RFE_HIP(c, hipStreamSynchronize(c->stream));
     memcpy(n, hp + ib, (size_t)B * 4);
     memcpy(kxy, hp + ib + nb, (size_t)B * Kmax * 8);
     memcpy(score, hp + ib + nb + kb, (size_t)B * Kmax * 4);
-    memcpy(desc, hp + ib + nb + kb + sb, (size_t)B * Kmax * 1024);
+    if (!direct) memcpy(desc, hp + ib + nb + kb + sb, (size_t)B * Kmax * 1024);
     prof_collect(c);
     return RFE_OK;
 }
@@ -803,6 +847,12 @@ void lg_ffn(rfe_ctx* c, LgBuffers& b, float* x, const float* second, int rows, c
       a.A2 = second; a.lda2 = 256; a.K1 = 256;
       if (ln_fuse && !gemm_latency_regime(a)) a.stats_out = b.lnstat;   // latency regime: the stand-alone pass below (see lg_kernels.hip)
       P = launch_gemm_nt(s, a); }
+    if (P == 0 && !c->opt_lg_fp16x2) {
+        // one / few pairs per call: LayerNorm + GELU inside ffn.3 (ffn2_lat.hip: the 16 x 512 panel normalised once per workgroup) -- no stand-alone
+        // pass, no second round trip of h.  (The fp16x2 option keeps the split form of gemm_lat behind the stand-alone pass.)
+        ProfScope p(c, "lg_ffn2");
+        if (launch_ffn2_ln_lat(s, b.h, w2, b2, g, be, x, 256, x, 256, rows)) return;
+    }
     if (P == 0) { ProfScope p(c, "lg_ln_gelu"); launch_lg_ln_gelu(s, b.h, g, be, rows); }   // small problems (and RFE_LN_FUSE=0): stand-alone pass
     { ProfScope p(c, "lg_ffn2");
       GemmArgs a = gemm_lgw(c, b.h, 512, w2, 512, b2, x, 256, rows, 256, 512);

@@ -195,6 +195,9 @@ inline bool gemm_latency_regime(const GemmArgs& g) {
 }
 // gemm_lat.hip: false = shape not served (nothing launched).  rope_csn != null: rotary epilogue on output columns < rope_cols (qkv).
 bool launch_gemm_lat(hipStream_t s, const GemmArgs& g, const float* rope_csn, int rope_cols);
+// ffn2_lat.hip: ffn.3 of a one- / few-pair forward with LayerNorm(512) + GELU of its activation fused in (h = ffn.0's raw output); false = not served
+bool launch_ffn2_ln_lat(hipStream_t s, const float* h, const float* w2, const float* b2, const float* ln_g, const float* ln_b, const float* R, int ldr,
+                        float* C, int ldc, int M);
 // lg_attention_lat.hip: one-/few-pair attention without rotary (q, k rotated by the projection); false = shape not served.
 bool launch_lg_attention_lat(hipStream_t s, const float* q, const float* k, const float* v, int ld, float* out, int nseq, int Lq, int Lk,
                              const int* qlen, const int* klen, const int* kv_map, bool h2 = false /*RFE_OPT_LG_FP16X2: split products*/);

@@ -10,10 +10,12 @@
 // interface forces, and what the device-resident entry points (bench.py `latency.resident`) avoid.
 // usage: lat_driver <pair.u8: 2 x 480x640> <stereo.u8: T x 2 x 480x752> T steps warmup <out.bin>
 // weights via $RFE_SP_WEIGHTS / $RFE_LG_WEIGHTS; prints ONE JSON line; out.bin holds the last results for bench.py's oracle check.
+#include <sched.h>
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <thread>
 #include <vector>
@@ -56,8 +58,28 @@ static void put_frame(FILE* f, const std::vector<cv::KeyPoint>& k, const cv::Mat
     for (int r = 0; r < n; ++r) put(f, d.ptr<float>(r), 256 * 4);
 }
 
+// RFE_LAT_CPULIST ("0-15,64-79": the CPUs local to the GPU, /sys/class/drm/cardN/device/local_cpulist): run on those.  A Tracking thread on
+// the far NUMA node pays for every doorbell, completion signal and staging copy across the socket link; bench.py passes the list so that
+// the drop-in figures do not depend on where the scheduler happened to start this process (do the same in deployment).
+static std::string pin_to_cpulist(const char* list) {
+    if (!list || !*list) return "";
+    cpu_set_t set; CPU_ZERO(&set);
+    int count = 0;
+    for (const char* p = list; *p;) {
+        char* e; long a = strtol(p, &e, 10), b = a;
+        if (e == p) break;
+        if (*e == '-') { p = e + 1; b = strtol(p, &e, 10); }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) { CPU_SET((int)c, &set); ++count; }
+        p = (*e == ',') ? e + 1 : e;
+        if (*e && *e != ',') break;
+    }
+    if (count == 0 || sched_setaffinity(0, sizeof(set), &set) != 0) return "";
+    return list;
+}
+
 int main(int argc, char** argv) {
     if (argc < 7) { fprintf(stderr, "usage: lat_driver pair.u8 stereo.u8 T steps warmup out.bin\n"); return 2; }
+    const std::string pinned_to = pin_to_cpulist(getenv("RFE_LAT_CPULIST"));
     const int H = 480, W = 640, Hs = 480, Ws = 752;
     const int T = atoi(argv[3]), steps = atoi(argv[4]), warm = atoi(argv[5]);
     std::vector<unsigned char> pair((size_t)2 * H * W), stereo((size_t)T * 2 * Hs * Ws);
@@ -77,7 +99,7 @@ int main(int argc, char** argv) {
     MockFrame f0, f1;
     f0.imgLeft = cv::Mat(H, W, CV_8UC1, pair.data());
     f1.imgLeft = cv::Mat(H, W, CV_8UC1, pair.data() + (size_t)H * W);
-    Samples q2, q2abi, q3, q3x, q3m, q5;
+    Samples q2, q2abi, q2pin, q3, q3x, q3m, q5;
     for (int i = -warm; i < steps; ++i) {
         if (i >= 0) q2.start();
         f0.mvKeys.clear();
@@ -97,6 +119,16 @@ int main(int argc, char** argv) {
             if (i >= 0) q2abi.start();
             if (rfe_extract_u8(cx, pair.data(), H, W, W, 1, K, extL.featureExtractor->detection_threshold, &nn, kxy.data(), sc.data(), de.data()) != RFE_OK) return 6;
             if (i >= 0) q2abi.stop();
+        }
+        void* pd = nullptr;                                   // ... and with the descriptor output in rfe_host_malloc'ed memory (direct DMA, what the shim's tensors use)
+        if (rfe_host_malloc((size_t)K * 1024, &pd) == RFE_OK) {
+            for (int i = -warm; i < steps; ++i) {
+                if (i >= 0) q2pin.start();
+                if (rfe_extract_u8(cx, pair.data(), H, W, W, 1, K, extL.featureExtractor->detection_threshold, &nn, kxy.data(), sc.data(), (float*)pd) != RFE_OK) return 6;
+                if (i >= 0) q2pin.stop();
+            }
+            if (memcmp(pd, de.data(), (size_t)K * 1024) != 0) { fprintf(stderr, "pinned-output descriptors differ from the staged ones\n"); return 7; }
+            rfe_host_free(pd);
         }
     }
 
@@ -155,9 +187,9 @@ int main(int argc, char** argv) {
     put(fo, &s5, 4); put(fo, &m, 4); put(fo, vt.data(), (size_t)m * 4);
     fclose(fo);
     printf("{\"c2_ms\": %.4f, \"c3_ms\": %.4f, \"c5_ms\": %.4f, \"steps\": %d, \"warmup\": %d, \"c2_keypoints\": %d, \"c3_matches\": %d, "
-           "\"c5_left_keypoints\": %d, \"c5_temporal_matches\": %d, \"per_call_ms\": {\"c2\": %s, \"c2_c_abi_only\": %s, \"c3\": %s, "
+           "\"c5_left_keypoints\": %d, \"c5_temporal_matches\": %d, \"cpu_affinity\": \"%s\", \"per_call_ms\": {\"c2\": %s, \"c2_c_abi_only\": %s, \"c2_c_abi_pinned_desc\": %s, \"c3\": %s, "
            "\"c3_two_extractions\": %s, \"c3_match\": %s, \"c5\": %s}}\n",
            c2, c3, c5, steps, warm, (int)f0.mvKeys.size(), s3, (int)cur.mvKeys.size(), s5,
-           q2.json().c_str(), q2abi.json().c_str(), q3.json().c_str(), q3x.json().c_str(), q3m.json().c_str(), q5.json().c_str());
+           pinned_to.c_str(), q2.json().c_str(), q2abi.json().c_str(), q2pin.json().c_str(), q3.json().c_str(), q3x.json().c_str(), q3m.json().c_str(), q5.json().c_str());
     return 0;
 }
