@@ -76,6 +76,10 @@ __global__ __launch_bounds__(64 * F2_NW, 1) void ffn2_ln_lat_kernel(const float*
     // accumulator starts at the bias (D layout: lane (r, q) holds columns n = 4 q .. + 3 of the wave's 16, row m = r)
     const int ncol = n0 + wave * 16 + 4 * q;
     f32x4 acc = *reinterpret_cast<const f32x4*>(bias + ncol);
+    // ... and at the residual (requested here, consumed in the epilogue: its round trip hides under the K loop; in place on x, every lane
+    // reads and later writes only its own four floats)
+    const int mres = m0 + r < M ? m0 + r : M - 1;
+    acc += *reinterpret_cast<const f32x4*>(R + (size_t)mres * ldr + ncol);
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- weight ring.  Group G = 4 consecutive rows; wave w issues groups w, w + 8, ...; lane l fills row 4 G + (l >> 4), physical slot l & 15
@@ -147,12 +151,9 @@ __global__ __launch_bounds__(64 * F2_NW, 1) void ffn2_ln_lat_kernel(const float*
             for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[kg][e], b4[kg][e], acc, 0, 0, 0);
     }
 
-    // ---- epilogue: residual + store, one 16-byte access each
+    // ---- epilogue: one 16-byte store (bias and residual went into the accumulator's start value)
     const int m = m0 + r;
-    if (m < M) {
-        const f32x4 rv = *reinterpret_cast<const f32x4*>(R + (size_t)m * ldr + ncol);
-        *reinterpret_cast<f32x4*>(C + (size_t)m * ldc + ncol) = rv + acc;
-    }
+    if (m < M) *reinterpret_cast<f32x4*>(C + (size_t)m * ldc + ncol) = acc;
 }
 
 // Serves: ffn.3 of a one- / few-pair forward (K = 512, N = 256, residual, LayerNorm parameters, at most 8192 rows).  h is the RAW output of

@@ -581,16 +581,46 @@ __global__ __launch_bounds__(256) void lg_rowlse_kernel(const float* __restrict_
     if (lane == 0) rowlse[(size_t)p * L + i] = mx + logf(s);
 }
 
+// few-pair shapes: the matchability head of BOTH sides rides in the row log-sum-exp launch (blockIdx.z = 0: row i of the similarity matrix and
+// token i of side 0; blockIdx.z = 1: token i of side 1) -- one 4.6 us launch fewer per forward; the arithmetic is the two kernels', wave for wave
+__global__ __launch_bounds__(256) void lg_rowlse_z_kernel(const float* __restrict__ sim, int L, int P, const int* __restrict__ m, const int* __restrict__ n,
+                                                          float* __restrict__ rowlse, const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ b, float* __restrict__ z) {
+    const int p = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, side = blockIdx.z;
+    if (i >= L) return;
+    {   // matchability of token (side, p, i): every row of the padded layout, like lg_matchability_kernel
+        const size_t row = ((size_t)side * P + p) * L + i;
+        const float4 a = reinterpret_cast<const float4*>(x + row * 256)[lane];
+        const float4 ww = reinterpret_cast<const float4*>(w)[lane];
+        float s = fmaf(a.w, ww.w, fmaf(a.z, ww.z, fmaf(a.y, ww.y, a.x * ww.x)));
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) z[row] = logsigmoid_(s + b[0]);
+    }
+    if (side || i >= m[p]) return;
+    const int nn = n[p];
+    const float* r = sim + ((size_t)p * L + i) * L;
+    float mx = -INFINITY;
+    for (int jj = lane; jj < nn; jj += 64) mx = fmaxf(mx, r[jj]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float s = 0.f;
+    for (int jj = lane; jj < nn; jj += 64) s += expf(r[jj] - mx);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) rowlse[(size_t)p * L + i] = mx + logf(s);
+}
+
 __device__ __forceinline__ float lg_score(float sv, float lr, float lc, float l0, float l1) {
     return ((sv - lr) + (sv - lc)) + (l0 + l1);
 }
 
 // row argmax (first maximum) + optional dump of the score matrix: one wave per row
-__global__ __launch_bounds__(256) void lg_rowarg_kernel(const float* __restrict__ sim, const float* __restrict__ z0,
-                                                        const float* __restrict__ z1, const float* __restrict__ rowlse,
-                                                        const float* __restrict__ collse, int L, const int* __restrict__ m,
-                                                        const int* __restrict__ n, int32_t* __restrict__ a0,
-                                                        float* __restrict__ mx0, float* __restrict__ scores_opt, int scores_pair) {
+__device__ __forceinline__ void lg_rowarg_row(const float* __restrict__ sim, const float* __restrict__ z0,
+                                              const float* __restrict__ z1, const float* __restrict__ rowlse,
+                                              const float* __restrict__ collse, int L, const int* __restrict__ m,
+                                              const int* __restrict__ n, int32_t* __restrict__ a0,
+                                              float* __restrict__ mx0, float* __restrict__ scores_opt, int scores_pair) {
     const int p = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= m[p]) return;
     const int nn = n[p];
@@ -610,6 +640,13 @@ __global__ __launch_bounds__(256) void lg_rowarg_kernel(const float* __restrict_
         if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
     if (lane == 0) { a0[(size_t)p * L + i] = bi == 0x7fffffff ? 0 : bi; mx0[(size_t)p * L + i] = best; }
+}
+__global__ __launch_bounds__(256) void lg_rowarg_kernel(const float* __restrict__ sim, const float* __restrict__ z0,
+                                                        const float* __restrict__ z1, const float* __restrict__ rowlse,
+                                                        const float* __restrict__ collse, int L, const int* __restrict__ m,
+                                                        const int* __restrict__ n, int32_t* __restrict__ a0,
+                                                        float* __restrict__ mx0, float* __restrict__ scores_opt, int scores_pair) {
+    lg_rowarg_row(sim, z0, z1, rowlse, collse, L, m, n, a0, mx0, scores_opt, scores_pair);
 }
 
 // Column pass, fused: column log-sum-exp AND column argmax (first maximum) of the score matrix in one launch -- a workgroup owns a
@@ -737,13 +774,12 @@ __global__ __launch_bounds__(1024) void lg_col_lds_kernel(const float* __restric
 }
 
 // mutual check + exp + threshold + ordered compaction: one workgroup per pair
-__global__ __launch_bounds__(256) void lg_mutual_kernel(const int32_t* __restrict__ a0, const float* __restrict__ mx0,
-                                                        const int32_t* __restrict__ a1, int L, int cap,
-                                                        const int* __restrict__ m, const int* __restrict__ n, float thr,
-                                                        int32_t* __restrict__ S, int32_t* __restrict__ pairs,
-                                                        float* __restrict__ ms) {
-    __shared__ int wave_tot[4];
-    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+__device__ __forceinline__ void lg_mutual_body(int p, int* wave_tot, const int32_t* __restrict__ a0, const float* __restrict__ mx0,
+                                               const int32_t* __restrict__ a1, int L, int cap,
+                                               const int* __restrict__ m, const int* __restrict__ n, float thr,
+                                               int32_t* __restrict__ S, int32_t* __restrict__ pairs,
+                                               float* __restrict__ ms) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int mm = m[p], nn = n[p];
     int count = 0;
     for (int base = 0; base < mm; base += 256) {
@@ -772,9 +808,59 @@ __global__ __launch_bounds__(256) void lg_mutual_kernel(const int32_t* __restric
     if (tid == 0) S[p] = count < cap ? count : cap;
 }
 
+__global__ __launch_bounds__(256) void lg_mutual_kernel(const int32_t* __restrict__ a0, const float* __restrict__ mx0,
+                                                        const int32_t* __restrict__ a1, int L, int cap,
+                                                        const int* __restrict__ m, const int* __restrict__ n, float thr,
+                                                        int32_t* __restrict__ S, int32_t* __restrict__ pairs,
+                                                        float* __restrict__ ms) {
+    __shared__ int wave_tot[4];
+    lg_mutual_body(blockIdx.x, wave_tot, a0, mx0, a1, L, cap, m, n, thr, S, pairs, ms);
+}
+
+// few-pair shapes: row argmax AND the mutual / compaction step in one launch.  Every workgroup of a pair takes a ticket when its four rows are
+// written (release fence + atomic); the one that draws the last ticket sees all rows of the pair (acquire fence) and runs the mutual step,
+// then clears the ticket for the next call.  No workgroup ever waits for another.
+__global__ __launch_bounds__(256) void lg_rowarg_mutual_kernel(const float* __restrict__ sim, const float* __restrict__ z0,
+                                                               const float* __restrict__ z1, const float* __restrict__ rowlse,
+                                                               const float* __restrict__ collse, int L, const int* __restrict__ m,
+                                                               const int* __restrict__ n, int32_t* __restrict__ a0,
+                                                               float* __restrict__ mx0, float* __restrict__ scores_opt, int scores_pair,
+                                                               const int32_t* __restrict__ a1, int cap, float thr, int32_t* __restrict__ S,
+                                                               int32_t* __restrict__ pairs, float* __restrict__ ms, int32_t* __restrict__ ticket) {
+    __shared__ int wave_tot[4];
+    __shared__ int last;
+    const int p = blockIdx.y;
+    lg_rowarg_row(sim, z0, z1, rowlse, collse, L, m, n, a0, mx0, scores_opt, scores_pair);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = atomicAdd(&ticket[p], 1);
+        last = t == (int)gridDim.x - 1;
+        if (last) ticket[p] = 0;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    lg_mutual_body(p, wave_tot, a0, mx0, a1, L, cap, m, n, thr, S, pairs, ms);
+}
+
+// few-pair shapes (one to four pairs per call, the reference's own): matchability + row log-sum-exp in one launch, row argmax + mutual step in one
+// launch -- 3 launches instead of 5 (launch_lg_matchability is then NOT called by lg_forward)
+bool lg_assign_few_pairs(int P, int L) {
+    static const bool on = tune_int("RFE_LG_ASSIGN_MERGE", 1) != 0;   // tuning build: 0 = the five separate launches
+    return on && (long long)P * ((L + 31) / 32) < 128;
+}
 void launch_lg_assign(hipStream_t s, const float* sim, const float* z0, const float* z1, int P, int L, int cap,
                       const int* m, const int* n, float thr, float* scores_opt, float* rowlse, float* collse,
-                      int32_t* a0, float* mx0, int32_t* a1, int32_t* S, int32_t* pairs, float* ms, int scores_pair) {
+                      int32_t* a0, float* mx0, int32_t* a1, int32_t* S, int32_t* pairs, float* ms, int scores_pair,
+                      const float* x, const float* wm, const float* bm, float* z, int32_t* ticket) {
+    if (lg_assign_few_pairs(P, L) && x && ticket) {
+        hipLaunchKernelGGL(lg_rowlse_z_kernel, dim3((L + 3) / 4, P, 2), dim3(256), 0, s, sim, L, P, m, n, rowlse, x, wm, bm, z);
+        hipLaunchKernelGGL((lg_col_kernel<16, 64>), dim3((L + 15) / 16, P), dim3(1024), 0, s, sim, z0, z1, rowlse, L, m, n, collse, a1);
+        hipLaunchKernelGGL(lg_rowarg_mutual_kernel, dim3((L + 3) / 4, P), dim3(256), 0, s, sim, z0, z1, rowlse, collse, L, m, n, a0, mx0, scores_opt, scores_pair,
+                           a1, cap, thr, S, pairs, ms, ticket);
+        return;
+    }
     hipLaunchKernelGGL(lg_rowlse_kernel, dim3((L + 3) / 4, P), dim3(256), 0, s, sim, L, m, n, rowlse);
     static const bool col_lds = tune_int("RFE_LG_COL_LDS", 1) != 0;   // tuning switch: 0 = the three-walk kernel for every shape
     if (col_lds && L <= 1024 && L % 32 == 0 && (long long)P * (L / 32) >= 256)   // throughput shape: stripe resident in LDS, read from HBM once
@@ -809,6 +895,42 @@ __global__ void normalize_kpts_kernel(const int32_t* __restrict__ kxy, int64_t n
 void launch_normalize_kpts(hipStream_t s, const int32_t* kxy, int64_t n, int rows, int cols, float* out) {
     const float sx = (float)cols / 2, sy = (float)rows / 2, scale = (float)(rows > cols ? rows : cols) / 2;
     hipLaunchKernelGGL(normalize_kpts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, kxy, n, sx, sy, scale, out);
+}
+
+// ---------------------------------------------------------------- one-launch prologue of the stream mode (round 5: it replaced normalize_kpts +
+// lg_posenc + copy_f32 + lg_setup, four 4-5 us launches in front of every one-pair forward).  One wave per token row of the B frames:
+// NormalizeKeypoints (reference src/Matchers/transform.cpp:19-32) of the integer pixel keypoint -> kn, its rotary table row (the arithmetic of
+// lg_posenc_kernel, operand for operand) -> csn, its descriptor -> x; workgroup 0 also clamps the lengths, writes the cross-attention map and
+// clears the assignment's tickets.  Requires L == Kmax (the caller's dedup path).
+__global__ __launch_bounds__(256) void lg_frame_prologue_kernel(const int32_t* __restrict__ kxy, const float* __restrict__ desc, const float* __restrict__ wr,
+                                                                const int32_t* __restrict__ nkp, int B, int L, float sx, float sy, float scale,
+                                                                float* __restrict__ kn, float2* __restrict__ csn, float* __restrict__ x,
+                                                                int32_t* __restrict__ lens, int32_t* __restrict__ kvmap, int32_t* __restrict__ ticket) {
+    const int P = B - 1;
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < 2 * P; i += 256) {
+            int v = i < P ? nkp[i] : nkp[i - P + 1];
+            v = v < 0 ? 0 : (v > L ? L : v);
+            lens[i] = v;
+            kvmap[i] = i < P ? i + P : i - P;
+            if (i < P) ticket[i] = 0;
+        }
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (int64_t)B * L) return;
+    const int lane = threadIdx.x & 63;
+    reinterpret_cast<float4*>(x + row * 256)[lane] = reinterpret_cast<const float4*>(desc + row * 256)[lane];
+    const float kx = ((float)kxy[2 * row] - sx) / scale, ky = ((float)kxy[2 * row + 1] - sy) / scale;
+    if (lane == 0) reinterpret_cast<float2*>(kn)[row] = make_float2(kx, ky);
+    if (lane < 32) {
+        const float th = fmaf(wr[2 * lane + 1], ky, wr[2 * lane] * kx);
+        csn[row * 32 + lane] = make_float2(cosf(th), sinf(th));
+    }
+}
+void launch_lg_frame_prologue(hipStream_t s, const int32_t* kxy, const float* desc, const float* wr, const int32_t* nkp, int B, int L, int rows, int cols,
+                              float* kn, float* csn, float* x, int32_t* lens, int32_t* kvmap, int32_t* ticket) {
+    const float sx = (float)cols / 2, sy = (float)rows / 2, scale = (float)(rows > cols ? rows : cols) / 2;
+    hipLaunchKernelGGL(lg_frame_prologue_kernel, dim3((unsigned)(((int64_t)B * L + 3) / 4)), dim3(256), 0, s, kxy, desc, wr, nkp, B, L, sx, sy, scale, kn,
+                       reinterpret_cast<float2*>(csn), x, lens, kvmap, ticket);
 }
 
 }  // namespace rfe

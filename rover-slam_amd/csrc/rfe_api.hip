@@ -797,7 +797,7 @@ namespace {
 
 struct LgBuffers {
     float *x, *kn, *csn, *lnstat, *qkv, *ctx, *msg, *h, *md, *z, *sim, *rowlse, *collse, *mx0, *apart;
-    int32_t *a0, *a1, *lens, *kvmap;
+    int32_t *a0, *a1, *lens, *kvmap, *ticket;
     char* extra;   // caller-sized scratch region carved after the fixed buffers
 };
 
@@ -808,7 +808,7 @@ size_t lg_ws_bytes(int P, int L, size_t extra_bytes = 0) {
     t += al(rows * 2 * 4) + al(rows * 64 * 4) + al(rows * 32 * 4) + al(rows * 768 * 4) + al(rows * 512 * 4) + al(rows * 4);
     t += al((size_t)P * L * L * 4);
     t += al((size_t)P * L * 4) * 5;
-    t += al((size_t)2 * P * 4) * 2;
+    t += al((size_t)2 * P * 4) * 3;
     t += al(lg_attention_part_bytes(2 * P, L));
     return t + al(extra_bytes) + 4096;
 }
@@ -823,6 +823,7 @@ void lg_carve(void* ws, int P, int L, LgBuffers& b, size_t extra_bytes = 0) {
     b.rowlse = a.take<float>((size_t)P * L); b.collse = a.take<float>((size_t)P * L); b.mx0 = a.take<float>((size_t)P * L);
     b.a0 = a.take<int32_t>((size_t)P * L); b.a1 = a.take<int32_t>((size_t)P * L);
     b.lens = a.take<int32_t>((size_t)2 * P); b.kvmap = a.take<int32_t>((size_t)2 * P);
+    b.ticket = a.take<int32_t>((size_t)2 * P);   // per pair: workgroups of the merged row-argmax / mutual launch that have finished (cleared by every staging kernel)
     { const size_t pb = lg_attention_part_bytes(2 * P, L); b.apart = pb ? a.take<float>(pb / 4) : nullptr; }
     b.extra = a.take<char>(extra_bytes);
 }
@@ -886,11 +887,11 @@ void lg_self_block(rfe_ctx* c, LgBuffers& b, const LgLayerDev& Lw, float* x, con
 // first_self_done: b.x already holds the output of layer 0's self block and b.csn the rotary table
 // (stream mode computes them once per FRAME instead of once per pair side).
 int lg_forward(rfe_ctx* c, LgBuffers& b, int P, int L, float thr, int cap, int32_t* S, int32_t* pairs, float* ms,
-               float* scores_opt, bool first_self_done = false) {
+               float* scores_opt, bool first_self_done = false, bool posenc_done = false) {
     hipStream_t s = c->stream;
     const LgWeightsDev& W = c->lg;
     const int rows = 2 * P * L, nseq = 2 * P;
-    if (!first_self_done) { ProfScope p(c, "lg_misc"); launch_lg_posenc(s, b.kn, W.wr, rows, b.csn); }
+    if (!first_self_done && !posenc_done) { ProfScope p(c, "lg_misc"); launch_lg_posenc(s, b.kn, W.wr, rows, b.csn); }
     for (int l = 0; l < LG_LAYERS; ++l) {
         const LgLayerDev& Lw = W.L[l];
         if (l > 0 || !first_self_done) lg_self_block(c, b, Lw, b.x, b.csn, b.lens, nseq, L);
@@ -921,25 +922,15 @@ int lg_forward(rfe_ctx* c, LgBuffers& b, int P, int L, float thr, int cap, int32
     int scores_pair = -1;
     if (tap && c->tap.scores && !scores_opt) { scores_opt = c->tap.scores; scores_pair = c->tap.pair; }
     { ProfScope p(c, "lg_assign");
-      launch_lg_matchability(s, b.x, W.wm, W.bm, rows, b.z);
+      if (!lg_assign_few_pairs(P, L)) launch_lg_matchability(s, b.x, W.wm, W.bm, rows, b.z);   // few pairs: inside the row log-sum-exp launch
       launch_lg_assign(s, b.sim, b.z, b.z + (size_t)P * L, P, L, cap, b.lens, b.lens + P, thr, scores_opt, b.rowlse,
-                       b.collse, b.a0, b.mx0, b.a1, S, pairs, ms, scores_pair); }
+                       b.collse, b.a0, b.mx0, b.a1, S, pairs, ms, scores_pair, b.x, W.wm, W.bm, b.z, b.ticket); }
     if (tap) {
         if (c->tap.x0) RFE_HIP(c, hipMemcpyAsync(c->tap.x0, b.x + (size_t)c->tap.pair * L * 256, (size_t)L * 1024, hipMemcpyDeviceToDevice, s));
         if (c->tap.x1) RFE_HIP(c, hipMemcpyAsync(c->tap.x1, b.x + (size_t)(P + c->tap.pair) * L * 256, (size_t)L * 1024, hipMemcpyDeviceToDevice, s));
     }
     RFE_HIP(c, hipGetLastError());
     return RFE_OK;
-}
-
-__global__ void lg_setup_kernel(const int32_t* m, const int32_t* n, int P, int Mmax, int Nmax, int32_t* lens, int32_t* kvmap) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 2 * P) return;
-    int v = i < P ? m[i] : n[i - P];
-    const int cap = i < P ? Mmax : Nmax;
-    v = v < 0 ? 0 : (v > cap ? cap : v);
-    lens[i] = v;
-    kvmap[i] = i < P ? i + P : i - P;
 }
 
 // stage device inputs [P,Mmax,*]/[P,Nmax,*] into the padded side-major token layout: descriptors -> x, normalised keypoints -> kn,
@@ -949,7 +940,8 @@ __global__ __launch_bounds__(256) void lg_stage_kernel(const float* __restrict__
                                                        const float* __restrict__ d0, const float* __restrict__ d1,
                                                        const int32_t* __restrict__ m, const int32_t* __restrict__ n, int P, int Mmax,
                                                        int Nmax, int L, float* __restrict__ x, float* __restrict__ kn,
-                                                       int32_t* __restrict__ lens, int32_t* __restrict__ kvmap) {
+                                                       int32_t* __restrict__ lens, int32_t* __restrict__ kvmap, int32_t* __restrict__ ticket,
+                                                       const float* __restrict__ wr, float2* __restrict__ csn) {
     if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < 2 * P; i += 256) {
             int v = i < P ? m[i] : n[i - P];
@@ -957,6 +949,7 @@ __global__ __launch_bounds__(256) void lg_stage_kernel(const float* __restrict__
             v = v < 0 ? 0 : (v > cap ? cap : v);
             lens[i] = v;
             kvmap[i] = i < P ? i + P : i - P;
+            ticket[i] = 0;
         }
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // side-major: row = (side * P + pair) * L + i
     if (row >= (int64_t)2 * P * L) return;
@@ -972,13 +965,20 @@ __global__ __launch_bounds__(256) void lg_stage_kernel(const float* __restrict__
     }
     reinterpret_cast<float4*>(x + row * 256)[lane] = v;
     if (lane == 0) reinterpret_cast<float2*>(kn)[row] = kv;
+    if (csn) {   // the rotary table row of this token (lg_posenc_kernel's arithmetic): saves the stand-alone launch in front of every forward
+        const float kx = __shfl(kv.x, 0), ky = __shfl(kv.y, 0);
+        if (lane < 32) {
+            const float th = fmaf(wr[2 * lane + 1], ky, wr[2 * lane] * kx);
+            csn[row * 32 + lane] = make_float2(cosf(th), sinf(th));
+        }
+    }
 }
 
 int lg_stage(rfe_ctx* c, LgBuffers& b, const float* k0n, const float* k1n, const float* d0, const float* d1,
              const int32_t* m, const int32_t* n, int P, int Mmax, int Nmax, int L) {
     const int64_t rows = (int64_t)2 * P * L;
     hipLaunchKernelGGL(lg_stage_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c->stream, k0n, k1n, d0, d1, m, n, P, Mmax, Nmax, L,
-                       b.x, b.kn, b.lens, b.kvmap);
+                       b.x, b.kn, b.lens, b.kvmap, b.ticket, c->lg.wr, reinterpret_cast<float2*>(b.csn));   // the rotary table too: lg_forward(posenc_done = true)
     return RFE_OK;
 }
 
@@ -1003,7 +1003,7 @@ extern "C" int rfe_match_dev(rfe_ctx* c, const float* k0n, const float* k1n, con
     LgBuffers b;
     lg_carve(c->ws_lg, P, L, b);
     if ((rc = lg_stage(c, b, k0n, k1n, d0, d1, m, n, P, Mmax, Nmax, L))) return rc;
-    return lg_forward(c, b, P, L, thr, std::min(Mmax, Nmax), S, pairs, ms, nullptr);
+    return lg_forward(c, b, P, L, thr, std::min(Mmax, Nmax), S, pairs, ms, nullptr, false, true);
 }
 
 extern "C" int rfe_match(rfe_ctx* c, const float* k0n, const float* k1n, const float* d0, const float* d1,
@@ -1092,7 +1092,7 @@ extern "C" int rfe_extract_match_stream_dev(rfe_ctx* c, const uint8_t* img, int 
         { ProfScope p(c, "lg_misc");
           launch_normalize_kpts(s, kxy, (int64_t)B * Kmax, H, W, kn_all);
           if ((rc = lg_stage(c, b, kn_all, kn_all + (size_t)Kmax * 2, desc, desc + (size_t)Kmax * 256, n, n + 1, P, Kmax, Kmax, L))) return rc; }
-        return lg_forward(c, b, P, L, filter_thr, Kmax, S, pairs, ms, nullptr);
+        return lg_forward(c, b, P, L, filter_thr, Kmax, S, pairs, ms, nullptr, false, true);
     }
     // Every interior frame is side 1 of pair i-1 and side 0 of pair i, and layer 0's self block depends on
     // the frame alone: run it (and the positional encoding) once per FRAME, then scatter into the pair layout.
@@ -1100,11 +1100,8 @@ extern "C" int rfe_extract_match_stream_dev(rfe_ctx* c, const uint8_t* img, int 
     float* xf = P == 1 ? b.x : b.md;         // [B, L, 256]: md ([2P, L, 256], B <= 2P) is only used by the assignment at the end
     float* csnf = P == 1 ? b.csn : (float*)(b.extra + kn_bytes);   // [B*L, 32, 2], own scratch (the similarity buffer [P, L, L] is too small
                                                                    //  for it when L < 64 (P+1)/P)
-    { ProfScope p(c, "lg_misc");
-      launch_normalize_kpts(s, kxy, (int64_t)B * Kmax, H, W, kn_all);
-      launch_lg_posenc(s, kn_all, c->lg.wr, B * L, csnf);
-      launch_copy_f32(s, desc, xf, (int64_t)B * L * 256);
-      hipLaunchKernelGGL(lg_setup_kernel, dim3((2 * P + 255) / 256), dim3(256), 0, s, n, n + 1, P, Kmax, Kmax, b.lens, b.kvmap); }
+    { ProfScope p(c, "lg_misc");   // one launch: NormalizeKeypoints + rotary table + descriptors -> token rows + lengths / cross map / tickets
+      launch_lg_frame_prologue(s, kxy, desc, c->lg.wr, n, B, L, H, W, kn_all, csnf, xf, b.lens, b.kvmap, b.ticket); }
     lg_self_block(c, b, c->lg.L[0], xf, csnf, n, B, L);
     if (P > 1) {
       ProfScope p(c, "lg_misc");
@@ -1237,7 +1234,7 @@ extern "C" int rfe_stereo_frame_dev(rfe_ctx* c, const uint8_t* imgL, const uint8
         lg_carve(c->ws_lg, 1, L, b);
         { ProfScope ps(c, "lg_misc");
           if ((rc = lg_stage(c, b, kn_cur, kn_prev, desc, desc_prev, n, n_prev, 1, Kmax, Kmax, L))) return rc; }
-        if ((rc = lg_forward(c, b, 1, L, filter_thr, Kmax, S, pairs, ms, nullptr))) return rc;
+        if ((rc = lg_forward(c, b, 1, L, filter_thr, Kmax, S, pairs, ms, nullptr, false, true))) return rc;
     } else {
         hipLaunchKernelGGL(st_zero_count_kernel, dim3(1), dim3(1), 0, s, S);
     }
@@ -1583,7 +1580,7 @@ extern "C" int rfe_k_lightglue_taps(rfe_ctx* c, const float* k0n, const float* k
     RFE_HIP(c, hipMemcpyAsync(dn, &N, 4, hipMemcpyHostToDevice, c->stream));
     RFE_HIP(c, hipStreamSynchronize(c->stream));
     if ((rc = lg_stage(c, b, k0n, k1n, d0, d1, dm, dn, 1, M, N, L))) return rc;
-    if ((rc = lg_forward(c, b, 1, L, 0.1f, cap, dS, dp, dms, scores ? sc : nullptr))) return rc;
+    if ((rc = lg_forward(c, b, 1, L, 0.1f, cap, dS, dp, dms, scores ? sc : nullptr, false, true))) return rc;
     if (x0) RFE_HIP(c, hipMemcpyAsync(x0, b.x, (size_t)M * 1024, hipMemcpyDeviceToDevice, c->stream));
     if (x1) RFE_HIP(c, hipMemcpyAsync(x1, b.x + (size_t)L * 256, (size_t)N * 1024, hipMemcpyDeviceToDevice, c->stream));
     if (scores) RFE_HIP(c, hipMemcpy2DAsync(scores, (size_t)N * 4, sc, (size_t)L * 4, (size_t)N * 4, M, hipMemcpyDeviceToDevice, c->stream));

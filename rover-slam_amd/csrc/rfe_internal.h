@@ -228,7 +228,11 @@ void launch_lg_ln_gelu(hipStream_t s, float* h, const float* g, const float* b, 
 void launch_lg_assign(hipStream_t s, const float* sim, const float* z0, const float* z1, int P, int L,
                       int cap, const int* m, const int* n, float thr, float* scores_opt, float* rowlse,
                       float* collse, int32_t* a0, float* mx0, int32_t* a1, int32_t* S, int32_t* pairs,
-                      float* ms, int scores_pair = -1 /*>= 0: scores_opt is [L,L] and receives that pair only*/);
+                      float* ms, int scores_pair /*>= 0: scores_opt is [L,L] and receives that pair only; < 0: every pair into [P,L,L]*/,
+                      const float* x, const float* wm, const float* bm, float* z, int32_t* ticket /*few-pair shapes: matchability + tickets of the merged launches*/);
+bool lg_assign_few_pairs(int P, int L);   // true: launch_lg_assign computes the matchability itself (launch_lg_matchability must not be called)
+void launch_lg_frame_prologue(hipStream_t s, const int32_t* kxy, const float* desc, const float* wr, const int32_t* nkp, int B, int L, int rows, int cols,
+                              float* kn, float* csn, float* x, int32_t* lens, int32_t* kvmap, int32_t* ticket);
 void launch_lg_matchability(hipStream_t s, const float* x, const float* w, const float* b, int64_t rows, float* z);
 void launch_copy_f32(hipStream_t s, const float* src, float* dst, int64_t n);
 void launch_normalize_kpts(hipStream_t s, const int32_t* kxy, int64_t n, int rows, int cols, float* out);
