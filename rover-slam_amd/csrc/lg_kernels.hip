@@ -817,35 +817,11 @@ __global__ __launch_bounds__(256) void lg_mutual_kernel(const int32_t* __restric
     lg_mutual_body(blockIdx.x, wave_tot, a0, mx0, a1, L, cap, m, n, thr, S, pairs, ms);
 }
 
-// few-pair shapes: row argmax AND the mutual / compaction step in one launch.  Every workgroup of a pair takes a ticket when its four rows are
-// written (release fence + atomic); the one that draws the last ticket sees all rows of the pair (acquire fence) and runs the mutual step,
-// then clears the ticket for the next call.  No workgroup ever waits for another.
-__global__ __launch_bounds__(256) void lg_rowarg_mutual_kernel(const float* __restrict__ sim, const float* __restrict__ z0,
-                                                               const float* __restrict__ z1, const float* __restrict__ rowlse,
-                                                               const float* __restrict__ collse, int L, const int* __restrict__ m,
-                                                               const int* __restrict__ n, int32_t* __restrict__ a0,
-                                                               float* __restrict__ mx0, float* __restrict__ scores_opt, int scores_pair,
-                                                               const int32_t* __restrict__ a1, int cap, float thr, int32_t* __restrict__ S,
-                                                               int32_t* __restrict__ pairs, float* __restrict__ ms, int32_t* __restrict__ ticket) {
-    __shared__ int wave_tot[4];
-    __shared__ int last;
-    const int p = blockIdx.y;
-    lg_rowarg_row(sim, z0, z1, rowlse, collse, L, m, n, a0, mx0, scores_opt, scores_pair);
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int t = atomicAdd(&ticket[p], 1);
-        last = t == (int)gridDim.x - 1;
-        if (last) ticket[p] = 0;
-    }
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    lg_mutual_body(p, wave_tot, a0, mx0, a1, L, cap, m, n, thr, S, pairs, ms);
-}
-
-// few-pair shapes (one to four pairs per call, the reference's own): matchability + row log-sum-exp in one launch, row argmax + mutual step in one
-// launch -- 3 launches instead of 5 (launch_lg_matchability is then NOT called by lg_forward)
+// few-pair shapes (one to four pairs per call, the reference's own): matchability + row log-sum-exp in one launch -- 4 launches instead of 5
+// (launch_lg_matchability is then NOT called by lg_forward).  Measured and NOT kept (round 5, kernel trace of one pair): row argmax + mutual step in
+// one launch, the workgroup that draws the last ticket of a pair (release fence + atomic per workgroup) running the mutual step -- 29.3 us against
+// 8.4 + 5.1 us for the two kernels: the device-scope fences write the L2s back in every one of the 256 workgroups and the mutual step becomes a
+// serial tail behind the slowest of them; a kernel boundary (2.4-4.3 us) is cheaper.
 bool lg_assign_few_pairs(int P, int L) {
     static const bool on = tune_int("RFE_LG_ASSIGN_MERGE", 1) != 0;   // tuning build: 0 = the five separate launches
     return on && (long long)P * ((L + 31) / 32) < 128;
@@ -853,12 +829,12 @@ bool lg_assign_few_pairs(int P, int L) {
 void launch_lg_assign(hipStream_t s, const float* sim, const float* z0, const float* z1, int P, int L, int cap,
                       const int* m, const int* n, float thr, float* scores_opt, float* rowlse, float* collse,
                       int32_t* a0, float* mx0, int32_t* a1, int32_t* S, int32_t* pairs, float* ms, int scores_pair,
-                      const float* x, const float* wm, const float* bm, float* z, int32_t* ticket) {
-    if (lg_assign_few_pairs(P, L) && x && ticket) {
+                      const float* x, const float* wm, const float* bm, float* z) {
+    if (lg_assign_few_pairs(P, L) && x) {
         hipLaunchKernelGGL(lg_rowlse_z_kernel, dim3((L + 3) / 4, P, 2), dim3(256), 0, s, sim, L, P, m, n, rowlse, x, wm, bm, z);
         hipLaunchKernelGGL((lg_col_kernel<16, 64>), dim3((L + 15) / 16, P), dim3(1024), 0, s, sim, z0, z1, rowlse, L, m, n, collse, a1);
-        hipLaunchKernelGGL(lg_rowarg_mutual_kernel, dim3((L + 3) / 4, P), dim3(256), 0, s, sim, z0, z1, rowlse, collse, L, m, n, a0, mx0, scores_opt, scores_pair,
-                           a1, cap, thr, S, pairs, ms, ticket);
+        hipLaunchKernelGGL(lg_rowarg_kernel, dim3((L + 3) / 4, P), dim3(256), 0, s, sim, z0, z1, rowlse, collse, L, m, n, a0, mx0, scores_opt, scores_pair);
+        hipLaunchKernelGGL(lg_mutual_kernel, dim3(P), dim3(256), 0, s, a0, mx0, a1, L, cap, m, n, thr, S, pairs, ms);
         return;
     }
     hipLaunchKernelGGL(lg_rowlse_kernel, dim3((L + 3) / 4, P), dim3(256), 0, s, sim, L, m, n, rowlse);
@@ -900,12 +876,11 @@ void launch_normalize_kpts(hipStream_t s, const int32_t* kxy, int64_t n, int row
 // ---------------------------------------------------------------- one-launch prologue of the stream mode (round 5: it replaced normalize_kpts +
 // lg_posenc + copy_f32 + lg_setup, four 4-5 us launches in front of every one-pair forward).  One wave per token row of the B frames:
 // NormalizeKeypoints (reference src/Matchers/transform.cpp:19-32) of the integer pixel keypoint -> kn, its rotary table row (the arithmetic of
-// lg_posenc_kernel, operand for operand) -> csn, its descriptor -> x; workgroup 0 also clamps the lengths, writes the cross-attention map and
-// clears the assignment's tickets.  Requires L == Kmax (the caller's dedup path).
+// lg_posenc_kernel, operand for operand) -> csn, its descriptor -> x; workgroup 0 also clamps the lengths and writes the cross-attention map.  Requires L == Kmax (the caller's dedup path).
 __global__ __launch_bounds__(256) void lg_frame_prologue_kernel(const int32_t* __restrict__ kxy, const float* __restrict__ desc, const float* __restrict__ wr,
                                                                 const int32_t* __restrict__ nkp, int B, int L, float sx, float sy, float scale,
                                                                 float* __restrict__ kn, float2* __restrict__ csn, float* __restrict__ x,
-                                                                int32_t* __restrict__ lens, int32_t* __restrict__ kvmap, int32_t* __restrict__ ticket) {
+                                                                int32_t* __restrict__ lens, int32_t* __restrict__ kvmap) {
     const int P = B - 1;
     if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < 2 * P; i += 256) {
@@ -913,7 +888,6 @@ __global__ __launch_bounds__(256) void lg_frame_prologue_kernel(const int32_t* _
             v = v < 0 ? 0 : (v > L ? L : v);
             lens[i] = v;
             kvmap[i] = i < P ? i + P : i - P;
-            if (i < P) ticket[i] = 0;
         }
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= (int64_t)B * L) return;
@@ -927,10 +901,10 @@ __global__ __launch_bounds__(256) void lg_frame_prologue_kernel(const int32_t* _
     }
 }
 void launch_lg_frame_prologue(hipStream_t s, const int32_t* kxy, const float* desc, const float* wr, const int32_t* nkp, int B, int L, int rows, int cols,
-                              float* kn, float* csn, float* x, int32_t* lens, int32_t* kvmap, int32_t* ticket) {
+                              float* kn, float* csn, float* x, int32_t* lens, int32_t* kvmap) {
     const float sx = (float)cols / 2, sy = (float)rows / 2, scale = (float)(rows > cols ? rows : cols) / 2;
     hipLaunchKernelGGL(lg_frame_prologue_kernel, dim3((unsigned)(((int64_t)B * L + 3) / 4)), dim3(256), 0, s, kxy, desc, wr, nkp, B, L, sx, sy, scale, kn,
-                       reinterpret_cast<float2*>(csn), x, lens, kvmap, ticket);
+                       reinterpret_cast<float2*>(csn), x, lens, kvmap);
 }
 
 }  // namespace rfe

@@ -797,7 +797,7 @@ namespace {
 
 struct LgBuffers {
     float *x, *kn, *csn, *lnstat, *qkv, *ctx, *msg, *h, *md, *z, *sim, *rowlse, *collse, *mx0, *apart;
-    int32_t *a0, *a1, *lens, *kvmap, *ticket;
+    int32_t *a0, *a1, *lens, *kvmap;
     char* extra;   // caller-sized scratch region carved after the fixed buffers
 };
 
@@ -808,7 +808,7 @@ size_t lg_ws_bytes(int P, int L, size_t extra_bytes = 0) {
     t += al(rows * 2 * 4) + al(rows * 64 * 4) + al(rows * 32 * 4) + al(rows * 768 * 4) + al(rows * 512 * 4) + al(rows * 4);
     t += al((size_t)P * L * L * 4);
     t += al((size_t)P * L * 4) * 5;
-    t += al((size_t)2 * P * 4) * 3;
+    t += al((size_t)2 * P * 4) * 2;
     t += al(lg_attention_part_bytes(2 * P, L));
     return t + al(extra_bytes) + 4096;
 }
@@ -823,7 +823,6 @@ void lg_carve(void* ws, int P, int L, LgBuffers& b, size_t extra_bytes = 0) {
     b.rowlse = a.take<float>((size_t)P * L); b.collse = a.take<float>((size_t)P * L); b.mx0 = a.take<float>((size_t)P * L);
     b.a0 = a.take<int32_t>((size_t)P * L); b.a1 = a.take<int32_t>((size_t)P * L);
     b.lens = a.take<int32_t>((size_t)2 * P); b.kvmap = a.take<int32_t>((size_t)2 * P);
-    b.ticket = a.take<int32_t>((size_t)2 * P);   // per pair: workgroups of the merged row-argmax / mutual launch that have finished (cleared by every staging kernel)
     { const size_t pb = lg_attention_part_bytes(2 * P, L); b.apart = pb ? a.take<float>(pb / 4) : nullptr; }
     b.extra = a.take<char>(extra_bytes);
 }
@@ -924,7 +923,7 @@ int lg_forward(rfe_ctx* c, LgBuffers& b, int P, int L, float thr, int cap, int32
     { ProfScope p(c, "lg_assign");
       if (!lg_assign_few_pairs(P, L)) launch_lg_matchability(s, b.x, W.wm, W.bm, rows, b.z);   // few pairs: inside the row log-sum-exp launch
       launch_lg_assign(s, b.sim, b.z, b.z + (size_t)P * L, P, L, cap, b.lens, b.lens + P, thr, scores_opt, b.rowlse,
-                       b.collse, b.a0, b.mx0, b.a1, S, pairs, ms, scores_pair, b.x, W.wm, W.bm, b.z, b.ticket); }
+                       b.collse, b.a0, b.mx0, b.a1, S, pairs, ms, scores_pair, b.x, W.wm, W.bm, b.z); }
     if (tap) {
         if (c->tap.x0) RFE_HIP(c, hipMemcpyAsync(c->tap.x0, b.x + (size_t)c->tap.pair * L * 256, (size_t)L * 1024, hipMemcpyDeviceToDevice, s));
         if (c->tap.x1) RFE_HIP(c, hipMemcpyAsync(c->tap.x1, b.x + (size_t)(P + c->tap.pair) * L * 256, (size_t)L * 1024, hipMemcpyDeviceToDevice, s));
@@ -940,7 +939,7 @@ __global__ __launch_bounds__(256) void lg_stage_kernel(const float* __restrict__
                                                        const float* __restrict__ d0, const float* __restrict__ d1,
                                                        const int32_t* __restrict__ m, const int32_t* __restrict__ n, int P, int Mmax,
                                                        int Nmax, int L, float* __restrict__ x, float* __restrict__ kn,
-                                                       int32_t* __restrict__ lens, int32_t* __restrict__ kvmap, int32_t* __restrict__ ticket,
+                                                       int32_t* __restrict__ lens, int32_t* __restrict__ kvmap,
                                                        const float* __restrict__ wr, float2* __restrict__ csn) {
     if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < 2 * P; i += 256) {
@@ -949,7 +948,6 @@ __global__ __launch_bounds__(256) void lg_stage_kernel(const float* __restrict__
             v = v < 0 ? 0 : (v > cap ? cap : v);
             lens[i] = v;
             kvmap[i] = i < P ? i + P : i - P;
-            ticket[i] = 0;
         }
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // side-major: row = (side * P + pair) * L + i
     if (row >= (int64_t)2 * P * L) return;
@@ -978,7 +976,7 @@ int lg_stage(rfe_ctx* c, LgBuffers& b, const float* k0n, const float* k1n, const
              const int32_t* m, const int32_t* n, int P, int Mmax, int Nmax, int L) {
     const int64_t rows = (int64_t)2 * P * L;
     hipLaunchKernelGGL(lg_stage_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c->stream, k0n, k1n, d0, d1, m, n, P, Mmax, Nmax, L,
-                       b.x, b.kn, b.lens, b.kvmap, b.ticket, c->lg.wr, reinterpret_cast<float2*>(b.csn));   // the rotary table too: lg_forward(posenc_done = true)
+                       b.x, b.kn, b.lens, b.kvmap, c->lg.wr, reinterpret_cast<float2*>(b.csn));   // the rotary table too: lg_forward(posenc_done = true)
     return RFE_OK;
 }
 
@@ -1100,8 +1098,8 @@ extern "C" int rfe_extract_match_stream_dev(rfe_ctx* c, const uint8_t* img, int 
     float* xf = P == 1 ? b.x : b.md;         // [B, L, 256]: md ([2P, L, 256], B <= 2P) is only used by the assignment at the end
     float* csnf = P == 1 ? b.csn : (float*)(b.extra + kn_bytes);   // [B*L, 32, 2], own scratch (the similarity buffer [P, L, L] is too small
                                                                    //  for it when L < 64 (P+1)/P)
-    { ProfScope p(c, "lg_misc");   // one launch: NormalizeKeypoints + rotary table + descriptors -> token rows + lengths / cross map / tickets
-      launch_lg_frame_prologue(s, kxy, desc, c->lg.wr, n, B, L, H, W, kn_all, csnf, xf, b.lens, b.kvmap, b.ticket); }
+    { ProfScope p(c, "lg_misc");   // one launch: NormalizeKeypoints + rotary table + descriptors -> token rows + lengths / cross map
+      launch_lg_frame_prologue(s, kxy, desc, c->lg.wr, n, B, L, H, W, kn_all, csnf, xf, b.lens, b.kvmap); }
     lg_self_block(c, b, c->lg.L[0], xf, csnf, n, B, L);
     if (P > 1) {
       ProfScope p(c, "lg_misc");

@@ -229,10 +229,10 @@ void launch_lg_assign(hipStream_t s, const float* sim, const float* z0, const fl
                       int cap, const int* m, const int* n, float thr, float* scores_opt, float* rowlse,
                       float* collse, int32_t* a0, float* mx0, int32_t* a1, int32_t* S, int32_t* pairs,
                       float* ms, int scores_pair /*>= 0: scores_opt is [L,L] and receives that pair only; < 0: every pair into [P,L,L]*/,
-                      const float* x, const float* wm, const float* bm, float* z, int32_t* ticket /*few-pair shapes: matchability + tickets of the merged launches*/);
+                      const float* x, const float* wm, const float* bm, float* z /*few-pair shapes: the matchability head rides in the row log-sum-exp launch*/);
 bool lg_assign_few_pairs(int P, int L);   // true: launch_lg_assign computes the matchability itself (launch_lg_matchability must not be called)
 void launch_lg_frame_prologue(hipStream_t s, const int32_t* kxy, const float* desc, const float* wr, const int32_t* nkp, int B, int L, int rows, int cols,
-                              float* kn, float* csn, float* x, int32_t* lens, int32_t* kvmap, int32_t* ticket);
+                              float* kn, float* csn, float* x, int32_t* lens, int32_t* kvmap);
 void launch_lg_matchability(hipStream_t s, const float* x, const float* w, const float* b, int64_t rows, float* z);
 void launch_copy_f32(hipStream_t s, const float* src, float* dst, int64_t n);
 void launch_normalize_kpts(hipStream_t s, const int32_t* kxy, int64_t n, int rows, int cols, float* out);
