@@ -20,7 +20,7 @@ public:
         : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST) {
         Configuration cfg;
         cfg.device = "cuda";                       // kept for symmetry with SPextractor.cc:92; ignored
-        cfg.extractorPath = "onnxmodel/superpoint.rfew";
+        cfg.extractorPath = "onnxmodel/superpoint.onnx";   // src/Extractors/SPextractor.cc:93, unedited
         cfg.extractorType = "superpoint";
         featureExtractor = new SuperPointOnnxRunner();
         featureExtractor->InitOrtEnv(cfg);         // return value ignored, as in SPextractor.cc:96

@@ -6,7 +6,7 @@
 // Behavioural notes w.r.t. the reference:
 //  * InitOrtEnv returns EXIT_SUCCESS / EXIT_FAILURE and prints to std::cerr on failure, as
 //    superpoint_onnx.cc:59-65 does.  cfg.device is ignored (the only backend is HIP); cfg.extractorPath
-//    names an RFEW weight file (see Matchers/Configuration.h).
+//    names the model file exactly as in the reference (an .onnx graph; an RFEW container is accepted too, see Matchers/Configuration.h).
 //  * Extractor_Inference takes the NormalizeImage()d CV_32F image like superpoint_onnx.cc:88 and
 //    stores {keypoints i64 [1,K,2], scores f32 [1,K], descriptors f32 [1,K,256]} in
 //    extractor_outputtensors, K = number of detected keypoints (<= max_keypoints).
@@ -53,8 +53,11 @@ public:
 
     int InitOrtEnv(Configuration cfg) {
         std::string path = cfg.extractorPath;
+        // the path is used AS GIVEN: the reference's own "onnxmodel/superpoint.onnx" (src/Extractors/SPextractor.cc:93) is read by the library
+        // itself (initializers + graph hyper-parameters, rover-slam_amd/csrc/onnx_load.hip), an RFEW container works as well; $RFE_SP_WEIGHTS
+        // only overrides where the file is
         if (const char* e = std::getenv("RFE_SP_WEIGHTS")) path = e;
-        if (path.empty() || path.size() < 5 || path.substr(path.size() - 5) != ".rfew") path = "onnxmodel/superpoint.rfew";
+        if (path.empty()) path = "onnxmodel/superpoint.onnx";
         int dev = 0;
         if (const char* e = std::getenv("RFE_DEVICE")) dev = std::atoi(e);
         int rc = rfe_init(dev, &ExtractorSession);

@@ -2,8 +2,8 @@
 // (include/Matchers/lightglue_onnx.h:10-67, src/Matchers/lightglue_onnx.cpp): same class / method names;
 // the session is an rfe_ctx of librover_fe.so, tensors are rfe::Tensor instead of Ort::Value.
 //  * InitOrtEnv: EXIT_SUCCESS / EXIT_FAILURE + std::cerr, like lightglue_onnx.cpp:4-98; the model path is
-//    cfg.lightgluePath / $RFE_LG_WEIGHTS / onnxmodel/lightglue_sim.rfew (reference hard-codes
-//    onnxmodel/lightglue_sim.onnx, lightglue_onnx.cpp:38).
+//    cfg.lightgluePath, else the reference's hard-coded onnxmodel/lightglue_sim.onnx (lightglue_onnx.cpp:38) -- read as an ONNX
+//    graph by the library itself ($RFE_LG_WEIGHTS overrides the location; an RFEW container is accepted too).
 //  * Matcher_Inference returns {matches0 i64 [S,2], mscores0 f32 [S]} or an EMPTY vector on failure
 //    (lightglue_onnx.cpp:232-237).  Unlike the reference it does not leak its keypoint copies (:176-177).
 //  * Matcher_PostProcess_fused: lightglue_onnx.cpp:396-482 (an empty `output` returns 0 instead of
@@ -42,8 +42,10 @@ public:
 
     int InitOrtEnv(Configuration cfg) {
         std::string path = cfg.lightgluePath;
+        // as given: the reference's hard-coded "onnxmodel/lightglue_sim.onnx" (src/Matchers/lightglue_onnx.cpp:38) is read by the library itself;
+        // an RFEW container works as well; $RFE_LG_WEIGHTS only overrides where the file is
         if (const char* e = std::getenv("RFE_LG_WEIGHTS")) path = e;
-        if (path.size() < 5 || path.substr(path.size() - 5) != ".rfew") path = "onnxmodel/lightglue_sim.rfew";
+        if (path.empty()) path = "onnxmodel/lightglue_sim.onnx";
         int dev = 0;
         if (const char* e = std::getenv("RFE_DEVICE")) dev = std::atoi(e);
         int rc = rfe_init(dev, &MatcherSession);

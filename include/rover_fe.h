@@ -63,8 +63,15 @@ void rfe_destroy(rfe_ctx* ctx);
 const char* rfe_last_error(rfe_ctx* ctx); /* ctx may be NULL: last error of a failed rfe_init */
 const char* rfe_version(void);
 
-/* ---- weights: RFEW container files, or host blobs in the canonical layout ---- */
+/* ---- weights: ONNX graph files, RFEW container files, or host blobs in the canonical layout ----
+ * rfe_load_weights takes, per path, EITHER the reference's own model file -- onnxmodel/superpoint.onnx (src/Extractors/SPextractor.cc:92-94) /
+ * onnxmodel/lightglue_sim.onnx (src/Matchers/lightglue_onnx.cpp:38): the initializers are re-packed into the canonical layout and the graph's
+ * baked-in hyper-parameters (see rfe_hparams below) are read from its nodes, in C++ (rover-slam_amd/csrc/onnx_load.hip; no Python step, no
+ * protobuf / onnx library); a graph whose constants cannot be read, or whose tensors cannot be placed, is refused with the reason
+ * (RFE_ERR_IO, rfe_last_error) -- OR an RFEW container written by rover-slam_amd/onnx_weights.py / weights.py; the file's first four bytes
+ * decide.  rfe_load_onnx insists on ONNX. */
 int rfe_load_weights(rfe_ctx* ctx, const char* sp_path, const char* lg_path); /* either may be NULL */
+int rfe_load_onnx(rfe_ctx* ctx, const char* sp_path, const char* lg_path);    /* either may be NULL */
 int rfe_set_weights(rfe_ctx* ctx, int kind, const float* blob, int64_t count);
 int64_t rfe_weight_count(int kind);
 /* Read-only weights are shared inside a process: every ctx that loads the same blob on the same device uses one device
@@ -364,6 +371,10 @@ int rfe_k_set_lightglue_tap(rfe_ctx* ctx, int pair, float* x0_dev, float* x1_dev
  * failing member aborts every member's communicator, nobody is left waiting in a collective, and the call delivers its results through
  * the COPY transport (RFE_POOL_AUTO) or reports the failure (RFE_POOL_RCCL); later calls use COPY.  tests/test_pool.py. */
 int rfe_k_pool_inject_gather_failure(rfe_pool* pool, int member);
+/* The ONNX reader without a ctx (and without a GPU): `path` of `kind` -> blob [rfe_weight_count(kind)] and that kind's fields of *hp (weights_only != 0:
+ * the initializers alone, no hyper-parameter readers).  RFE_OK, or RFE_ERR_IO with the reason in err.  tests/test_onnx_cpp.py holds it bit for bit
+ * against rover-slam_amd/onnx_weights.py. */
+int rfe_k_onnx_convert(const char* path, int kind, int weights_only, float* blob, rfe_hparams* hp, char* err, int errlen);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,7 @@ OPT_LG_FOLD_WO = 1
 OPT_LG_FP16X2 = 2   # LightGlue Linears + attention of batched calls as split products on the f16 matrix pipe (default off)
 
 EXPORTS = [
-    "rfe_init", "rfe_destroy", "rfe_last_error", "rfe_version", "rfe_load_weights", "rfe_set_weights",
+    "rfe_init", "rfe_destroy", "rfe_last_error", "rfe_version", "rfe_load_weights", "rfe_load_onnx", "rfe_set_weights",
     "rfe_weight_count", "rfe_weights_id", "rfe_get_hparams", "rfe_set_hparams", "rfe_set_option", "rfe_get_option", "rfe_set_stream", "rfe_synchronize", "rfe_malloc", "rfe_free", "rfe_host_malloc", "rfe_host_free", "rfe_workspace_bytes", "rfe_memcpy_h2d",
     "rfe_memcpy_d2h", "rfe_extract_u8", "rfe_extract_u8_dev", "rfe_extract_f32", "rfe_extract_f32_dev", "rfe_extract_u8_bin", "rfe_extract_u8_bin_dev", "rfe_match", "rfe_match_dev", "rfe_match_fused",
     "rfe_extract_match_stream_dev", "rfe_stereo_match", "rfe_stereo_match_dev", "rfe_stereo_frame_dev", "rfe_l2_distance_matrix", "rfe_binarize_descriptors",
@@ -24,7 +24,7 @@ EXPORTS = [
     "rfe_pool_create", "rfe_pool_destroy", "rfe_pool_last_error", "rfe_pool_size", "rfe_pool_ctx", "rfe_pool_has_rccl", "rfe_pool_set_weights",
     "rfe_pool_load_weights", "rfe_pool_set_option", "rfe_pool_set_hparams", "rfe_pool_shard", "rfe_pool_extract_match_stream",
     "rfe_profile_enable", "rfe_profile_filter", "rfe_profile_reset", "rfe_profile_read",
-    "rfe_k_conv3x3", "rfe_k_linear", "rfe_k_scoremap", "rfe_k_select", "rfe_k_lightglue_taps", "rfe_k_set_lightglue_tap", "rfe_k_lightglue_ffn", "rfe_k_attention", "rfe_k_pool_inject_gather_failure",
+    "rfe_k_conv3x3", "rfe_k_linear", "rfe_k_scoremap", "rfe_k_select", "rfe_k_lightglue_taps", "rfe_k_set_lightglue_tap", "rfe_k_lightglue_ffn", "rfe_k_attention", "rfe_k_pool_inject_gather_failure", "rfe_k_onnx_convert",
 ]
 
 if not os.path.exists(LIB_PATH):
@@ -120,6 +120,8 @@ lib.rfe_pool_ctx.argtypes = [C.c_void_p, C.c_int]
 lib.rfe_pool_ctx.restype = C.c_void_p
 lib.rfe_pool_has_rccl.argtypes = [C.c_void_p]
 lib.rfe_k_pool_inject_gather_failure.argtypes = [C.c_void_p, C.c_int]
+lib.rfe_load_onnx.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+lib.rfe_k_onnx_convert.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p, C.c_char_p, C.c_int]
 lib.rfe_host_malloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
 lib.rfe_host_free.argtypes = [C.c_void_p]
 lib.rfe_host_free.restype = None

@@ -532,11 +532,53 @@ extern "C" int rfe_set_hparams(rfe_ctx* c, const rfe_hparams* in) {
     return RFE_OK;
 }
 
+// An ONNX graph file (the reference's own onnxmodel/superpoint.onnx / lightglue_sim.onnx, src/Extractors/SPextractor.cc:92-94,
+// src/Matchers/lightglue_onnx.cpp:38): initializers -> canonical blob, graph constants -> hyper-parameters (onnx_load.hip), then exactly what an RFEW
+// v2 file does.  A graph whose hyper-parameters cannot be read is refused with the reason (RFE_ERR_IO).
+static int load_onnx(rfe_ctx* c, const char* path, int want_kind) {
+    std::vector<float> blob;
+    rfe_hparams hp = rfe_default_hparams();
+    std::string err;
+    if (!rfe::onnx_convert(path, want_kind, blob, &hp, err)) return fail(c, RFE_ERR_IO, err);
+    int rc = check_hparams(c, hp, path);
+    if (rc) { c->err = "graph hyper-parameters refused: " + c->err; return RFE_ERR_IO; }
+    if ((int64_t)blob.size() != rfe_weight_count(want_kind)) return fail(c, RFE_ERR_IO, std::string("converted weight count mismatch for ") + path);
+    rc = rfe_set_weights(c, want_kind, blob.data(), (int64_t)blob.size());   // resets this kind's hyper-parameters to the defaults
+    if (rc == RFE_OK) {
+        if (want_kind == RFE_KIND_SUPERPOINT) {
+            c->hp.sp_max_keypoints = hp.sp_max_keypoints; c->hp.sp_detection_threshold = hp.sp_detection_threshold; c->hp.sp_nms_radius = hp.sp_nms_radius;
+            c->hp.sp_remove_borders = hp.sp_remove_borders; c->hp.sp_topk_always = hp.sp_topk_always;
+        } else {
+            c->hp.lg_layers = hp.lg_layers; c->hp.lg_heads = hp.lg_heads; c->hp.lg_filter_threshold = hp.lg_filter_threshold;
+        }
+    }
+    return rc;
+}
+
+// RFEW container or ONNX graph, told apart by the file's first four bytes
+static int load_any(rfe_ctx* c, const char* path, int want_kind) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(c, RFE_ERR_IO, std::string("cannot open weight file ") + path);
+    unsigned char magic[4] = {0, 0, 0, 0};
+    const size_t got = fread(magic, 1, 4, f);
+    fclose(f);
+    if (got == 4 && memcmp(magic, "RFEW", 4) == 0) return load_rfew(c, path, want_kind);
+    return load_onnx(c, path, want_kind);
+}
+
 extern "C" int rfe_load_weights(rfe_ctx* c, const char* sp_path, const char* lg_path) {
     if (!c) return RFE_ERR_INVALID;
     int rc;
-    if (sp_path && (rc = load_rfew(c, sp_path, RFE_KIND_SUPERPOINT))) return rc;
-    if (lg_path && (rc = load_rfew(c, lg_path, RFE_KIND_LIGHTGLUE))) return rc;
+    if (sp_path && (rc = load_any(c, sp_path, RFE_KIND_SUPERPOINT))) return rc;
+    if (lg_path && (rc = load_any(c, lg_path, RFE_KIND_LIGHTGLUE))) return rc;
+    return RFE_OK;
+}
+
+extern "C" int rfe_load_onnx(rfe_ctx* c, const char* sp_path, const char* lg_path) {
+    if (!c) return RFE_ERR_INVALID;
+    int rc;
+    if (sp_path && (rc = load_onnx(c, sp_path, RFE_KIND_SUPERPOINT))) return rc;
+    if (lg_path && (rc = load_onnx(c, lg_path, RFE_KIND_LIGHTGLUE))) return rc;
     return RFE_OK;
 }
 

@@ -195,6 +195,9 @@ inline bool gemm_latency_regime(const GemmArgs& g) {
 }
 // gemm_lat.hip: false = shape not served (nothing launched).  rope_csn != null: rotary epilogue on output columns < rope_cols (qkv).
 bool launch_gemm_lat(hipStream_t s, const GemmArgs& g, const float* rope_csn, int rope_cols);
+// onnx_load.hip (host only): an ONNX graph file -> canonical weight blob of `kind` + that kind's fields of *hp; false + reason when the file cannot be
+// read, a tensor cannot be placed, or a hyper-parameter cannot be read from the graph (nothing is guessed)
+bool onnx_convert(const std::string& path, int kind, std::vector<float>& blob, rfe_hparams* hp, std::string& err);
 // ffn2_lat.hip: ffn.3 of a one- / few-pair forward with LayerNorm(512) + GELU of its activation fused in (h = ffn.0's raw output); false = not served
 bool launch_ffn2_ln_lat(hipStream_t s, const float* h, const float* w2, const float* b2, const float* ln_g, const float* ln_b, const float* R, int ldr,
                         float* C, int ldc, int M);

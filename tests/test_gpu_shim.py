@@ -66,3 +66,55 @@ def test_cpp_shims_match_oracle(tmp_path, oracle, H, W):
     # Frame::ComputeStereoMatches through include/rfe/stereo_match.h (frames 0 / 1 as left / right view)
     u_ref, z_ref = oracle.stereo_match(frames[0], frames[1], kp0, kp1, d0, d1, 0.11, 0.11 * 435.0)
     assert np.array_equal(u_right, u_ref) and np.array_equal(z_depth, z_ref)
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="no g++")
+def test_cpp_shims_take_the_references_onnx_paths_unedited(tmp_path, oracle):
+    """the drop-in classes constructed exactly as the reference constructs them -- cfg.extractorPath = "onnxmodel/superpoint.onnx"
+    (src/Extractors/SPextractor.cc:93) and the hard-coded "onnxmodel/lightglue_sim.onnx" (src/Matchers/lightglue_onnx.cpp:38) -- with NO environment
+    override and no .rfew file anywhere: the working directory holds onnxmodel/*.onnx written by torch's exporter, the library reads weights AND graph
+    hyper-parameters (K = 2048, radius 3, border 2, threshold 0.005, unconditional top-k; filter 0.25) from them."""
+    torch = pytest.importorskip("torch")  # noqa: F841
+    import onnx_export as X
+    H, W = 120, 160
+    exe = str(tmp_path / "shim_driver")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "shim_driver.cpp"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "rover-slam_amd"), "-lrover_fe", "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + os.path.join(ROOT, "rover-slam_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    (tmp_path / "onnxmodel").mkdir()
+    try:
+        _, wsp = X.export_sp(str(tmp_path / "onnxmodel"), X.SETTINGS[1], seed=7, desc_center="auto")
+        _, wlg = X.export_lg(str(tmp_path / "onnxmodel"), 0.25, seed=11, calibrated=True)
+    except X.ExporterUnavailable as e:                         # pragma: no cover
+        pytest.skip(str(e))
+    frames, _ = synth.make_frames(2, H, W, seed=20240314, max_shift=16, shift_step=8)
+    frames.tofile(str(tmp_path / "frames.u8"))
+    env = {k: v for k, v in os.environ.items() if k not in ("RFE_SP_WEIGHTS", "RFE_LG_WEIGHTS")}
+    r = subprocess.run([exe, str(tmp_path / "frames.u8"), str(H), str(W), str(tmp_path / "out.bin")], env=env, cwd=str(tmp_path),
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    buf = open(str(tmp_path / "out.bin"), "rb").read()
+    off, ext = 0, []
+    for i in range(2):
+        n = struct.unpack_from("<i", buf, off)[0]; off += 4
+        kp = np.frombuffer(buf, np.float32, n * 5, off).reshape(n, 5); off += n * 20
+        desc = np.frombuffer(buf, np.float32, n * 256, off).reshape(n, 256); off += n * 1024
+        ext.append((n, kp, desc))
+    s_frame, _, _, _, m = struct.unpack_from("<iiiii", buf, off); off += 20
+    vn_frame = np.frombuffer(buf, np.int32, m, off)
+    ref = [oracle.superpoint(wsp, frames[i], kmax=2048, thr=0.005, nms_radius=3, border=2, topk_always=True) for i in range(2)]
+    for (n, kp, desc), r_ in zip(ext, ref):
+        assert n == r_["n"] and n > 300
+        assert np.array_equal(kp[:, :2], r_["kxy"][:n].astype(np.float32)) and np.array_equal(kp[:, 2], r_["score"][:n]) and np.array_equal(desc, r_["desc"][:n])
+    kp0, kp1 = [r_["kxy"][:r_["n"]].astype(np.float32) for r_ in ref]
+    lg = oracle.lightglue(wlg, oracle.normalize_keypoints(kp0, H, W), oracle.normalize_keypoints(kp1, H, W), ref[0]["desc"][:ref[0]["n"]],
+                          ref[1]["desc"][:ref[1]["n"]], filter_thr=0.25)
+    s_ref, vn_ref = oracle.postprocess_fused(lg["pairs"], lg["ms"], 0.0, len(kp0))
+    assert s_ref > 10 and s_frame == s_ref and np.array_equal(vn_frame, vn_ref)
+    # a directory without the model files: the constructors report it the way the reference's do (std::cerr, EXIT_FAILURE ignored by the ctor) and
+    # the driver, which checks the sessions, stops
+    (tmp_path / "empty").mkdir()
+    r = subprocess.run([exe, str(tmp_path / "frames.u8"), str(H), str(W), str(tmp_path / "out2.bin")], env=env, cwd=str(tmp_path / "empty"),
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "onnxmodel/superpoint.onnx" in r.stderr

@@ -79,9 +79,8 @@ def _interleave_qkv(w, b):
             np.ascontiguousarray(b.reshape(3, 4, 64).transpose(1, 2, 0).reshape(768)))
 
 
-def test_lightglue_roundtrip(tmp_path):
-    blob = Wt.make_lightglue(seed=5)
-    t = _named(blob, Wt.lg_manifest()[0])
+def _named_lightglue_model(t):
+    """cvg parameter names, every Linear as MatMul(x, anonymous W^T) + Add(named bias): what a constant-folded export looks like"""
     inits, nodes, cnt = [], [], [1000]
 
     def linear(prefix, w, b):     # MatMul(x, W^T as an anonymous constant) + Add(named bias)
@@ -106,10 +105,41 @@ def test_lightglue_roundtrip(tmp_path):
         linear(c + "ffn.3", t[p + "cross.W2"], t[p + "cross.b2"])
     linear(f"log_assignment.{Wt.LG_LAYERS - 1}.final_proj", t["final_proj.W"], t["final_proj.b"])
     linear(f"log_assignment.{Wt.LG_LAYERS - 1}.matchability", t["matchability.w"].reshape(1, 256), t["matchability.b"])
+    return _model(inits, nodes)
+
+
+def test_lightglue_roundtrip(tmp_path):
+    blob = Wt.make_lightglue(seed=5)
     path = tmp_path / "lightglue_sim.onnx"
-    path.write_bytes(_model(inits, nodes))
+    path.write_bytes(_named_lightglue_model(_named(blob, Wt.lg_manifest()[0])))
     got = OW.convert_lightglue(str(path))
     assert np.array_equal(got, blob)
+
+
+def anonymous_cases(tmp_path):
+    """every hand-written file of this module as (path, kind, converts?) -- tests/test_onnx_cpp.py runs the C++ reader over the same files"""
+    out = []
+
+    def put(name, data, kind, ok):
+        p = tmp_path / name
+        p.write_bytes(data)
+        out.append((str(p), kind, ok))
+
+    sp = _named(Wt.make_superpoint(seed=3), Wt.sp_manifest()[0])
+    for anonymous in (False, True):
+        inits = []
+        for li, (name, cin, cout, k) in enumerate(Wt.SP_LAYERS):
+            wn, bn = (f"onnx::Conv_{200 + 2 * li}", f"onnx::Conv_{201 + 2 * li}") if anonymous else (name + ".weight", name + ".bias")
+            inits += [(wn, sp[name + ".weight"]), (bn, sp[name + ".bias"])]
+        put(f"sp_{int(anonymous)}.onnx", _model(inits, [_node("Conv", ["image", inits[0][0], inits[1][0]], ["x1"], "/conv1a/Conv")]), 1, True)
+    put("sp_bad.onnx", _model([("conv1a.weight", np.zeros((64, 1, 3, 3), np.float32))], []), 1, False)
+    t = _named(Wt.make_lightglue(seed=6), Wt.lg_manifest()[0])
+    put("lg_named.onnx", _named_lightglue_model(t), 2, True)
+    put("lg_simplified.onnx", _simplified_lightglue(t), 2, True)
+    put("lg_dropped.onnx", _simplified_lightglue(t, drop=(3, "cross.Wv")), 2, False)
+    put("lg_extra.onnx", _simplified_lightglue(t, extra_first=True), 2, False)
+    put("lg_bad.onnx", _model([("posenc.Wr.weight", np.zeros((32, 2), np.float32))], []), 2, False)
+    return out
 
 
 def _simplified_lightglue(t, drop=None, extra_first=False):
