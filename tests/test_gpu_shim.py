@@ -85,7 +85,7 @@ def test_cpp_shims_take_the_references_onnx_paths_unedited(tmp_path, oracle):
     (tmp_path / "onnxmodel").mkdir()
     try:
         _, wsp = X.export_sp(str(tmp_path / "onnxmodel"), X.SETTINGS[1], seed=7, desc_center="auto")
-        _, wlg = X.export_lg(str(tmp_path / "onnxmodel"), 0.25, seed=11, calibrated=True)
+        _, wlg = X.export_lg(str(tmp_path / "onnxmodel"), 0.25, seed=11)
     except X.ExporterUnavailable as e:                         # pragma: no cover
         pytest.skip(str(e))
     frames, _ = synth.make_frames(2, H, W, seed=20240314, max_shift=16, shift_step=8)

@@ -128,7 +128,7 @@ def test_rfe_load_weights_takes_onnx_files(tmp_path, oracle):
     matching equal to the oracle run on the converter's blob"""
     from rover_slam_amd import synth
     sp, wsp = _export(X.export_sp, tmp_path, X.SETTINGS[1], seed=7, desc_center="auto")
-    lg, wlg = _export(X.export_lg, tmp_path, 0.25, seed=11, calibrated=True)
+    lg, wlg = _export(X.export_lg, tmp_path, 0.25, seed=11)     # the seeded law: 40 matches on these small frames (the calibrated one leaves 1 above 0.25)
     ctx = capi.Context(0)
     try:
         ctx.load_weights(sp_path=sp, lg_path=lg)
@@ -146,7 +146,8 @@ def test_rfe_load_weights_takes_onnx_files(tmp_path, oracle):
         k1 = oracle.normalize_keypoints(feats[1]["kxy"][:n[1]].astype(np.float32), 120, 160)
         S, pairs, ms = ctx.match(k0[None], k1[None], desc[0, :n[0]][None], desc[1, :n[1]][None], [int(n[0])], [int(n[1])], filter_thr=hp["lg_filter_threshold"])
         r = oracle.lightglue(wlg, k0, k1, desc[0, :n[0]], desc[1, :n[1]], filter_thr=0.25)
-        assert r["S"] > 10 and S[0] == r["S"] and np.array_equal(pairs[0, :S[0]], r["pairs"]) and np.abs(ms[0, :S[0]] - r["ms"]).max() < 1e-4
+        from tolerances import LG_SCORE_TOL
+        assert r["S"] > 10 and S[0] == r["S"] and np.array_equal(pairs[0, :S[0]], r["pairs"]) and np.abs(ms[0, :S[0]] - r["ms"]).max() < LG_SCORE_TOL
         (tmp_path / "short").mkdir()
         short, _ = X.export_lg(str(tmp_path / "short"), 0.1, n_layers=3)
         with pytest.raises(capi.RfeError, match="3 layers of 4 heads"):
