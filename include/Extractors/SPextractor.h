@@ -80,10 +80,11 @@ protected:
     int ExtractSingleLayer(const cv::Mat& image, std::vector<cv::KeyPoint>& vKeyPoints, cv::Mat& Descriptors) {
         Configuration cfg;
         featureExtractor->lastmatch = lastmatchnum;
-        // NormalizeImage (transform.cpp:11) is fused into the first kernel: hand the u8 rows over directly
-        if (featureExtractor->Extractor_Inference_u8(image.ptr<unsigned char>(0), image.rows, image.cols, (int)image.step) != EXIT_SUCCESS)
-            return (int)vKeyPoints.size();
-        featureExtractor->Extractor_PostProcess(cfg, std::move(featureExtractor->extractor_outputtensors[0]), vKeyPoints, Descriptors);
+        // NormalizeImage (transform.cpp:11) is fused into the first kernel: hand the u8 rows over directly.  Inference + post-processing in one
+        // step (the library writes the descriptors into the cv::Mat this call returns; same results as Extractor_Inference_u8 followed by
+        // Extractor_PostProcess, which stay available: tests/cpp/shim_driver.cpp drives both and compares)
+        (void)cfg;
+        featureExtractor->Extract_u8_direct(image.ptr<unsigned char>(0), image.rows, image.cols, (int)image.step, vKeyPoints, Descriptors);
         return (int)vKeyPoints.size();
     }
 

@@ -85,6 +85,37 @@ public:
     // u8 fast path used by SPextractor::ExtractSingleLayer (NormalizeImage is fused into the first kernel)
     int Extractor_Inference_u8(const unsigned char* img, int H, int W, int stride) { return run_(img, false, H, W, stride); }
 
+    // Extractor_Inference_u8 + Extractor_PostProcess in one step for SPextractor::operator(): the library writes the K x 256 descriptors straight into
+    // a FRESH cv::Mat (a new allocation per frame like the reference's `Descriptors = mat1`, superpoint_onnx.cc:231-244: headers that share the
+    // previous frame's buffer stay valid), the detected n <= K rows are declared afterwards (rowRange: a header, no copy) -- one host copy of the
+    // descriptors per frame (the library's staging block -> the Mat) instead of two (-> tensor -> Mat).  Same field values as
+    // Extractor_PostProcess: pt = (x, y), response = scores[idx], size 10, octave 0; its threshold is the reference's constant 0 (:190), which no
+    // score of the graph's output is below.
+    int Extract_u8_direct(const unsigned char* img, int H, int W, int stride, std::vector<cv::KeyPoint>& vKeyPoints, cv::Mat& Descriptors) {
+        extractor_outputtensors.clear();
+        if (!ExtractorSession) { std::cerr << "[ERROR] Extractor inference failed : no session" << std::endl; return EXIT_FAILURE; }
+        const int K = max_keypoints;
+        if (stage_kxy_.size() < (size_t)K * 2) stage_kxy_.resize((size_t)K * 2);
+        if (stage_score_.size() < (size_t)K) stage_score_.resize((size_t)K);
+        cv::Mat d(K, 256, CV_32F);
+        int32_t n = 0;
+        auto t0 = std::chrono::high_resolution_clock::now();
+        const int rc = rfe_extract_u8(ExtractorSession, img, H, W, stride, 1, K, detection_threshold, &n, stage_kxy_.data(), stage_score_.data(), d.ptr<float>(0));
+        extractor_timer += std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count();
+        if (rc != RFE_OK) { std::cerr << "[ERROR] Extractor inference failed : " << rfe_last_error(ExtractorSession) << std::endl; return EXIT_FAILURE; }
+        vKeyPoints.reserve(vKeyPoints.size() + (size_t)n);
+        for (int i = 0; i < n; ++i) {
+            cv::KeyPoint kp;
+            kp.pt = cv::Point2f((float)stage_kxy_[2 * i], (float)stage_kxy_[2 * i + 1]);
+            kp.response = stage_score_[i];
+            kp.size = 10;
+            kp.octave = 0;
+            vKeyPoints.emplace_back(kp);
+        }
+        Descriptors = n == K ? d : d.rowRange(0, n);
+        return EXIT_SUCCESS;
+    }
+
     // reference superpoint_onnx.cc:88-162: image is a CV_32F single-channel image, normally NormalizeImage's output; like the graph,
     // the kernels take the values as they are (no assumption that they are multiples of 1/255 or inside [0, 1])
     int Extractor_Inference(Configuration, const cv::Mat& image) {
@@ -158,6 +189,7 @@ private:
         return EXIT_SUCCESS;
     }
     std::vector<int32_t> stage_kxy_;
+    std::vector<float> stage_score_;
 
     // blocks of one size, handed out as shared_ptr whose deleter puts them back; the pool outlives the runner while tensors are in flight
     struct PinnedPool : std::enable_shared_from_this<PinnedPool> {

@@ -64,6 +64,7 @@ public:
         return m;
     }
     void release() { buf_.reset(); data = nullptr; rows = cols = 0; }
+    Mat rowRange(int r0, int r1) const { Mat m(*this); m.data = data + step * (size_t)r0; m.rows = r1 - r0; return m; }   // header over the same buffer, like cv::Mat
     Mat getMat() const { return *this; }   // so that Mat doubles as InputArray
 private:
     int type_ = CV_8U;

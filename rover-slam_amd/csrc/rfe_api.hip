@@ -1066,13 +1066,16 @@ extern "C" int rfe_match(rfe_ctx* c, const float* k0n, const float* k1n, const f
     const size_t in_bytes = bk0 + bk1 + bd0 + bd1 + 2 * bi, out_bytes = bi + bp + bs;
     if ((rc = ensure_pin(c, in_bytes + out_bytes))) return rc;
     char* hp = (char*)c->h_pin;
+    // two DMAs, so that the host copy of the second descriptor block (1 MB at K = 1024) runs while the first one is on the bus
     memcpy(hp, k0n, (size_t)P * Mmax * 8);
     memcpy(hp + bk0, k1n, (size_t)P * Nmax * 8);
     memcpy(hp + bk0 + bk1, d0, (size_t)P * Mmax * 1024);
-    memcpy(hp + bk0 + bk1 + bd0, d1, (size_t)P * Nmax * 1024);
-    memcpy(hp + bk0 + bk1 + bd0 + bd1, m, (size_t)P * 4);
-    memcpy(hp + bk0 + bk1 + bd0 + bd1 + bi, n, (size_t)P * 4);
-    RFE_HIP(c, hipMemcpyAsync(c->ws_io, hp, in_bytes, hipMemcpyHostToDevice, s));
+    const size_t first = bk0 + bk1 + bd0;
+    RFE_HIP(c, hipMemcpyAsync(c->ws_io, hp, first, hipMemcpyHostToDevice, s));
+    memcpy(hp + first, d1, (size_t)P * Nmax * 1024);
+    memcpy(hp + first + bd1, m, (size_t)P * 4);
+    memcpy(hp + first + bd1 + bi, n, (size_t)P * 4);
+    RFE_HIP(c, hipMemcpyAsync((char*)c->ws_io + first, hp + first, in_bytes - first, hipMemcpyHostToDevice, s));
     if ((rc = rfe_match_dev(c, dk0, dk1, dd0, dd1, dm, dn, P, Mmax, Nmax, thr, dS, dp, dms))) return rc;
     RFE_HIP(c, hipMemcpyAsync(hp + in_bytes, dS, out_bytes, hipMemcpyDeviceToHost, s));
     RFE_HIP(c, hipStreamSynchronize(s));

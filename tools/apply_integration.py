@@ -225,7 +225,7 @@ def main(argv=None):
         shutil.copy2(cm, cm + ".pre_rfe")
         with open(cm, "w") as f:
             f.write(new)
-        print(f"wrote {cm} (original kept as CMakeLists.txt.pre_rfe); weights: onnxmodel/superpoint.rfew, onnxmodel/lightglue_sim.rfew "
+        print(f"wrote {cm} (original kept as CMakeLists.txt.pre_rfe); model files: the reference's own onnxmodel/superpoint.onnx, onnxmodel/lightglue_sim.onnx (read by librover_fe.so itself; RFEW containers work too) "
               "(python -m rover_slam_amd.onnx_weights converts the .onnx initialisers)")
     problems = check_tree(a.checkout, a.rfe_root, applied=True)
     if problems:

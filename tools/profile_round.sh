@@ -45,5 +45,14 @@ if [ -z "$QUICK" ]; then
   python3 tools/rocpd_stats.py $(find $OUT/trace_c3_fp16x2 -name "*_results.db" | head -1) --gaps > $OUT/stats_c3_fp16x2.md
   rm -rf $OUT/trace_c3_fp16x2
 fi
-find $OUT -name "*_results.db" | head
-cat $OUT/bench.json | cut -c1-1500
+# the summaries are written HERE, on the box (the rocpd databases are far beyond the 64 MiB gpurun merges back): profiles/<rnd>_* -> gpurun_out/<tag>_profiles/
+RND=${TAG:0:3}
+python3 tools/refresh_profiles.py $TAG $RND > $OUT/refresh.log 2>&1
+mkdir -p $R/gpurun_out/${TAG}_profiles
+cp $R/profiles/${RND}_* $R/gpurun_out/${TAG}_profiles/ 2>/dev/null
+cp $OUT/*.json $OUT/*.md $OUT/*.log $OUT/*.err $R/gpurun_out/${TAG}_profiles/ 2>/dev/null
+find $R/gpurun_out -name "*.db" -delete
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
+tail -5 $OUT/refresh.log
+du -sh $R/gpurun_out
+cat $OUT/bench.json | cut -c1-600
