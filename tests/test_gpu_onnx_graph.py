@@ -30,3 +30,20 @@ def test_hip_path_against_recorded_graph_execution(tmp_path, golden_dir, case, c
     assert rc == 0, out
     hip = [l for l in out.splitlines() if " hip:" in l]
     assert len(hip) == 3 and all("same_set=True" in l and "order_ok=True" in l for l in hip[:2]) and "identical=True" in hip[2], out
+
+
+@pytest.mark.gpu
+def test_hip_path_against_live_graph_execution_at_the_benchmark_size(tmp_path, capsys):
+    """no fixture in between: on the GPU box the exported graph files are executed by tools/mini_onnx.py (torch-CPU) at 480 x 640, K = 1024 (top-k cut active),
+    two frames of bench.py's stream, calibrated LightGlue weights -- and librover_fe.so, loaded from the SAME .onnx files through rfe_load_weights' C++ reader
+    (--gpu-onnx), must give the graph's keypoints, descriptors <= 1e-4, matches0 and mscores0 <= 1e-4"""
+    try:
+        sp, lg = G.export_case(str(tmp_path), "s0")
+    except X.ExporterUnavailable as e:                         # pragma: no cover
+        pytest.skip(str(e))
+    rc = P.main(["--superpoint", sp, "--lightglue", lg, "--backend", "mini", "--gpu", "--gpu-onnx", "--frames", "2", "--height", "480", "--width", "640",
+                 "--shift-step", "8", "--mscore-tol", "1e-4", "--min-matches", "100"])
+    out = capsys.readouterr().out
+    assert rc == 0, out
+    hip = [l for l in out.splitlines() if " hip:" in l]
+    assert len(hip) == 3 and all("K_ref=1024 K=1024 same_set=True" in l and "order_ok=True" in l for l in hip[:2]) and "identical=True" in hip[2], out

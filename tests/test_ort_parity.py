@@ -48,6 +48,16 @@ def test_harness_runs_end_to_end_on_graph_execution(tmp_path, golden_dir, case, 
     assert P.main(G.harness_args(case, sp, lg) + ["--backend", "replay", "--replay", os.path.join(golden_dir, f"onnx_{case}.npz")]) == 0
 
 
+def test_harness_at_the_benchmark_size(tmp_path, capsys):
+    """the same, live, at the size bench.py runs: two 480 x 640 frames of its stream (cell-aligned shifts), K = 1024 through the top-k cut, the calibrated
+    LightGlue weights -- oracle against graph execution at 1e-4 with > 100 matches (no fixture: 2 x 1 MB of descriptors per frame)"""
+    sp, lg = _export(tmp_path, "s0")
+    rc = P.main(["--superpoint", sp, "--lightglue", lg, "--backend", "mini", "--frames", "2", "--height", "480", "--width", "640", "--shift-step", "8",
+                 "--mscore-tol", "1e-4", "--min-matches", "100"])
+    out = capsys.readouterr().out
+    assert rc == 0 and "K_ref=1024 K=1024 same_set=True" in out and "identical=True" in out, out
+
+
 def test_replay_refuses_other_weights(tmp_path, golden_dir):
     """a graph file holding other weights than the recording's is not silently compared"""
     try:
