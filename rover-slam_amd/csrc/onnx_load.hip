@@ -148,6 +148,13 @@ bool parse_tensor(const Buf& b, Tensor& t) {
         case 10: t.supported = true; break;   // float16: carried without values (never a weight or a hyper-parameter of the fp32 exports)
         default: t.supported = false; break;
     }
+    // a tensor whose element count is not the product of its dims (a damaged or hostile file) is dropped: every later shape test may then trust dims
+    if (t.has_dims && t.dtype != 10 && t.supported) {
+        unsigned long long prod = 1;
+        bool ok_dims = true;
+        for (auto d : t.dims) { if (d < 0 || (d > 0 && prod > (1ull << 40) / (unsigned long long)d)) { ok_dims = false; break; } prod *= (unsigned long long)d; }
+        if (!ok_dims || prod != (unsigned long long)t.size()) t.supported = false;
+    }
     return true;
 }
 

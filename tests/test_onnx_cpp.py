@@ -157,3 +157,33 @@ def test_rfe_load_weights_takes_onnx_files(tmp_path, oracle):
         assert S2[0] == S[0]
     finally:
         ctx.close()
+
+
+def test_damaged_files_are_refused_not_crashed_on(tmp_path):
+    """truncations, random byte flips and insertions in an exported graph file: the C++ reader either converts (a flip inside a weight payload) or refuses with a
+    reason -- it never reads past a tensor its dims lie about (an element count that is not the product of the dims drops the tensor)"""
+    sp, _ = _export(X.export_sp, tmp_path, X.SETTINGS[0], seed=5)
+    data = bytearray(open(sp, "rb").read())
+    rng = np.random.default_rng(0)
+    p = tmp_path / "m.onnx"
+    refused = 0
+    for it in range(80):
+        d = bytearray(data)
+        if it % 4 == 0:
+            d = d[:int(rng.integers(1, len(d)))]
+        elif it % 4 == 1:
+            for _ in range(int(rng.integers(1, 20))):
+                d[int(rng.integers(0, len(d)))] = int(rng.integers(0, 256))
+        elif it % 4 == 2:
+            pos = int(rng.integers(0, min(len(d), 200000)))
+            d[pos:pos + 8] = bytes(rng.integers(0, 256, 8, dtype=np.uint8))
+        else:
+            pos = int(rng.integers(0, len(d)))
+            d = d[:pos] + bytes(rng.integers(0, 256, int(rng.integers(1, 64)), dtype=np.uint8)) + d[pos:]
+        p.write_bytes(bytes(d))
+        try:
+            cpp_convert(p, 1)
+        except ValueError as e:
+            refused += 1
+            assert str(e)                       # a reason, always
+    assert refused >= 20
