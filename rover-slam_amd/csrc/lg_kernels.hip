@@ -657,7 +657,10 @@ __global__ __launch_bounds__(256) void lg_rowarg_kernel(const float* __restrict_
 // for the row argmax that follows.
 // <32, 8>: throughput shape (L/32 workgroups per pair).  <16, 64>: one or a few pairs -- 1024 threads, 64 workgroups per 1024
 // columns, 16 rows per thread instead of 128 (single pair at K = 1024: 46 + 20 us for the two separate kernels -> one short launch).
-template <int CW, int RG>
+// CACHE (round 5, the one- / few-pair shape with m <= 16 RG rows): a thread's <= 16 values of its column are read ONCE into registers (16 independent
+// loads in flight instead of three dependent walks through L2) -- the arithmetic and every reduction order are those of the walking form, so the
+// results are bit-identical to it; 25.6 -> ~10 us per forward at K = 1024.
+template <int CW, int RG, bool CACHE = false>
 __global__ __launch_bounds__(CW * RG) void lg_col_kernel(const float* __restrict__ sim, const float* __restrict__ z0,
                                                          const float* __restrict__ z1, const float* __restrict__ rowlse, int L,
                                                          const int* __restrict__ m, const int* __restrict__ n,
@@ -668,8 +671,25 @@ __global__ __launch_bounds__(CW * RG) void lg_col_kernel(const float* __restrict
     const int jj = blockIdx.x * CW + c;
     const int mm = m[p], nn = n[p];
     const float* base = sim + (size_t)p * L * L;
+    constexpr int NR = 16;
+    float v[NR], lr[NR], l0[NR];
+    if constexpr (CACHE) {
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            const int i = rg + u * RG;
+            const bool live = jj < nn && i < mm;
+            v[u] = live ? base[(size_t)i * L + jj] : -INFINITY;
+            lr[u] = live ? rowlse[(size_t)p * L + i] : 0.f;
+            l0[u] = live ? z0[(size_t)p * L + i] : 0.f;
+        }
+    }
     float mx = -INFINITY;
-    if (jj < nn) for (int i = rg; i < mm; i += RG) mx = fmaxf(mx, base[(size_t)i * L + jj]);
+    if constexpr (CACHE) {
+#pragma unroll
+        for (int u = 0; u < NR; ++u) mx = fmaxf(mx, v[u]);
+    } else {
+        if (jj < nn) for (int i = rg; i < mm; i += RG) mx = fmaxf(mx, base[(size_t)i * L + jj]);
+    }
     rb[rg][c] = mx;
     __syncthreads();
     float gm = rb[0][c];
@@ -677,7 +697,12 @@ __global__ __launch_bounds__(CW * RG) void lg_col_kernel(const float* __restrict
     for (int g = 1; g < RG; ++g) gm = fmaxf(gm, rb[g][c]);
     __syncthreads();
     float sum = 0.f;
-    if (jj < nn) for (int i = rg; i < mm; i += RG) sum += expf(base[(size_t)i * L + jj] - gm);
+    if constexpr (CACHE) {
+#pragma unroll
+        for (int u = 0; u < NR; ++u) if (jj < nn && rg + u * RG < mm) sum += expf(v[u] - gm);
+    } else {
+        if (jj < nn) for (int i = rg; i < mm; i += RG) sum += expf(base[(size_t)i * L + jj] - gm);
+    }
     rb[rg][c] = sum;
     __syncthreads();
     float t = 0.f;
@@ -689,9 +714,20 @@ __global__ __launch_bounds__(CW * RG) void lg_col_kernel(const float* __restrict
     if (jj < nn) {
         if (rg == 0) collse[(size_t)p * L + jj] = lc;
         const float l1 = z1[(size_t)p * L + jj];
-        for (int i = rg; i < mm; i += RG) {
-            const float sc = lg_score(base[(size_t)i * L + jj], rowlse[(size_t)p * L + i], lc, z0[(size_t)p * L + i], l1);
-            if (sc > best) { best = sc; bi = i; }
+        if constexpr (CACHE) {
+#pragma unroll
+            for (int u = 0; u < NR; ++u) {
+                const int i = rg + u * RG;
+                if (i < mm) {
+                    const float sc = lg_score(v[u], lr[u], lc, l0[u], l1);
+                    if (sc > best) { best = sc; bi = i; }
+                }
+            }
+        } else {
+            for (int i = rg; i < mm; i += RG) {
+                const float sc = lg_score(base[(size_t)i * L + jj], rowlse[(size_t)p * L + i], lc, z0[(size_t)p * L + i], l1);
+                if (sc > best) { best = sc; bi = i; }
+            }
         }
     }
     rb[rg][c] = best; ri[rg][c] = bi;
@@ -832,7 +868,8 @@ void launch_lg_assign(hipStream_t s, const float* sim, const float* z0, const fl
                       const float* x, const float* wm, const float* bm, float* z) {
     if (lg_assign_few_pairs(P, L) && x) {
         hipLaunchKernelGGL(lg_rowlse_z_kernel, dim3((L + 3) / 4, P, 2), dim3(256), 0, s, sim, L, P, m, n, rowlse, x, wm, bm, z);
-        hipLaunchKernelGGL((lg_col_kernel<16, 64>), dim3((L + 15) / 16, P), dim3(1024), 0, s, sim, z0, z1, rowlse, L, m, n, collse, a1);
+        if (L <= 1024) hipLaunchKernelGGL((lg_col_kernel<16, 64, true>), dim3((L + 15) / 16, P), dim3(1024), 0, s, sim, z0, z1, rowlse, L, m, n, collse, a1);   // m <= L <= 16 x 64 rows: the column in registers
+        else hipLaunchKernelGGL((lg_col_kernel<16, 64>), dim3((L + 15) / 16, P), dim3(1024), 0, s, sim, z0, z1, rowlse, L, m, n, collse, a1);
         hipLaunchKernelGGL(lg_rowarg_kernel, dim3((L + 3) / 4, P), dim3(256), 0, s, sim, z0, z1, rowlse, collse, L, m, n, a0, mx0, scores_opt, scores_pair);
         hipLaunchKernelGGL(lg_mutual_kernel, dim3(P), dim3(256), 0, s, a0, mx0, a1, L, cap, m, n, thr, S, pairs, ms);
         return;

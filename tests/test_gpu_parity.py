@@ -435,6 +435,38 @@ def test_two_contexts_concurrently(oracle):
         assert n[0] == r["n"] and np.array_equal(kxy[0], r["kxy"]) and np.array_equal(desc[0], r["desc"])
 
 
+def test_extract_into_pinned_host_memory_is_identical(ctx):
+    """rfe_host_malloc (round 5): a descriptor output inside a block from it is written by the DMA engine directly instead of being staged through the ctx's
+    pinned block and copied on the host -- same bytes, for the u8, the binarised and the float entry, with one and with three frames; a pointer INTO the block
+    (offset) counts, a block that is too small does not (falls back to staging)."""
+    import ctypes as C
+    from rover_slam_amd import capi
+    frames, _ = synth.make_frames(3, 120, 160, seed=31)
+    K = 300
+    for B in (1, 3):
+        n0, k0, s0, d0, b0 = ctx.extract(frames[:B], kmax=K, binarized=True)
+        nf, kf, sf, df = ctx.extract_f32(frames[:B].astype(np.float32) * np.float32(1.0 / 255.0), kmax=K)
+        nbytes = B * K * 1024
+        blk = C.c_void_p()
+        assert capi.lib.rfe_host_malloc(nbytes + 4096, C.byref(blk)) == 0 and blk.value
+        try:
+            for off in (0, 1024):
+                desc = np.ctypeslib.as_array(C.cast(blk.value + off, C.POINTER(C.c_float)), shape=(B, K, 256))
+                n = np.zeros((B,), np.int32); kxy = np.zeros((B, K, 2), np.int32); sc = np.zeros((B, K), np.float32); dbin = np.zeros((B, K, 256), np.uint8)
+                desc[:] = -7.0
+                ctx._chk(capi.lib.rfe_extract_u8_bin(ctx.h, frames[:B].ctypes.data, 120, 160, 160, B, K, 0.0005, n.ctypes.data, kxy.ctypes.data, sc.ctypes.data,
+                                                     blk.value + off, dbin.ctypes.data))
+                assert np.array_equal(n, n0) and np.array_equal(kxy, k0) and np.array_equal(sc, s0) and np.array_equal(desc, d0) and np.array_equal(dbin, b0)
+                desc[:] = -7.0
+                img = np.ascontiguousarray(frames[:B].astype(np.float32) * np.float32(1.0 / 255.0))
+                ctx._chk(capi.lib.rfe_extract_f32(ctx.h, img.ctypes.data, 120, 160, 160, B, K, 0.0005, n.ctypes.data, kxy.ctypes.data, sc.ctypes.data, blk.value + off))
+                assert np.array_equal(n, nf) and np.array_equal(desc, df)
+        finally:
+            capi.lib.rfe_host_free(blk)
+    assert capi.lib.rfe_host_malloc(0, C.byref(blk)) != 0            # bad argument, not a crash
+    capi.lib.rfe_host_free(None)                                      # no-op
+
+
 def test_error_paths(ctx):
     from rover_slam_amd import capi
     c = capi.Context(0)
