@@ -363,12 +363,16 @@ typedef const __attribute__((address_space(1))) void* conv_gptr_t;
 constexpr int T16D_WROWS = 144, T16D_PIX = 128;    // ring-stage capacities: weight rows (18 copy slots of 8), pixels (108 used: 8 slots of 16); 3 x 26 KB = 78 KB
 __device__ __attribute__((aligned(64))) float t16d_zero_line[16];   // zero-initialised: the source of every out-of-image pixel
 
-template <int CIN, bool RELU>
+// NC: output channels per workgroup, 32 (two accumulator chains per wave) or 16 (ONE chain per wave, twice the workgroups: round 5, for the launches whose
+// 32-channel grid leaves SIMDs idle or badly balanced -- a 60 x 80 layer of one frame is 300 workgroups for 256 CUs; the arithmetic and its order are the same).
+template <int CIN, bool RELU, int NC = T16_NC>
 __global__ __launch_bounds__(256, 2) void conv3x3_t16d_kernel(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ out, int H, int W, int COUT, int gx, int gy, int ntiles) {
+    static_assert(NC == 32 || NC == 16, "32 or 16 output channels per workgroup");
+    constexpr int NB = NC / 16;                                                 // accumulator chains per wave
     constexpr int NST = CIN / T16_CK;                                           // 16 channels = 144 kappa per stage
-    constexpr int IST_W = T16D_PIX * T16_CK, WST_W = T16D_WROWS * T16_NC;        // 2048 + 5120 words per stage
+    constexpr int IST_W = T16D_PIX * T16_CK, WST_W = T16D_WROWS * NC;            // 2048 + 5120 (2560) words per stage
     // dynamic LDS on purpose (a static array makes the compiler order every ds_read behind ALL outstanding copies): 3 x (8 + 20) KB
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const lin = lds;
@@ -376,15 +380,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_t16d_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = lane & 15, q = lane >> 4;
-    const ConvBlock blk = conv_decode(COUT / T16_NC, gx, gy, ntiles);
+    const ConvBlock blk = conv_decode(COUT / NC, gx, gy, ntiles);
     if (!blk.valid) return;
     const int b = blk.b, ct = blk.ct;
     const int x0 = blk.bx * T16_W, y0 = blk.by * T16_H;
-    const int co0 = ct * T16_NC;
+    const int co0 = ct * NC;
 
-    f32x4 acc[2];
+    f32x4 acc[NB];
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) acc[nb] = *reinterpret_cast<const f32x4*>(bias + co0 + nb * 16 + 4 * q);
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = *reinterpret_cast<const f32x4*>(bias + co0 + nb * 16 + 4 * q);
     // pixel-operand addressing of the 9 k-steps of a 36-kappa period (4 input channels = granule c4 of the stage): kappa = 4 s + q ->
     // (channel e = kappa / 9 inside the granule, tap) -> haloed pixel p; word = p * 16 + ((c4 ^ swizzle(p)) << 2) + e
     int pbase[9], pswz[9];
@@ -396,15 +400,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_t16d_kernel(
         pswz[s9] = (p >> 2) & 3;
     }
     const float* in_b = in + (size_t)b * H * W * CIN;
-    const float* wp_ct = wp + (size_t)(ct >> 1) * (CIN / 8) * 72 * NT + (ct & 1) * T16_NC;
+    const float* wp_ct = wp + (size_t)(ct / (NT / NC)) * (CIN / 8) * 72 * NT + (ct % (NT / NC)) * NC;
 
-    // weight copies: lane -> row lane >> 3, 16-byte piece lane & 7; 18 slots of 8 rows; wave w issues slots w, w + 4, .. -- five each, so that the
-    // vector-memory counter advances alike in every wave: the fifth of waves 2, 3 repeats their fourth (same data to the same place)
-    int w_off[5], w_slot[5];
+    // weight copies: a row of the stage is NC floats (128 B / 64 B): lane -> row lane / PCS, 16-byte piece lane % PCS; 144 rows = 18 slots of 8 rows (NC = 32) or
+    // 9 slots of 16 rows (NC = 16); wave w issues slots w, w + 4, .. -- WCP each, so that the vector-memory counter advances alike in every wave: a surplus
+    // copy repeats the wave's previous one (same data to the same place)
+    constexpr int PCS = NC / 4, RPS = 64 / PCS, NSLOT = T16D_WROWS / RPS, WCP = (NSLOT + 3) / 4;   // pieces per row, rows per slot, slots, copies per wave
+    int w_off[WCP], w_slot[WCP];
 #pragma unroll
-    for (int u = 0; u < 5; ++u) {
-        w_slot[u] = wave + 4 * u < 18 ? wave + 4 * u : wave + 4 * (u - 1);
-        w_off[u] = (w_slot[u] * 8 + (lane >> 3)) * NT + (lane & 7) * 4;
+    for (int u = 0; u < WCP; ++u) {
+        w_slot[u] = wave + 4 * u < NSLOT ? wave + 4 * u : wave + 4 * (u - 1);
+        w_off[u] = (w_slot[u] * RPS + lane / PCS) * NT + (lane % PCS) * 4;
     }
     // input copies: lane -> pixel slot * 16 + (lane >> 2), physical granule lane & 3; wave w issues slots w, w + 4 (pixels >= 108: padding)
     const float* i_src[2];
@@ -423,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_t16d_kernel(
         float* wdst = lwr + (st % 3) * WST_W;
         float* idst = lin + (st % 3) * IST_W;
 #pragma unroll
-        for (int u = 0; u < 5; ++u)
+        for (int u = 0; u < WCP; ++u)
             __builtin_amdgcn_global_load_lds((conv_gptr_t)(src + w_off[u]), (conv_lds_ptr_t)(wdst + w_slot[u] * 256), 16, 0, 0);
 #pragma unroll
         for (int u = 0; u < 2; ++u)
@@ -432,34 +438,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_t16d_kernel(
     issue(0);
     if (NST > 1) issue(1);
     for (int st = 0; st < NST; ++st) {
-        // stage st has landed (this wave's copies: the 7 of stage st + 1 may still be in flight; everybody's: barrier), and every wave has left
+        // stage st has landed (this wave's copies: the WCP + 2 of stage st + 1 may still be in flight; everybody's: barrier), and every wave has left
         // stage st - 1, whose buffers the next request reuses
-        if (st + 1 < NST) asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory");
+        if (st + 1 < NST) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(WCP + 2) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         if (st + 2 < NST) issue(st + 2);
         const float* li = lin + (st % 3) * IST_W;
         const float* lw = lwr + (st % 3) * WST_W + px;
 #pragma unroll
         for (int c4 = 0; c4 < T16_CK / 4; ++c4) {          // 4 input channels = 36 kappa = 9 k-steps
-            const float* bp = lw + (c4 * 36 + q) * T16_NC;
+            const float* bp = lw + (c4 * 36 + q) * NC;
 #pragma unroll
             for (int s9 = 0; s9 < 9; ++s9) {
                 const float pv = li[pbase[s9] + ((c4 ^ pswz[s9]) << 2)];
-                const float w0 = bp[4 * s9 * T16_NC], w1 = bp[4 * s9 * T16_NC + 16];
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, pv, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, pv, acc[1], 0, 0, 0);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bp[4 * s9 * NC + 16 * nb], pv, acc[nb], 0, 0, 0);
             }
         }
     }
     if (RELU) {
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) { acc[nb][0] = fmaxf(acc[nb][0], 0.f); acc[nb][1] = fmaxf(acc[nb][1], 0.f); acc[nb][2] = fmaxf(acc[nb][2], 0.f); acc[nb][3] = fmaxf(acc[nb][3], 0.f); }
+        for (int nb = 0; nb < NB; ++nb) { acc[nb][0] = fmaxf(acc[nb][0], 0.f); acc[nb][1] = fmaxf(acc[nb][1], 0.f); acc[nb][2] = fmaxf(acc[nb][2], 0.f); acc[nb][3] = fmaxf(acc[nb][3], 0.f); }
     }
     const int y = y0 + wave, x = x0 + px;
     if (y < H && x < W) {
         float* o = out + (((size_t)b * H + y) * W + x) * COUT + co0 + 4 * q;
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) *reinterpret_cast<f32x4*>(o + nb * 16) = acc[nb];
+        for (int nb = 0; nb < NB; ++nb) *reinterpret_cast<f32x4*>(o + nb * 16) = acc[nb];
     }
 }
 
@@ -698,6 +703,23 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
     if (ck8 && relu && !pool && (long long)gx * gy * B * (cout / NT) < small_thr && (cin == 64 || cin == 128) &&
         (long long)B * H * W <= (cin == 64 ? t16_px64 : t16_px) && cout % T16_NC == 0) {
         const int sx = (W + T16_W - 1) / T16_W, sy = (H + T16_H - 1) / T16_H;
+        // 16 output channels per workgroup (one accumulator chain per wave, twice the workgroups, 48 KB of LDS: three workgroups per CU) while the
+        // 32-channel grid is below nc16_thr workgroups: a 60 x 80 layer of ONE frame is 300 (conv4a / 4b) or 600 (convPa / Da) workgroups of 32 channels
+        // for 256 CUs x 2 -- 88 CUs run three, 168 run two, and a wave alone on its SIMD issues its chain at 40 instead of 32 cycles
+        static const int nc16_thr = tune_int("RFE_CONV_T16_NC16", 1300);   // 0 disables (tuning build A/B)
+        if ((long long)sx * sy * B * (cout / T16_NC) < nc16_thr && cout % 16 == 0) {
+            const dim3 g16(conv_grid(sx, sy, B, cout / 16));
+            constexpr int b16 = 3 * (T16D_PIX * T16_CK + T16D_WROWS * 16) * 4;        // 51 KB
+            static bool l16_[2][64];
+            if (cin == 128) {
+                ensure_dynamic_lds((const void*)conv3x3_t16d_kernel<128, true, 16>, b16, l16_[0]);
+                hipLaunchKernelGGL((conv3x3_t16d_kernel<128, true, 16>), g16, dim3(256), b16, s, in, wp, bias, out, H, W, cout, sx, sy, sx * sy * B);
+            } else {
+                ensure_dynamic_lds((const void*)conv3x3_t16d_kernel<64, true, 16>, b16, l16_[1]);
+                hipLaunchKernelGGL((conv3x3_t16d_kernel<64, true, 16>), g16, dim3(256), b16, s, in, wp, bias, out, H, W, cout, sx, sy, sx * sy * B);
+            }
+            return;
+        }
         const dim3 gs(conv_grid(sx, sy, B, cout / T16_NC));
         constexpr int bytes = 3 * (T16D_PIX * T16_CK + T16D_WROWS * T16_NC) * 4;   // 78 KB: two workgroups per CU
         static bool ls_[2][64];
