@@ -129,12 +129,14 @@ __global__ __launch_bounds__(64 * F2_NW, 1) void ffn2_ln_lat_kernel(const float*
     for (int t = 0; t < T; ++t) {
         // stage t has landed (this wave's copies: counted wait -- the younger stages stay in flight; everybody's: barrier, which at t = 0 also
         // publishes the normalised panel), and every wave has left stage t - 1, whose buffer the next request reuses
+        __builtin_amdgcn_sched_barrier(0);   // nothing of stage t is read above its wait + barrier (the machine scheduler moves ds_reads across the asm statement otherwise)
         {
             int younger = T - 1 - t; younger = younger < F2_ST - 2 ? younger : F2_ST - 2;
             if (younger == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * F2_NDMA) : "memory");
             else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(F2_NDMA) : "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (t + F2_ST - 1 < T) issue(t + F2_ST - 1, (t + F2_ST - 1) % F2_ST);
         const float* const ws = wfrag + (t % F2_ST) * F2_STAGE_F;
         const float* const as = afrag + t * (F2_BM * F2_LBK);

@@ -701,6 +701,8 @@ int sp_forward_maps(rfe_ctx* c, const void* img, int H, int W, int stride, int B
     { ProfScope p(c, "convDb", sd); launch_gemm_nt(sd, gemm_plain(b.da, 256, w.packed[L_DB], 256, w.bias[L_DB], b.dmap, 256, cells, 256, 256)); }
     { ProfScope p(c, "sp_post", sd); launch_descmap_norm(sd, b.dmap, cells); }
     if (fork) RFE_HIP(c, hipEventRecord(c->ev_join, sd));
+    static const bool join_early = tune_env("RFE_SP_JOIN_EARLY") != nullptr;   // tuning build: two streams, but the heads one after the other (diagnostic)
+    if (fork && join_early) RFE_HIP(c, hipStreamWaitEvent(s, c->ev_join, 0));
     { ProfScope p(c, "convPa"); launch_conv3x3(s, b.f4, B, Hc, Wc, 128, w.packed[L_PA], w.bias[L_PA], 256, true, false, b.pa, L_PA); }
     { ProfScope p(c, "convPb"); launch_gemm_nt(s, gemm_plain(b.pa, 256, w.packed[L_PB], 256, w.bias[L_PB], b.logits, 65, cells, 65, 256)); }
     { ProfScope p(c, "sp_post");

@@ -440,8 +440,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_t16d_kernel(
     for (int st = 0; st < NST; ++st) {
         // stage st has landed (this wave's copies: the WCP + 2 of stage st + 1 may still be in flight; everybody's: barrier), and every wave has left
         // stage st - 1, whose buffers the next request reuses
+        // The sched_barriers pin the wait + barrier against the machine scheduler: with the stage loop fully unrolled it hoisted the first LDS read of stage
+        // st ABOVE this barrier (found in round 5: the 16-channel form gave wrong descriptor rows whenever the two heads ran concurrently -- the read
+        // raced the copy it was waiting for; the "memory" clobber of the asm statement does not stop the post-RA scheduler)
+        __builtin_amdgcn_sched_barrier(0);
         if (st + 1 < NST) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(WCP + 2) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
         if (st + 2 < NST) issue(st + 2);
         const float* li = lin + (st % 3) * IST_W;
         const float* lw = lwr + (st % 3) * WST_W + px;
@@ -706,18 +711,16 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
         // 16 output channels per workgroup (one accumulator chain per wave, twice the workgroups, 48 KB of LDS: three workgroups per CU) while the
         // 32-channel grid is below nc16_thr workgroups: a 60 x 80 layer of ONE frame is 300 (conv4a / 4b) or 600 (convPa / Da) workgroups of 32 channels
         // for 256 CUs x 2 -- 88 CUs run three, 168 run two, and a wave alone on its SIMD issues its chain at 40 instead of 32 cycles
-        static const int nc16_thr = tune_int("RFE_CONV_T16_NC16", 1300);   // 0 disables (tuning build A/B)
-        if ((long long)sx * sy * B * (cout / T16_NC) < nc16_thr && cout % 16 == 0) {
+        // Measured on one box (tools/tune_sweep.py, 200 steps, off / 700 / 1300 / 2500): one 640 x 480 frame 0.630 -> 0.605 ms (conv4a / 4b 28.7 -> 22.3 us,
+        // convPa / Da 45 -> 33.7), one pair 2.314 -> 2.276, one 752 x 480 stereo frame 2.517 -> 2.487 (2500: convPa / Da of two 60 x 94 maps too); the
+        // 64-channel-input layer (conv3a of one frame, 1200 workgroups) does not gain (36.6 -> 37.2 us) and keeps 32.
+        static const int nc16_thr = tune_int("RFE_CONV_T16_NC16", 2500);   // 0 disables (tuning build A/B)
+        if (cin == 128 && (long long)sx * sy * B * (cout / T16_NC) < nc16_thr && cout % 16 == 0) {
             const dim3 g16(conv_grid(sx, sy, B, cout / 16));
             constexpr int b16 = 3 * (T16D_PIX * T16_CK + T16D_WROWS * 16) * 4;        // 51 KB
             static bool l16_[2][64];
-            if (cin == 128) {
-                ensure_dynamic_lds((const void*)conv3x3_t16d_kernel<128, true, 16>, b16, l16_[0]);
-                hipLaunchKernelGGL((conv3x3_t16d_kernel<128, true, 16>), g16, dim3(256), b16, s, in, wp, bias, out, H, W, cout, sx, sy, sx * sy * B);
-            } else {
-                ensure_dynamic_lds((const void*)conv3x3_t16d_kernel<64, true, 16>, b16, l16_[1]);
-                hipLaunchKernelGGL((conv3x3_t16d_kernel<64, true, 16>), g16, dim3(256), b16, s, in, wp, bias, out, H, W, cout, sx, sy, sx * sy * B);
-            }
+            ensure_dynamic_lds((const void*)conv3x3_t16d_kernel<128, true, 16>, b16, l16_[0]);
+            hipLaunchKernelGGL((conv3x3_t16d_kernel<128, true, 16>), g16, dim3(256), b16, s, in, wp, bias, out, H, W, cout, sx, sy, sx * sy * B);
             return;
         }
         const dim3 gs(conv_grid(sx, sy, B, cout / T16_NC));

@@ -435,6 +435,22 @@ def test_two_contexts_concurrently(oracle):
         assert n[0] == r["n"] and np.array_equal(kxy[0], r["kxy"]) and np.array_equal(desc[0], r["desc"])
 
 
+@pytest.mark.parametrize("B,H,W,K", [(5, 120, 160, 128), (3, 200, 152, 48), (4, 120, 160, 300), (2, 480, 640, 1024)])
+def test_extract_is_repeatable_when_the_heads_overlap(ctx, oracle, B, H, W, K):
+    """Regression (round 5): the descriptor head runs on a side stream next to the detector head; with the 16-channel form of conv3x3_t16d_kernel the heads
+    overlapped differently and a latent race showed -- an LDS read hoisted by the machine scheduler above the barrier that orders it behind its LDS-DMA copy
+    (tests/test_isa_screen.py is the static screen).  Ten calls must give identical bytes, and the oracle's."""
+    frames, _ = synth.make_frames(B, H, W, seed=11)
+    first = ctx.extract(frames, kmax=K)
+    for _ in range(9):
+        again = ctx.extract(frames, kmax=K)
+        assert all(np.array_equal(a, b) for a, b in zip(first, again))
+    w = Wt.make_superpoint(seed=7)
+    for i in (0, B - 1):
+        r = oracle.superpoint(w, frames[i], kmax=K)
+        assert first[0][i] == r["n"] and np.array_equal(first[1][i], r["kxy"]) and np.array_equal(first[3][i], r["desc"])
+
+
 def test_extract_into_pinned_host_memory_is_identical(ctx):
     """rfe_host_malloc (round 5): a descriptor output inside a block from it is written by the DMA engine directly instead of being staged through the ctx's
     pinned block and copied on the host -- same bytes, for the u8, the binarised and the float entry, with one and with three frames; a pointer INTO the block
