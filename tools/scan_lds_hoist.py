@@ -12,6 +12,8 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WAR = "--war" in sys.argv     # also flag copy REQUESTS between a stage's last matrix instruction and the next barrier (informational: a request that belongs to the
+                              # prologue of a ring, or one whose destination stage every wave left a barrier earlier, is legitimate there)
 
 
 def scan(asm_text):
@@ -27,7 +29,7 @@ def scan(asm_text):
         if "s_barrier" in ln and kern:
             j, reads = i - 1, []
             while j > 0 and "v_mfma" not in txt[j] and "s_barrier" not in txt[j] and not re.match(r"^_Z\w+:", txt[j]) and i - j < 40:
-                if re.search(r"\bds_read", txt[j]):
+                if re.search(r"\bds_read", txt[j]) or (WAR and "global_load_lds" in txt[j]):
                     reads.append(txt[j].strip())
                 j -= 1
             if reads and "v_mfma" in txt[j]:
