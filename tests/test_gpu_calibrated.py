@@ -97,6 +97,20 @@ def test_batch16_k1024_calibrated_1e4(ctx, oracle, wcal):
         d.free()
 
 
+@pytest.mark.parametrize("tag", ["e", "f"])
+def test_one_pair_vs_hf_fixture_calibrated_1e4(ctx, golden_dir, tag):
+    """the HIP path against HuggingFace transformers' LightGlue on the calibrated law (tests/golden/lg_e.npz, lg_f.npz; tools/gen_golden.py calibrated):
+    an implementation that shares no code with this repo -- identical match lists, scores within 1e-4"""
+    import gen_golden as G
+    g = np.load(f"{golden_dir}/lg_{tag}.npz")
+    k0, k1, d0, d1, _ = G.calibrated_case(tag)
+    S, pairs, ms = ctx.match(k0[None], k1[None], d0[None], d1[None], [len(k0)], [len(k1)])
+    assert S[0] == len(g["pairs"]) and np.array_equal(pairs[0, :S[0]], g["pairs"])
+    dev = float(np.abs(ms[0, :S[0]] - g["ms"]).max())
+    assert dev < LG_SCORE_TOL_CALIBRATED, dev
+    print(f"HIP vs HF (calibrated law, lg_{tag}): {S[0]} matches, lists identical, max |score dev| {dev:.2e}")
+
+
 def _run_stream(ctx, frames, K, filter_thr=0.1):
     from rover_slam_amd import capi
     B, H, W = frames.shape

@@ -98,6 +98,23 @@ def test_lightglue_oracle_vs_golden_fullsize(oracle, golden_dir, tag):
     assert all(inv[i] == j for i, j in r["pairs"])       # set 1 is a permuted noisy copy of set 0: every match is a true one
 
 
+@pytest.mark.parametrize("tag", ["e", "f"])
+def test_lightglue_oracle_vs_golden_calibrated_1e4(oracle, golden_dir, tag):
+    """Round 5: HF transformers on the CALIBRATED LightGlue law (log-assignment in the range trained weights live in) at 1024 x 1024 and ragged 700 x 1024:
+    the oracle agrees with that independent implementation to north_star's 1e-4 (measured ~1e-5), lists identical, ~1000 / ~700 true matches."""
+    import gen_golden as G
+    from tolerances import LG_SCORE_TOL_CALIBRATED
+    g = np.load(f"{golden_dir}/lg_{tag}.npz")
+    k0, k1, d0, d1, perm = G.calibrated_case(tag)
+    assert np.array_equal(perm, g["perm"])
+    r = oracle.lightglue(Wt.make_lightglue(seed=11, calibrated=True), k0, k1, d0, d1, debug=True)
+    assert np.array_equal(r["pairs"], g["pairs"]) and len(g["pairs"]) > 0.9 * min(len(k0), len(k1))
+    assert np.abs(r["ms"] - g["ms"]).max() < LG_SCORE_TOL_CALIBRATED
+    assert np.abs(r["x0"][::16] - g["x0_rows16"]).max() < 1e-5 and np.abs(r["x1"][::16] - g["x1_rows16"]).max() < 1e-5
+    inv = np.argsort(g["perm"])
+    assert all(inv[i] == j for i, j in r["pairs"])
+
+
 def test_topk_order_and_padding(oracle, golden_dir):
     g = np.load(f"{golden_dir}/sp_b.npz")
     w = Wt.make_superpoint(seed=int(g["seed"]))

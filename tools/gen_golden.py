@@ -227,6 +227,34 @@ def main_fullsize():
         print(f"lg_{tag}: {M} x {N} matches={len(hf['pairs'])}")
 
 
+def calibrated_case(tag):
+    """inputs of the calibrated-weight fixtures lg_e / lg_f, regenerated from the seed by generator and tests alike (the fixtures hold outputs only)"""
+    M, N, seed = {"e": (1024, 1024, 2025), "f": (700, 1024, 2026)}[tag]
+    rng = np.random.default_rng(seed)
+    d0 = rng.standard_normal((1024, 256)).astype(np.float32)
+    d0 /= np.linalg.norm(d0, axis=1, keepdims=True)
+    perm = rng.permutation(1024)
+    d1 = d0[perm] + 0.01 * rng.standard_normal((1024, 256)).astype(np.float32)
+    d1 = (d1 / np.linalg.norm(d1, axis=1, keepdims=True)).astype(np.float32)[:N]
+    k0 = rng.uniform(-0.9, 0.9, (1024, 2)).astype(np.float32)
+    k1 = (k0[perm] + 0.02 * rng.standard_normal((1024, 2))).astype(np.float32)[:N]
+    return np.ascontiguousarray(k0[:M]), k1, np.ascontiguousarray(d0[:M]), d1, perm
+
+
+def main_calibrated():
+    """Round 5: the HF modules on the CALIBRATED LightGlue law (weights.make_lightglue(calibrated=True): logits in the range trained weights live in) at
+    M = N = 1024 and ragged 700 x 1024 -- an independent implementation for north_star's 1e-4 bar (tests/test_oracle_golden.py, tests/test_gpu_calibrated.py)."""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    mods = hf_lightglue_modules(Wt.make_lightglue(seed=11, calibrated=True))
+    for tag in ("e", "f"):
+        k0, k1, d0, d1, perm = calibrated_case(tag)
+        hf = run_hf_lightglue(mods, k0, k1, d0, d1)
+        np.savez_compressed(os.path.join(GOLD, f"lg_{tag}.npz"), seed=11, calibrated=1, perm=perm, x0_rows16=hf["x0"][::16], x1_rows16=hf["x1"][::16],
+                            pairs=hf["pairs"], ms=hf["ms"])
+        print(f"lg_{tag}: {len(k0)} x {len(k1)} matches={len(hf['pairs'])}")
+
+
 def main_oddsize():
     """Image sizes that are not multiples of 8 (the reference graph has dynamic axes; KITTI is 1241 x 376): sp_f = 376 x 1241 through
     the top-k path, sp_g = 101 x 151 with every candidate kept.  The pools floor, the score map is 8*(H/8) x 8*(W/8)."""
@@ -247,5 +275,7 @@ if __name__ == "__main__":
         main_fullsize()
     elif len(sys.argv) > 1 and sys.argv[1] == "oddsize":
         main_oddsize()
+    elif len(sys.argv) > 1 and sys.argv[1] == "calibrated":
+        main_calibrated()
     else:
         main()
