@@ -411,7 +411,7 @@ def latency_resident(ctx, capi, synth, sharding, torch, dev, frames, steps=50, w
     return out
 
 
-def latency_dropin(synth, wsp, wlg, pair_np, steps=50, warmup=5, check=True, tol=None):
+def latency_dropin(synth, wsp, wlg, pair_np, steps=50, warmup=5, check=True, tol=None, host_graph=False):
     """`latency.dropin`: the same three configurations through the C++ drop-in classes with HOST pointers in and out -- what a
     Rover-SLAM Tracking thread sees (SPextractor::operator(), src/Extractors/SPextractor.cc:516-617; SPmatcher::MatchingPoints_onnx(Frame&,
     Frame&), src/Matchers/SPmatcher.cc:457-542; stereo pair of extractor threads, src/Frame.cc:142-147) -- timed by a compiled driver
@@ -433,6 +433,8 @@ def latency_dropin(synth, wsp, wlg, pair_np, steps=50, warmup=5, check=True, tol
         numa = gpu_numa(0)
         if numa and numa.get("local_cpulist") and "RFE_LAT_CPULIST" not in env and os.environ.get("RFE_LAT_NO_PIN") != "1":
             env["RFE_LAT_CPULIST"] = numa["local_cpulist"]       # the driver runs on the CPUs local to the GPU (see lat_driver.cpp)
+        if host_graph:
+            env["RFE_HOST_GRAPH"] = "1"
         r = subprocess.run([exe, os.path.join(d, "pair.u8"), os.path.join(d, "stereo.u8"), str(T), str(steps), str(warmup), os.path.join(d, "out.bin")],
                            env=env, capture_output=True, text=True, timeout=600)
         if r.returncode != 0:
@@ -1066,6 +1068,12 @@ def main():
                                                tol=lg_tol)
         except Exception as e:
             latency["dropin"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        try:    # the same driver with RFE_OPT_HOST_GRAPH on (default off): every host entry submits ONE replayed hipGraph per call; results checked the same way
+            hg = latency_dropin(synth, wsp, wlg, frames_np, steps=max(args.latency_steps, 500), warmup=20, check=not args.no_cpu_baseline, tol=lg_tol, host_graph=True)
+            latency["dropin_host_graph"] = {k: hg[k] for k in ("c2_ms", "c3_ms", "c5_ms", "per_call_ms", "verified_against_oracle", "error") if k in hg}
+            latency["dropin_host_graph"]["note"] = "RFE_OPT_HOST_GRAPH = 1 (include/rover_fe.h): a tail-latency option, not the default; the device is busy 98 % of a one-pair call either way"
+        except Exception as e:
+            latency["dropin_host_graph"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         # the same device-resident calls with RFE_OPT_LG_FP16X2 on (default off, never the headline): at one pair the Linears take the split form of
         # the latency tiles (gemm_lat.hip, H2) and the attention the split form of lg_attention_lat.hip.  SuperPoint (c2) is unaffected and not repeated.
         try:
@@ -1079,7 +1087,7 @@ def main():
             latency["resident_fp16x2"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         finally:
             ctx.set_option(capi.OPT_LG_FP16X2, 0)
-        for k in ("resident", "dropin", "resident_fp16x2"):
+        for k in ("resident", "dropin", "dropin_host_graph", "resident_fp16x2"):
             if "error" in latency[k]:
                 print(f"bench.py: latency.{k} failed: {latency[k]['error']}", file=sys.stderr)
         step(); fence()      # the resident results are those of the bench batch again (cpu_baseline checks them)

@@ -73,6 +73,7 @@ public:
         }
         rfe_hparams hp;
         if (rfe_get_hparams(ExtractorSession, &hp) == RFE_OK) { max_keypoints = hp.sp_max_keypoints; detection_threshold = hp.sp_detection_threshold; }
+        if (const char* e = std::getenv("RFE_HOST_GRAPH")) rfe_set_option(ExtractorSession, RFE_OPT_HOST_GRAPH, std::atoi(e));   // deployment switch, see rover_fe.h
         return EXIT_SUCCESS;
     }
 

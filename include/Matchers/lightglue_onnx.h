@@ -61,6 +61,7 @@ public:
         }
         rfe_hparams hp;
         if (rfe_get_hparams(MatcherSession, &hp) == RFE_OK) filter_threshold = hp.lg_filter_threshold;
+        if (const char* e = std::getenv("RFE_HOST_GRAPH")) rfe_set_option(MatcherSession, RFE_OPT_HOST_GRAPH, std::atoi(e));   // deployment switch, see rover_fe.h
         return EXIT_SUCCESS;
     }
 

@@ -59,6 +59,43 @@ bool is_lib_pinned(const void* p, size_t bytes) {
     return false;
 }
 
+// RFE_OPT_HOST_GRAPH: run `enqueue` (the kernel launches of a host entry, on c->stream and -- forked and joined by events -- c->side_stream) as a replayed
+// hipGraph.  First call of a key: ordinary launches (workspaces grow, function attributes are set -- neither is legal inside a capture).  Second call:
+// the same launches under hipStreamBeginCapture, instantiated, launched.  From then on one hipGraphLaunch per call.  Anything the kernel arguments bake in
+// is part of the key (shape, thresholds, workspace addresses, settings_gen); profiling and the test tap fall back to ordinary launches.  A failed capture
+// or instantiation falls back too -- the option never changes results, only how the work is submitted.
+template <typename F>
+int run_host_graph(rfe_ctx* c, rfe_ctx::HostGraph& g, const std::string& key, F&& enqueue) {
+    if (!c->opt_host_graph || c->prof || c->tap.armed) return enqueue();
+    if (g.exec && g.key == key) { RFE_HIP(c, hipGraphLaunch(g.exec, c->stream)); return RFE_OK; }
+    if (g.seen != key) { g.seen = key; return enqueue(); }
+    if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; g.key.clear(); }
+    if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return enqueue(); }
+    const int rc = enqueue();
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(c->stream, &graph);
+    if (rc != RFE_OK || e != hipSuccess || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        g.seen.clear();
+        return rc != RFE_OK ? rc : enqueue();          // nothing ran during the capture: submit it the ordinary way
+    }
+    const hipError_t ei = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) { g.exec = nullptr; (void)hipGetLastError(); g.seen.clear(); return enqueue(); }
+    g.key = key;
+    RFE_HIP(c, hipGraphLaunch(g.exec, c->stream));
+    return RFE_OK;
+}
+static std::string host_graph_key(const rfe_ctx* c, const char* kind, std::initializer_list<long long> v) {
+    std::string k = kind;
+    for (long long x : v) { k += '|'; k += std::to_string(x); }
+    k += "|g" + std::to_string(c->settings_gen) + "|" + std::to_string((unsigned long long)(uintptr_t)c->ws_sp) + "|" + std::to_string((unsigned long long)(uintptr_t)c->ws_lg) +
+         "|" + std::to_string((unsigned long long)(uintptr_t)c->ws_io) + "|" + std::to_string((unsigned long long)(uintptr_t)c->sp_hold.get()) + "|" +
+         std::to_string((unsigned long long)(uintptr_t)c->lg_hold.get());
+    return k;
+}
+
 ProfScope::ProfScope(rfe_ctx* ctx, const char* name, hipStream_t on) : c(ctx), idx(-1), st(on ? on : ctx->stream) {
     if (!c->prof) return;
     if (!c->prof_filter.empty() && c->prof_filter != name) return;
@@ -142,6 +179,8 @@ extern "C" void rfe_destroy(rfe_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->g_extract.exec) (void)hipGraphExecDestroy(c->g_extract.exec);
+    if (c->g_match.exec) (void)hipGraphExecDestroy(c->g_match.exec);
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
     c->sp_hold.reset(); c->lg_hold.reset();   // the last ctx holding a device copy frees it
     fr(c->ws_sp); fr(c->ws_lg); fr(c->ws_io); fr(c->ws_tmp); fr(c->ws_st);
@@ -156,8 +195,9 @@ extern "C" void rfe_destroy(rfe_ctx* c) {
 extern "C" int rfe_set_option(rfe_ctx* c, int option, int value) {
     if (!c) return RFE_ERR_INVALID;
     switch (option) {
-        case RFE_OPT_LG_FOLD_WO: c->opt_lg_fold = value != 0; return RFE_OK;
-        case RFE_OPT_LG_FP16X2: c->opt_lg_fp16x2 = value != 0; return RFE_OK;
+        case RFE_OPT_LG_FOLD_WO: c->opt_lg_fold = value != 0; ++c->settings_gen; return RFE_OK;
+        case RFE_OPT_LG_FP16X2: c->opt_lg_fp16x2 = value != 0; ++c->settings_gen; return RFE_OK;
+        case RFE_OPT_HOST_GRAPH: c->opt_host_graph = value != 0; return RFE_OK;
         default: return fail(c, RFE_ERR_INVALID, "rfe_set_option: unknown option");
     }
 }
@@ -166,6 +206,7 @@ extern "C" int rfe_get_option(rfe_ctx* c, int option, int* value) {
     switch (option) {
         case RFE_OPT_LG_FOLD_WO: *value = c->opt_lg_fold ? 1 : 0; return RFE_OK;
         case RFE_OPT_LG_FP16X2: *value = c->opt_lg_fp16x2 ? 1 : 0; return RFE_OK;
+        case RFE_OPT_HOST_GRAPH: *value = c->opt_host_graph ? 1 : 0; return RFE_OK;
         default: return fail(c, RFE_ERR_INVALID, "rfe_get_option: unknown option");
     }
 }
@@ -418,6 +459,7 @@ extern "C" int rfe_set_weights(rfe_ctx* c, int kind, const float* blob, int64_t 
     if (count != rfe_weight_count(kind)) return fail(c, RFE_ERR_INVALID, "rfe_set_weights: wrong float count for this model kind");
     RFE_HIP(c, hipStreamSynchronize(c->stream));
     const int rc = kind == RFE_KIND_SUPERPOINT ? set_sp(c, blob) : set_lg(c, blob);
+    ++c->settings_gen;
     if (rc == RFE_OK) {
         // hyper-parameters belong to a weight set: a bare blob (and a version-1 file) carries none, so this kind's values go back to the published
         // defaults -- a v2 load followed by rfe_set_weights must not keep the earlier file's radius / border / top-k rule silently (rover_fe.h)
@@ -529,6 +571,7 @@ extern "C" int rfe_set_hparams(rfe_ctx* c, const rfe_hparams* in) {
     const int rc = check_hparams(c, *in, "rfe_set_hparams");
     if (rc) return rc;
     c->hp = *in;
+    ++c->settings_gen;
     return RFE_OK;
 }
 
@@ -770,7 +813,10 @@ extern "C" int rfe_extract_u8_bin(rfe_ctx* c, const uint8_t* img, int H, int W, 
     uint8_t* d_b = desc_bin ? (uint8_t*)(p + ib + nb + kb + sb + db) : nullptr;
     for (size_t r = 0; r < (size_t)B * H; ++r) memcpy(hp + r * W, img + r * stride, (size_t)W);
     RFE_HIP(c, hipMemcpyAsync(d_img, hp, (size_t)B * H * W, hipMemcpyHostToDevice, c->stream));
-    if ((rc = sp_forward(c, d_img, H, W, W, B, Kmax, thr, d_n, d_k, d_s, d_d, d_b))) return rc;
+    if ((rc = ensure_ws(c, &c->ws_sp, &c->ws_sp_bytes, sp_ws_bytes(B, H, W)))) return rc;   // before the key is formed: a capture must not allocate
+    int thr_bits; memcpy(&thr_bits, &thr, 4);
+    if ((rc = run_host_graph(c, c->g_extract, host_graph_key(c, "xu8", {H, W, B, Kmax, thr_bits, desc_bin != nullptr}),
+                             [&] { return sp_forward(c, d_img, H, W, W, B, Kmax, thr, d_n, d_k, d_s, d_d, d_b); }))) return rc;
     // descriptors in rfe_host_malloc'ed memory (the class shims' tensors are): the DMA engine writes them where the caller wants them
     const bool direct = is_lib_pinned(desc, (size_t)B * Kmax * 1024);
     if (direct) {
@@ -817,7 +863,10 @@ extern "C" int rfe_extract_f32(rfe_ctx* c, const float* img, int H, int W, int s
     float* d_s = (float*)(p + ib + nb + kb); float* d_d = (float*)(p + ib + nb + kb + sb);
     for (size_t r = 0; r < (size_t)B * H; ++r) memcpy(hp + r * W * 4, img + r * stride, (size_t)W * 4);
     RFE_HIP(c, hipMemcpyAsync(d_img, hp, (size_t)B * H * W * 4, hipMemcpyHostToDevice, c->stream));
-    if ((rc = sp_forward(c, d_img, H, W, W, B, Kmax, thr, d_n, d_k, d_s, d_d, nullptr, true))) return rc;
+    if ((rc = ensure_ws(c, &c->ws_sp, &c->ws_sp_bytes, sp_ws_bytes(B, H, W)))) return rc;
+    int thr_bits; memcpy(&thr_bits, &thr, 4);
+    if ((rc = run_host_graph(c, c->g_extract, host_graph_key(c, "xf32", {H, W, B, Kmax, thr_bits}),
+                             [&] { return sp_forward(c, d_img, H, W, W, B, Kmax, thr, d_n, d_k, d_s, d_d, nullptr, true); }))) return rc;
     const bool direct = is_lib_pinned(desc, (size_t)B * Kmax * 1024);
     if (direct) {
         RFE_HIP(c, hipMemcpyAsync(hp + ib, p + ib, nb + kb + sb, hipMemcpyDeviceToHost, c->stream));
@@ -1078,7 +1127,13 @@ extern "C" int rfe_match(rfe_ctx* c, const float* k0n, const float* k1n, const f
     memcpy(hp + first + bd1, m, (size_t)P * 4);
     memcpy(hp + first + bd1 + bi, n, (size_t)P * 4);
     RFE_HIP(c, hipMemcpyAsync((char*)c->ws_io + first, hp + first, in_bytes - first, hipMemcpyHostToDevice, s));
-    if ((rc = rfe_match_dev(c, dk0, dk1, dd0, dd1, dm, dn, P, Mmax, Nmax, thr, dS, dp, dms))) return rc;
+    {
+        const int L = ((std::max(Mmax, Nmax) + 3) / 4) * 4;
+        if ((rc = ensure_ws(c, &c->ws_lg, &c->ws_lg_bytes, lg_ws_bytes(P, L)))) return rc;
+        int thr_bits; memcpy(&thr_bits, &thr, 4);
+        if ((rc = run_host_graph(c, c->g_match, host_graph_key(c, "m", {P, Mmax, Nmax, thr_bits}),
+                                 [&] { return rfe_match_dev(c, dk0, dk1, dd0, dd1, dm, dn, P, Mmax, Nmax, thr, dS, dp, dms); }))) return rc;
+    }
     RFE_HIP(c, hipMemcpyAsync(hp + in_bytes, dS, out_bytes, hipMemcpyDeviceToHost, s));
     RFE_HIP(c, hipStreamSynchronize(s));
     memcpy(S, hp + in_bytes, (size_t)P * 4);

@@ -113,6 +113,12 @@ struct rfe_ctx {
     bool has_sp = false, has_lg = false;
     bool opt_lg_fold = true;             // RFE_OPT_LG_FOLD_WO
     bool opt_lg_fp16x2 = false;          // RFE_OPT_LG_FP16X2
+    bool opt_host_graph = false;         // RFE_OPT_HOST_GRAPH: the synchronous host entries replay a captured hipGraph of their kernel sequence
+    // one instantiated graph per host entry kind (extract / match): `key` names the call shape + every pointer and setting baked into the kernel arguments,
+    // `seen` the shape of the last ordinary call (a shape is captured on its SECOND call: the first one allocates workspaces and sets function attributes)
+    struct HostGraph { std::string key, seen; hipGraphExec_t exec = nullptr; };
+    HostGraph g_extract, g_match;
+    unsigned long long settings_gen = 0; // bumped by everything a captured graph bakes in: weights, hyper-parameters, options
     rfe_hparams hp = rfe_default_hparams();   // graph hyper-parameters (RFEW v2 header / rfe_set_hparams)
     rfe::SpWeightsDev sp;                // views into *sp_hold / *lg_hold
     rfe::LgWeightsDev lg;

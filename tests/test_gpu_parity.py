@@ -451,6 +451,55 @@ def test_extract_is_repeatable_when_the_heads_overlap(ctx, oracle, B, H, W, K):
         assert first[0][i] == r["n"] and np.array_equal(first[1][i], r["kxy"]) and np.array_equal(first[3][i], r["desc"])
 
 
+def test_host_graph_option_gives_identical_results(ctx, oracle):
+    """RFE_OPT_HOST_GRAPH: the host entries replay a captured hipGraph per call shape (captured on the second call; weights, hyper-parameters, options, shape
+    and workspace addresses are part of the key).  Same bytes as ordinary launches for extract (u8 / float / binarised) and match, across shape changes,
+    a weight change, a hyper-parameter change and back."""
+    from rover_slam_amd import capi
+    fa, _ = synth.make_frames(2, 120, 160, seed=41)
+    fb, _ = synth.make_frames(1, 240, 320, seed=42)
+    w2 = Wt.make_superpoint(seed=9, dustbin_bias=7.0)
+
+    def run_all():
+        out = []
+        for fr, K in ((fa, 200), (fb, 512), (fa, 200), (fa, 64)):
+            out.append(ctx.extract(fr, kmax=K, binarized=True))
+            out.append(ctx.extract_f32(fr.astype(np.float32) * np.float32(1.0 / 255.0), kmax=K))
+        n, kxy, _, desc, _ = out[0]
+        k0 = oracle.normalize_keypoints(kxy[0, :n[0]].astype(np.float32), 120, 160); k1 = oracle.normalize_keypoints(kxy[1, :n[1]].astype(np.float32), 120, 160)
+        for _ in range(3):
+            out.append(ctx.match(k0[None], k1[None], desc[0, :n[0]][None], desc[1, :n[1]][None], [int(n[0])], [int(n[1])]))
+        ctx.set_weights(capi.KIND_SUPERPOINT, w2)
+        for _ in range(3):
+            out.append(ctx.extract(fa, kmax=200))
+        ctx.set_weights(capi.KIND_SUPERPOINT, Wt.make_superpoint(seed=7))
+        ctx.set_hparams(sp_nms_radius=3, sp_remove_borders=2, sp_topk_always=1)
+        for _ in range(3):
+            out.append(ctx.extract(fa, kmax=200))
+        ctx.set_hparams(sp_nms_radius=4, sp_remove_borders=4, sp_topk_always=0)
+        for _ in range(3):
+            out.append(ctx.extract(fa, kmax=200))
+        return out
+
+    plain = run_all()
+    ctx.set_option(capi.OPT_HOST_GRAPH, 1)
+    try:
+        assert ctx.get_option(capi.OPT_HOST_GRAPH) == 1
+        graphed = run_all()
+        graphed2 = run_all()
+    finally:
+        ctx.set_option(capi.OPT_HOST_GRAPH, 0)
+    for a, b, c2 in zip(plain, graphed, graphed2):
+        S_or_n = a[0]
+        for x, y, z in zip(a, b, c2):
+            if x.ndim >= 2 and x.shape[:1] == S_or_n.shape and len(a) == 3:      # match outputs: rows beyond S are undefined
+                for q in range(len(S_or_n)):
+                    assert np.array_equal(x[q, :S_or_n[q]], y[q, :S_or_n[q]]) and np.array_equal(x[q, :S_or_n[q]], z[q, :S_or_n[q]])
+            else:
+                assert np.array_equal(x, y) and np.array_equal(x, z)
+    assert not np.array_equal(plain[-4][1], plain[-7][1])            # the hyper-parameter change really changed the output (and the graph key)
+
+
 def test_extract_into_pinned_host_memory_is_identical(ctx):
     """rfe_host_malloc (round 5): a descriptor output inside a block from it is written by the DMA engine directly instead of being staged through the ctx's
     pinned block and copied on the host -- same bytes, for the u8, the binarised and the float entry, with one and with three frames; a pointer INTO the block
