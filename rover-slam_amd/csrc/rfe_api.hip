@@ -708,7 +708,8 @@ int sp_check(rfe_ctx* c, int H, int W, int B, int Kmax) {
 // backbone + heads up to the NMS'ed score map and the normalised descriptor map
 // join = false: the caller still has detector-only work to enqueue and joins the descriptor stream itself
 // (hipStreamWaitEvent(c->stream, c->ev_join)) when `forked` comes back true
-int sp_forward_maps(rfe_ctx* c, const void* img, int H, int W, int stride, int B, SpBuffers& b, bool join, bool& forked, bool img_f32 = false) {
+int sp_forward_maps(rfe_ctx* c, const void* img, int H, int W, int stride, int B, SpBuffers& b, bool join, bool& forked, bool img_f32 = false,
+                    long long frame_step = 0 /*pixels from frame b to b + 1; 0 = stride * H*/) {
     forked = false;
     int rc = ensure_ws(c, &c->ws_sp, &c->ws_sp_bytes, sp_ws_bytes(B, H, W));
     if (rc) return rc;
@@ -724,7 +725,7 @@ int sp_forward_maps(rfe_ctx* c, const void* img, int H, int W, int stride, int B
         { ProfScope p(c, "conv1b"); launch_conv3x3(s, b.a1, B, H, W, 64, w.packed[L_1B], w.bias[L_1B], 64, true, true, b.p1, L_1B); }
     } else {   // conv1a recomputed inside conv1b's LDS staging: the [B,H,W,64] activation never touches HBM
         ProfScope p(c, "conv1ab");
-        launch_conv1ab_fused(s, img, img_f32, stride, B, H, W, w.conv1a_w, w.bias[L_1A], w.packed[L_1B], w.bias[L_1B], b.p1);
+        launch_conv1ab_fused(s, img, img_f32, stride, B, H, W, w.conv1a_w, w.bias[L_1A], w.packed[L_1B], w.bias[L_1B], b.p1, frame_step);
     }
     { ProfScope p(c, "conv2a"); launch_conv3x3(s, b.p1, B, H1, W1, 64, w.packed[L_2A], w.bias[L_2A], 64, true, false, b.a2, L_2A); }
     { ProfScope p(c, "conv2b"); launch_conv3x3(s, b.a2, B, H1, W1, 64, w.packed[L_2B], w.bias[L_2B], 64, true, true, b.p2, L_2B); }
@@ -758,10 +759,10 @@ int sp_forward_maps(rfe_ctx* c, const void* img, int H, int W, int stride, int B
 }
 
 int sp_forward(rfe_ctx* c, const void* img, int H, int W, int stride, int B, int Kmax, float thr,
-               int32_t* n, int32_t* kxy, float* score, float* desc, uint8_t* desc_bin = nullptr, bool img_f32 = false) {
+               int32_t* n, int32_t* kxy, float* score, float* desc, uint8_t* desc_bin = nullptr, bool img_f32 = false, long long frame_step = 0) {
     SpBuffers b;
     bool forked;
-    int rc = sp_forward_maps(c, img, H, W, stride, B, b, false, forked, img_f32);
+    int rc = sp_forward_maps(c, img, H, W, stride, B, b, false, forked, img_f32, frame_step);
     if (rc) return rc;
     const int Hc = H / 2 / 2 / 2, Wc = W / 2 / 2 / 2, Hs = 8 * Hc, Ws = 8 * Wc;   // score-map frame, see sp_forward_maps
     { ProfScope p(c, "sp_select");
@@ -1270,14 +1271,46 @@ extern "C" int rfe_stereo_match(rfe_ctx* c, const uint8_t* imgL, const uint8_t* 
 // =====================================================================================
 __global__ void st_zero_count_kernel(int32_t* S) { S[0] = 0; }
 
-// this left view becomes the previous one: normalised keypoints, descriptors and count in one launch
-__global__ __launch_bounds__(256) void st_save_kernel(const float* __restrict__ kn, const float* __restrict__ desc, const int32_t* __restrict__ n,
-                                                      int Kmax, float* __restrict__ kn_prev, float* __restrict__ desc_prev, int32_t* __restrict__ n_prev) {
+// One launch in front of the temporal match of a stereo frame (round 5: it replaced normalize_kpts + lg_stage + the save kernel behind the match).  One wave per
+// token row of the pair layout [side 0 = this left view | side 1 = the previous left view], L rows each:
+//   side 0: NormalizeKeypoints (reference src/Matchers/transform.cpp:19-32) of the integer keypoint, descriptor row -> x, rotary table row -> csn, AND both into
+//           the state slot that becomes "previous" for the next frame (two slots, flipped per frame: nothing is copied after the match);
+//   side 1: the stored normalised keypoint / descriptor of the previous view -> x, csn;
+// workgroup 0: clamped lengths, cross-attention map, the next slot's keypoint count.  have_prev = 0 (first frame of a stream): side 1 is zero-filled, length 0.
+__global__ __launch_bounds__(256) void st_stage_kernel(const int32_t* __restrict__ kxy, const float* __restrict__ desc, const int32_t* __restrict__ n, int Kmax, int L,
+                                                       float sx, float sy, float scale, const float* __restrict__ kn_prev, const float* __restrict__ desc_prev,
+                                                       const int32_t* __restrict__ n_prev, int have_prev, const float* __restrict__ wr, float* __restrict__ x,
+                                                       float* __restrict__ kn, float2* __restrict__ csn, int32_t* __restrict__ lens, int32_t* __restrict__ kvmap,
+                                                       float* __restrict__ kn_next, float* __restrict__ desc_next, int32_t* __restrict__ n_next) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int v0 = n[0]; v0 = v0 < 0 ? 0 : (v0 > Kmax ? Kmax : v0);
+        int v1 = have_prev ? n_prev[0] : 0; v1 = v1 < 0 ? 0 : (v1 > Kmax ? Kmax : v1);
+        lens[0] = v0; lens[1] = v1; kvmap[0] = 1; kvmap[1] = 0;
+        n_next[0] = n[0];
+    }
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row == 0 && lane == 0) n_prev[0] = n[0];
-    if (row >= Kmax) return;
-    reinterpret_cast<float4*>(desc_prev + (size_t)row * 256)[lane] = reinterpret_cast<const float4*>(desc + (size_t)row * 256)[lane];
-    if (lane == 0) reinterpret_cast<float2*>(kn_prev)[row] = reinterpret_cast<const float2*>(kn)[row];
+    if (row >= 2 * L) return;
+    const int side = row >= L, i = side ? row - L : row;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    float kx = 0.f, ky = 0.f;
+    if (i < Kmax) {
+        if (!side) {
+            v = reinterpret_cast<const float4*>(desc + (size_t)i * 256)[lane];
+            kx = ((float)kxy[2 * i] - sx) / scale; ky = ((float)kxy[2 * i + 1] - sy) / scale;
+            reinterpret_cast<float4*>(desc_next + (size_t)i * 256)[lane] = v;
+            if (lane == 0) reinterpret_cast<float2*>(kn_next)[i] = make_float2(kx, ky);
+        } else if (have_prev) {
+            v = reinterpret_cast<const float4*>(desc_prev + (size_t)i * 256)[lane];
+            const float2 kp = reinterpret_cast<const float2*>(kn_prev)[i];
+            kx = kp.x; ky = kp.y;
+        }
+    }
+    reinterpret_cast<float4*>(x + (size_t)row * 256)[lane] = v;
+    if (lane == 0) reinterpret_cast<float2*>(kn)[row] = make_float2(kx, ky);
+    if (lane < 32) {
+        const float th = fmaf(wr[2 * lane + 1], ky, wr[2 * lane] * kx);
+        csn[(size_t)row * 32 + lane] = make_float2(cosf(th), sinf(th));
+    }
 }
 
 extern "C" int rfe_stereo_frame_dev(rfe_ctx* c, const uint8_t* imgL, const uint8_t* imgR, int H, int W, int stride, int Kmax,
@@ -1291,23 +1324,32 @@ extern "C" int rfe_stereo_frame_dev(rfe_ctx* c, const uint8_t* imgL, const uint8
         return fail(c, RFE_ERR_INVALID, "stereo_frame: null pointer, stride < W or mb <= 0");
     RFE_HIP(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    // state: [2,H,W] staged views | sadv [Kmax] | kn_prev, kn_cur [Kmax,2] | desc_prev [Kmax,256] | n_prev [1]
-    const size_t b_img = al((size_t)2 * H * W), b_sad = al((size_t)Kmax * 4), b_kn = al((size_t)Kmax * 8), b_desc = al((size_t)Kmax * 1024);
+    // state: [2,H,W] staged views (unfused-conv1 tuning path only) | sadv [Kmax] | two slots of { kn [Kmax,2], desc [Kmax,256], n [1] }: the previous left
+    // view lives in slot st_flip, this frame's staging kernel fills the other one, then the slots swap -- nothing is copied behind the match
+    const size_t b_img = al((size_t)2 * H * W), b_sad = al((size_t)Kmax * 4), b_kn = al((size_t)Kmax * 8), b_desc = al((size_t)Kmax * 1024), b_n = al(4);
     const bool fresh = c->st_H != H || c->st_W != W || c->st_K != Kmax;
-    if ((rc = ensure_ws(c, &c->ws_st, &c->ws_st_bytes, b_img + b_sad + 2 * b_kn + b_desc + 256))) return rc;
+    if ((rc = ensure_ws(c, &c->ws_st, &c->ws_st_bytes, b_img + b_sad + 2 * (b_kn + b_desc + b_n) + 256))) return rc;
     if (fresh || reset) { c->st_have_prev = false; c->st_H = H; c->st_W = W; c->st_K = Kmax; }
     char* p = (char*)c->ws_st;
     uint8_t* d_img = (uint8_t*)p; p += b_img;
     int32_t* sadv = (int32_t*)p; p += b_sad;
-    float* kn_prev = (float*)p; p += b_kn; float* kn_cur = (float*)p; p += b_kn;
-    float* desc_prev = (float*)p; p += b_desc; int32_t* n_prev = (int32_t*)p;
+    float* kn_slot[2]; float* desc_slot[2]; int32_t* n_slot[2];
+    for (int q = 0; q < 2; ++q) { kn_slot[q] = (float*)p; p += b_kn; desc_slot[q] = (float*)p; p += b_desc; n_slot[q] = (int32_t*)p; p += b_n; }
+    const int prev = c->st_flip & 1, next = prev ^ 1;
     // both views as ONE batch of 2 (the reference runs them on two threads, src/Frame.cc:142-147).  Measured alternative: the
     // right view + stereo match on a second lane (own streams / workspace) next to left view + LightGlue -- 3.52 ms per stereo
     // frame against 3.26 ms for this form: two batch-1 extractions are no faster than one batch of 2, and the co-running
-    // kernels slow the latency-bound LightGlue chain (profiles/r02_ab_notes.md)
-    RFE_HIP(c, hipMemcpy2DAsync(d_img, (size_t)W, imgL, (size_t)stride, (size_t)W, (size_t)H, hipMemcpyDeviceToDevice, s));
-    RFE_HIP(c, hipMemcpy2DAsync(d_img + (size_t)H * W, (size_t)W, imgR, (size_t)stride, (size_t)W, (size_t)H, hipMemcpyDeviceToDevice, s));
-    if ((rc = sp_forward(c, d_img, H, W, W, 2, Kmax, thr, n, kxy, score, desc))) return rc;
+    // kernels slow the latency-bound LightGlue chain (profiles/r02_ab_notes.md).  The two views are read where the caller has them (round 5: conv1's
+    // tile loader takes the distance between frame 0 and frame 1 -- any distance, here imgR - imgL; the two staging copies are gone).  The caller keeps
+    // them valid until the ctx stream has passed this call, like every input of a *_dev entry.
+    const uint8_t *vL = imgL, *vR = imgR;
+    int vstride = stride;
+    if (sp_unfused_conv1()) {     // tuning path (stand-alone conv1a has no frame step): stage as before
+        RFE_HIP(c, hipMemcpy2DAsync(d_img, (size_t)W, imgL, (size_t)stride, (size_t)W, (size_t)H, hipMemcpyDeviceToDevice, s));
+        RFE_HIP(c, hipMemcpy2DAsync(d_img + (size_t)H * W, (size_t)W, imgR, (size_t)stride, (size_t)W, (size_t)H, hipMemcpyDeviceToDevice, s));
+        vL = d_img; vR = d_img + (size_t)H * W; vstride = W;
+    }
+    if ((rc = sp_forward(c, vL, H, W, vstride, 2, Kmax, thr, n, kxy, score, desc, nullptr, false, (long long)(vR - vL)))) return rc;
     // Frame::ComputeStereoMatches (src/Frame.cc:1159-1446) on the device-resident features; counts stay on the device
     // ... on the SIDE stream: the stereo kernels (45 us of small launches) and the temporal LightGlue match below only share their inputs, and
     // the one-pair LightGlue is a chain of latency-bound kernels that leaves room next to it (with an event pair around every stage, full
@@ -1316,30 +1358,33 @@ extern "C" int rfe_stereo_frame_dev(rfe_ctx* c, const uint8_t* imgL, const uint8
     hipStream_t ss = st_fork ? c->side_stream : s;
     if (st_fork) { RFE_HIP(c, hipEventRecord(c->ev_fork, s)); RFE_HIP(c, hipStreamWaitEvent(ss, c->ev_fork, 0)); }
     { ProfScope ps(c, "stereo_match", ss);
-      launch_stereo_match_counts(ss, d_img, d_img + (size_t)H * W, H, W, W, kxy, kxy + (size_t)Kmax * 2, Kmax, n, desc,
+      launch_stereo_match_counts(ss, vL, vR, H, W, vstride, kxy, kxy + (size_t)Kmax * 2, Kmax, n, desc,
                                  desc + (size_t)Kmax * 256, mb, mbf, uRight, depth, sadv); }
     if (st_fork) RFE_HIP(c, hipEventRecord(c->ev_join, ss));
-    // every exit below -- the error returns of ensure_ws / lg_stage / lg_forward included -- joins the side stream first: the caller's NEXT call
-    // rewrites d_img / uRight / depth on the ctx stream, which must not overtake stereo kernels still reading or writing them
+    // every exit below -- the error returns of ensure_ws / lg_forward included -- joins the side stream first: the caller's NEXT call
+    // rewrites uRight / depth (and its image buffers) on the ctx stream, which must not overtake stereo kernels still reading or writing them
     struct JoinGuard { rfe_ctx* c; hipStream_t s; bool on; ~JoinGuard() { if (on) (void)hipStreamWaitEvent(s, c->ev_join, 0); } } join_guard{c, s, st_fork};
     // temporal match exactly as Tracking issues it: SearchBySP(mCurrentFrame, mLastFrame) (src/Tracking.cc:3465) ->
     // MatchingPoints_onnx(CurrentFrame, LastFrame, vnMatches1) (src/Matchers/SPmatcher.cc:1050-1054): THIS left view is set 0,
     // the previous left view set 1, so pairs are (current index, previous index) like vnMatches1[IdxCF] = IdxLF; true image
     // size like the Frame overload (:457-542, :463-464)
-    { ProfScope ps(c, "lg_misc"); launch_normalize_kpts(s, kxy, Kmax, H, W, kn_cur); }
-    if (c->st_have_prev) {
+    {
         const int L = ((Kmax + 3) / 4) * 4;
         if ((rc = ensure_ws(c, &c->ws_lg, &c->ws_lg_bytes, lg_ws_bytes(1, L)))) return rc;
         LgBuffers b;
         lg_carve(c->ws_lg, 1, L, b);
-        { ProfScope ps(c, "lg_misc");
-          if ((rc = lg_stage(c, b, kn_cur, kn_prev, desc, desc_prev, n, n_prev, 1, Kmax, Kmax, L))) return rc; }
-        if ((rc = lg_forward(c, b, 1, L, filter_thr, Kmax, S, pairs, ms, nullptr, false, true))) return rc;
-    } else {
-        hipLaunchKernelGGL(st_zero_count_kernel, dim3(1), dim3(1), 0, s, S);
+        const float sx = (float)W / 2, sy = (float)H / 2, scale = (float)(H > W ? H : W) / 2;     // launch_normalize_kpts' constants
+        { ProfScope ps(c, "lg_misc");   // ONE staging launch: normalise, rotary table, token rows of both sides, lengths -- and this view into the next slot
+          hipLaunchKernelGGL(st_stage_kernel, dim3((unsigned)((2 * L + 3) / 4)), dim3(256), 0, s, kxy, desc, n, Kmax, L, sx, sy, scale, kn_slot[prev], desc_slot[prev],
+                             n_slot[prev], c->st_have_prev ? 1 : 0, c->lg.wr, b.x, b.kn, reinterpret_cast<float2*>(b.csn), b.lens, b.kvmap, kn_slot[next], desc_slot[next],
+                             n_slot[next]); }
+        if (c->st_have_prev) {
+            if ((rc = lg_forward(c, b, 1, L, filter_thr, Kmax, S, pairs, ms, nullptr, false, true))) return rc;
+        } else {
+            hipLaunchKernelGGL(st_zero_count_kernel, dim3(1), dim3(1), 0, s, S);
+        }
     }
-    { ProfScope ps(c, "lg_misc");   // this left view becomes the previous one
-      hipLaunchKernelGGL(st_save_kernel, dim3((Kmax + 3) / 4), dim3(256), 0, s, kn_cur, desc, n, Kmax, kn_prev, desc_prev, n_prev); }
+    c->st_flip = next;
     if (st_fork) { join_guard.on = false; RFE_HIP(c, hipStreamWaitEvent(s, c->ev_join, 0)); }   // uRight / depth are complete when the ctx stream is
     c->st_have_prev = true;
     RFE_HIP(c, hipGetLastError());

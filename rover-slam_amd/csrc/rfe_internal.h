@@ -130,7 +130,7 @@ struct rfe_ctx {
     void* h_pin = nullptr; size_t h_pin_bytes = 0;   // pinned host mirror of ws_io for the per-frame host entries (extract / match): one DMA each way
     void* ws_tmp = nullptr; size_t ws_tmp_bytes = 0; // test hooks
     void* ws_st = nullptr; size_t ws_st_bytes = 0;   // stereo stream state: staged views, previous left view's features
-    int st_H = 0, st_W = 0, st_K = 0; bool st_have_prev = false;
+    int st_H = 0, st_W = 0, st_K = 0; bool st_have_prev = false; int st_flip = 0;   // st_flip: which of the two state slots holds the previous left view
     // one-shot test tap (rfe_k_set_lightglue_tap): the next LightGlue forward of this ctx, whatever entry point runs it,
     // copies the final token states / log-assignment matrix of one pair to these device buffers
     struct { bool armed = false; int pair = 0; float *x0 = nullptr, *x1 = nullptr, *scores = nullptr; } tap;
@@ -175,7 +175,7 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
                     const float* wpacked, const float* bias, int cout, bool relu, bool pool, float* out,
                     int tag = 0);
 void launch_conv1ab_fused(hipStream_t s, const void* img, bool img_f32, int stride, int B, int H, int W, const float* w1a,
-                          const float* b1a, const float* wp, const float* bias, float* out);
+                          const float* b1a, const float* wp, const float* bias, float* out, long long frame_step = 0 /*pixels between frames; 0 = stride * H*/);
 // gemm.hip
 // hipFuncAttributeMaxDynamicSharedMemorySize belongs to the CURRENT device's copy of a kernel: set it once per (kernel, device) -- pools run
 // one ctx per device.  `done` is the caller's per-kernel flag array (static bool [64]); races only repeat the idempotent call.

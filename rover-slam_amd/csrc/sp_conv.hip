@@ -599,7 +599,7 @@ __device__ __forceinline__ float px_value(PX v) {
 template <int CK, typename PX>
 __global__ __launch_bounds__(256, 2) void conv1ab_fused_kernel(
     const PX* __restrict__ img, int stride, const float* __restrict__ w1a /*[9][64]*/, const float* __restrict__ b1a,
-    const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ out, int H, int W) {
+    const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ out, int H, int W, long long frame_step /*pixels from frame b to b + 1*/) {
     constexpr int CIN = 64, COUT = 64, KCH = CK * 9;
     constexpr int MH = TH + 4, MW = TW + 4;   // image tile with a 2-pixel halo
     __shared__ __attribute__((aligned(16))) float lds[CK * PLANE + KCH * NT + MH * MW];
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(256, 2) void conv1ab_fused_kernel(
     conv_a_offsets(aoff, h, wave, col);
     const int boff = h * NT + col;
 
-    const PX* im = img + (size_t)b * stride * H;
+    const PX* im = img + (long long)b * frame_step;     // usually stride * H; a stereo pair hands over two separate views (rfe_stereo_frame_dev)
     for (int idx = tid; idx < MH * MW; idx += 256) {
         const int py = idx / MW, px = idx % MW;
         const int gy = y0 - 2 + py, gx = x0 - 2 + px;
@@ -672,19 +672,20 @@ __global__ __launch_bounds__(256, 2) void conv1ab_fused_kernel(
 }
 
 void launch_conv1ab_fused(hipStream_t s, const void* img, bool img_f32, int stride, int B, int H, int W, const float* w1a,
-                          const float* b1a, const float* wp, const float* bias, float* out) {
+                          const float* b1a, const float* wp, const float* bias, float* out, long long frame_step) {
     dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B);
+    if (frame_step == 0) frame_step = (long long)stride * H;
     if (img_f32) {
         if (conv_ck() == 8)
-            hipLaunchKernelGGL((conv1ab_fused_kernel<8, float>), grid, dim3(256), 0, s, (const float*)img, stride, w1a, b1a, wp, bias, out, H, W);
+            hipLaunchKernelGGL((conv1ab_fused_kernel<8, float>), grid, dim3(256), 0, s, (const float*)img, stride, w1a, b1a, wp, bias, out, H, W, frame_step);
         else
-            hipLaunchKernelGGL((conv1ab_fused_kernel<16, float>), grid, dim3(256), 0, s, (const float*)img, stride, w1a, b1a, wp, bias, out, H, W);
+            hipLaunchKernelGGL((conv1ab_fused_kernel<16, float>), grid, dim3(256), 0, s, (const float*)img, stride, w1a, b1a, wp, bias, out, H, W, frame_step);
         return;
     }
     if (conv_ck() == 8)
-        hipLaunchKernelGGL((conv1ab_fused_kernel<8, uint8_t>), grid, dim3(256), 0, s, (const uint8_t*)img, stride, w1a, b1a, wp, bias, out, H, W);
+        hipLaunchKernelGGL((conv1ab_fused_kernel<8, uint8_t>), grid, dim3(256), 0, s, (const uint8_t*)img, stride, w1a, b1a, wp, bias, out, H, W, frame_step);
     else
-        hipLaunchKernelGGL((conv1ab_fused_kernel<16, uint8_t>), grid, dim3(256), 0, s, (const uint8_t*)img, stride, w1a, b1a, wp, bias, out, H, W);
+        hipLaunchKernelGGL((conv1ab_fused_kernel<16, uint8_t>), grid, dim3(256), 0, s, (const uint8_t*)img, stride, w1a, b1a, wp, bias, out, H, W, frame_step);
 }
 
 #define RFE_CONV_LAUNCH(CIN, POOL, RELU, TAG)                                                                            \
