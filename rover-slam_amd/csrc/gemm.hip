@@ -52,11 +52,19 @@ __device__ __forceinline__ float gelu_short(float t) {
 // copies stay in flight across the one that publishes the A tile.
 typedef __attribute__((address_space(3))) void* gemm_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gemm_gptr_t;
-template <int MB, int NB, bool RES, bool PFT = false, bool LNA = false, bool KP = false, bool DMAB = false>
+// ROPE (the qkv projection on the k-permuted throughput tile): LightGlue's rotary encoding of the q | k column tiles in the epilogue, so that the attention
+// kernel takes K tiles straight into LDS (lg_attention_dma_kernel for the self blocks too).  The table rows of the workgroup's 128 token rows (256 B
+// each = the 32 (cos, sin) pairs every head shares) are copied by global_load_lds_dwordx4 into a 32 KB dynamic LDS tile when the workgroup STARTS --
+// no registers, and the whole K loop to land -- and the epilogue rotates in place from LDS before the first store.  48 + 32 = 80 KB: still two
+// workgroups per CU (tools/kbench/lds_occupancy.hip).  Forms that read the table from global memory in the epilogue measured 216 -> 288 us (row by row
+// between the stores: every load waits for the stores in front of it on the in-order vector-memory counter) and 216 -> 239 us (16 loads at a time in
+// front of all stores; the same whether the q | k or only the k tiles rotate: exposed round trips, not work) -- profiles/r05_ab_notes.md.
+template <int MB, int NB, bool RES, bool PFT = false, bool LNA = false, bool KP = false, bool DMAB = false, bool ROPE = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     constexpr int BM = MB * 64, BN = NB * 64;
     constexpr int LDR = KP ? BK : LDT;          // LDS row stride in words
     static_assert(!DMAB || (KP && PFT && !LNA && MB == 2), "DMAB: k-permuted throughput tile only");
+    static_assert(!ROPE || (KP && PFT && !LNA && !RES && !DMAB && MB == 2 && NB == 4), "ROPE: plain k-permuted 128 x 256 tile only");
     __shared__ __attribute__((aligned(16))) float lds_static[DMAB ? 4 : (BM + BN) * LDR];   // A tile | B tile
     extern __shared__ __attribute__((aligned(16))) float lds_dynamic[];                      // DMAB: A tile | B tile x 2 = (BM + 2 BN) * LDR words
     float* const lds_ab = DMAB ? lds_dynamic : lds_static;
@@ -77,6 +85,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     const float* B = g.B + (size_t)z * g.sB;
     float* C = g.C + (size_t)z * g.sC;
 
+    const bool rope = ROPE && n0 >= g.rope_c0 && n0 < g.rope_c1;   // workgroup-uniform (the bounds are multiples of the column tile)
     f32x16 acc[MB][NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -185,6 +194,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 #endif
     if (DMAB) dma_b(0, 0);
     if (PF) load_tile(0);
+    if (rope) {   // behind the first tile's loads on the in-order counter: the wait for that tile does not cover these copies
+        // one wave instruction = 64 x 16 B = 4 table rows; wave w copies rows 32 w .. 32 w + 31 of the tile (rows past M: the last row, never stored)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            int row = m0 + wave * 32 + u * 4 + (lane >> 4);
+            row = row < M ? row : M - 1;
+            __builtin_amdgcn_global_load_lds((gemm_gptr_t)(g.rope_csn + (size_t)row * 64 + (lane & 15) * 4), (gemm_lds_ptr_t)(lds_dynamic + (wave * 32 + u * 4) * 64), 16, 0, 0);
+        }
+    }
     if (LNI) ln_tile();   // first tile: nothing to hide it under
     int bbuf = 0;
     for (int k0 = 0; k0 < g.K; k0 += BK) {
@@ -303,6 +321,30 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 
     {   // bias (+alpha, +ReLU, +residual) epilogue: 128-B coalesced accesses straight from the D layout
         const float* Rz = (RES && g.R) ? g.R + (size_t)z * g.sR : nullptr;
+        if (rope) {
+            // rotary epilogue (alpha = 1, no ReLU), IN PLACE and before the first store: in the D layout a lane holds column n = .. + i of 16 rows, the other
+            // element of its pair (n ^ 1) sits in lane i ^ 1 of the same register -> one DPP move.  (c, s) of head dimension (nb & 1) * 32 + i from the LDS
+            // table tile (blocks nb and nb + 2 = the same dimensions of two heads): the copies were requested before the K loop, whose barriers have long
+            // published them.
+            const float* csl = lds_dynamic + ((wm * MB) * 32 + 4 * h) * 64 + (i & ~1);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float* cp = csl + (mb * 32 + (r & 3) + 8 * (r >> 2)) * 64;
+                    float2 c0 = *reinterpret_cast<const float2*>(cp), c1 = *reinterpret_cast<const float2*>(cp + 32);
+                    // even lane: t0 c - t1 s = t0 c + t1 (-s); odd lane: t1 c + t0 s -- one signed sine per lane, then the same mul, mul, add in both
+                    // (bit-identical to the attention kernels' on-load form: x (-s) = -(x s) and a + (-b) = a - b exactly)
+                    c0.y = (i & 1) ? c0.y : -c0.y; c1.y = (i & 1) ? c1.y : -c1.y;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const float v = acc[mb][nb][r];
+                        const float pv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]: lane i ^ 1
+                        const float2 t = (nb & 1) ? c1 : c0;
+                        acc[mb][nb][r] = v * t.x + pv * t.y;
+                    }
+                }
+        }
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -397,6 +439,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     }
 }
 
+// the shapes whose projection can carry the rotary epilogue: what takes the plain k-permuted 128 x 256 tile below
+bool gemm_nt_rope_ok(const GemmArgs& g) {
+    static const bool kp_on = tune_int("RFE_GEMM_KP", 1) != 0, pft = tune_int("RFE_GEMM_PF", 1) != 0, dmab = tune_int("RFE_GEMM_DMA", 0) != 0;
+    const int batch = g.batch > 0 ? g.batch : 1;
+    return kp_on && pft && !dmab && g.kperm && batch == 1 && !g.m_valid && !g.R && !g.stats_in && !g.stats_out && !g.Bh && !g.relu && g.alpha == 1.0f && g.N % 256 == 0 &&
+           g.rope_c0 % 256 == 0 && g.rope_c1 % 256 == 0 && (long long)((g.M + 127) / 128) * (g.N / 256) >= 256 && !gemm_latency_regime(g);
+}
+
 int launch_gemm_nt(hipStream_t s, const GemmArgs& g_in) {
     GemmArgs g = g_in;
 #ifdef RFE_TUNING
@@ -405,9 +455,10 @@ int launch_gemm_nt(hipStream_t s, const GemmArgs& g_in) {
     const int batch = g.batch > 0 ? g.batch : 1;
     auto tiles = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * batch; };
     // RFE_OPT_LG_FP16X2: a LightGlue Linear whose weights come with fp16 (hi, lo) planes and whose shape takes the throughput tile
+    if (g.rope_csn && !gemm_nt_rope_ok(g)) return -1;   // callers ask first
     if (g.Bh && g.Bl && batch == 1 && !g.m_valid && !g.relu && g.N % 256 == 0 && g.K % 32 == 0 && (!g.A2 || g.K1 % 32 == 0) && tiles(128, 256) >= 256)
         return launch_gemm_h2(s, g);
-    if (gemm_latency_regime(g)) {   // one / few pairs per call: the 16x16x4 latency tiling (gemm_lat.hip) when it serves the shape
+    if (!g.rope_csn && gemm_latency_regime(g)) {   // one / few pairs per call: the 16x16x4 latency tiling (gemm_lat.hip) when it serves the shape
         if (launch_gemm_lat(s, g, nullptr, 0)) return 0;
     }
     const bool res = g.R != nullptr, lna = g.stats_in != nullptr;
@@ -428,6 +479,10 @@ int launch_gemm_nt(hipStream_t s, const GemmArgs& g_in) {
                 static bool ls_[64]; ensure_dynamic_lds((const void*)gemm_nt_kernel<2, 4, false, true, false, true, true>, kDmaLds, ls_); \
                 hipLaunchKernelGGL((gemm_nt_kernel<2, 4, false, true, false, true, true>), GRID, dim3(256), kDmaLds, s, g); \
             }                                                                                        \
+        } else                                                                                       \
+        if (g.rope_csn && MB_ == 2 && NB_ == 4) {                                                    \
+            static bool lr_[64]; ensure_dynamic_lds((const void*)gemm_nt_kernel<2, 4, false, true, false, true, false, true>, 128 * 64 * 4, lr_); \
+            hipLaunchKernelGGL((gemm_nt_kernel<2, 4, false, true, false, true, false, true>), GRID, dim3(256), 128 * 64 * 4, s, g); \
         } else                                                                                       \
         if (kp && MB_ == 2 && pft && !lna) {                                                         \
             if (res) hipLaunchKernelGGL((gemm_nt_kernel<MB_, NB_, true, MB_ == 2, false, MB_ == 2>), GRID, dim3(256), 0, s, g); \

@@ -73,7 +73,9 @@ __device__ __forceinline__ float at_softmax_finish(float l_run) { return l_run +
 // SPLIT: split-key variant for latency-bound problems (one pair = 64 (sequence, head, query block) units for 256 CUs and
 // a 2048-MFMA serial chain per wave): blockIdx.y selects one of gridDim.y key ranges, the workgroup writes its
 // unnormalised accumulators and (reference max, sum) to `part`, and lg_attention_combine_kernel merges the ranges.
-// ROPE: the LightGlue rotary encoding of the self blocks -- (t0, t1) -> (t0 c - t1 s, t1 c + t0 s) on adjacent pairs (2f, 2f+1),
+// ROPE (since round 5 the FALLBACK of the self blocks: the throughput projection rotates q | k in its epilogue -- gemm.hip, ROPE -- and the self blocks run
+// lg_attention_dma_kernel like the cross blocks, 9.48 -> 9.14 ms of attention per step for +0.08 ms of projection; this form still serves RFE_OPT_LG_FP16X2's
+// fp32 fallbacks and shapes the rotary epilogue does not take): the LightGlue rotary encoding of the self blocks -- (t0, t1) -> (t0 c - t1 s, t1 c + t0 s) on adjacent pairs (2f, 2f+1),
 // (c, s) = rope_csn[row][f] -- is applied HERE, to the Q fragment as it is loaded and to every K tile as it is staged, with the
 // same three fp32 operations round 1's projection epilogue used (bit-identical results).  The qkv projection keeps the plain
 // coalesced epilogue (101 -> 122 TFLOP/s); the K rows are rotated once per staging workgroup (8 query blocks per (sequence,
@@ -289,7 +291,7 @@ constexpr int AD_K = 32;
 __global__ __launch_bounds__(256, 4) void lg_attention_dma_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld, float* __restrict__ out,
     int Lq, int Lk, int nqb, const int* __restrict__ qlen, const int* __restrict__ klen, const int* __restrict__ kv_map,
-    int prio, int nseq_total) {
+    int prio, int nseq_total, const float* __restrict__ rope_q) {
     // Dynamic LDS on purpose: with static `__shared__ float Kd[2][..]` tiles the compiler's wait-count pass cannot tell buffer buf from
     // buf ^ 1 and puts an s_waitcnt vmcnt(0) in front of the first ds_read of tile t -- i.e. AFTER tile t + 1 has just been requested, so
     // every wave sat out that round trip and nothing overlapped (round-3 advisor finding, visible in the ISA).  With one dynamic array and
@@ -320,9 +322,16 @@ __global__ __launch_bounds__(256, 4) void lg_attention_dma_kernel(
     float qreg[32];   // qreg[4 g + e] = Q[query][8 g + 4 h + e] * scale
     {
         const float4* qp4 = reinterpret_cast<const float4*>(q + qrow_c * ld + head * 64) + h;
+        // rope_q (self blocks at throughput shapes: the projection's epilogue has rotated K, gemm.hip): Q is rotated here, as it is loaded -- a lane's
+        // float4 is two whole pairs (dims 8 g + 4 h .. + 3), (c, s) from the table row of this query; the three operations of every other rotary form
+        const float4* cp4 = rope_q ? reinterpret_cast<const float4*>(rope_q + qrow_c * 64) + h : nullptr;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-            const float4 t = qp4[2 * g];
+            float4 t = qp4[2 * g];
+            if (rope_q) {
+                const float4 cs = cp4[2 * g];
+                t = make_float4(t.x * cs.x - t.y * cs.y, t.y * cs.x + t.x * cs.y, t.z * cs.z - t.w * cs.w, t.w * cs.z + t.z * cs.w);
+            }
             qreg[4 * g] = t.x * kScale; qreg[4 * g + 1] = t.y * kScale; qreg[4 * g + 2] = t.z * kScale; qreg[4 * g + 3] = t.w * kScale;
         }
     }
@@ -438,7 +447,13 @@ size_t lg_attention_part_bytes(int nseq, int Lq) {   // scratch of the split-key
 }
 
 void launch_lg_attention(hipStream_t s, const float* q, const float* k, const float* v, int ld, float* out, int nseq, int Lq,
-                         int Lk, const int* qlen, const int* klen, const int* kv_map, float* part, const float* rope_csn, bool fp16x2) {
+                         int Lk, const int* qlen, const int* klen, const int* kv_map, float* part, const float* rope_csn, bool fp16x2, bool k_roped) {
+    if (rope_csn && k_roped) {   // K already rotated by the projection's epilogue, Q not (tuning form RFE_QKV_ROPE=2): K / V tiles by LDS-DMA, Q rotated on load
+        const int nqb = (Lq + AT_Q - 1) / AT_Q, units8 = (4 * nseq + 7) / 8 * 8;
+        static const int prio = tune_int("RFE_ATT_PRIO", 1);
+        hipLaunchKernelGGL(lg_attention_dma_kernel, dim3(nqb * units8), dim3(256), 4 * AD_K * 64 * sizeof(float), s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nseq, rope_csn);
+        return;
+    }
     if (fp16x2 && (size_t)nseq * Lq >= 32768 && (ld % 4) == 0) {   // RFE_OPT_LG_FP16X2, throughput shapes (one / few pairs: the split form of the latency kernel below)
         launch_lg_attention_h2(s, q, k, v, ld, out, nseq, Lq, Lk, qlen, klen, kv_map, rope_csn);
         return;
@@ -488,7 +503,7 @@ void launch_lg_attention(hipStream_t s, const float* q, const float* k, const fl
     static const int prio = tune_int("RFE_ATT_PRIO", 1);   // s_setprio(1) around the MFMA clusters (+0.8 %); RFE_ATT_PRIO=0 disables
     static const bool dma = tune_int("RFE_ATT_DMA", 1) != 0;   // tuning switch: 0 = register-staged tiles for the cross blocks too
     if (!rope && dma && (ld % 4) == 0)
-        hipLaunchKernelGGL(lg_attention_dma_kernel, dim3(nqb * units8), dim3(256), 4 * AD_K * 64 * sizeof(float), s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nseq);
+        hipLaunchKernelGGL(lg_attention_dma_kernel, dim3(nqb * units8), dim3(256), 4 * AD_K * 64 * sizeof(float), s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nseq, (const float*)nullptr);
     else if (rope)
         hipLaunchKernelGGL((lg_attention_kernel<0, false, true>), dim3(nqb * units8), dim3(256), 0, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, prio, nullptr, nseq, rope_csn);
     else

@@ -959,15 +959,25 @@ void lg_ffn(rfe_ctx* c, LgBuffers& b, float* x, const float* second, int rows, c
 void lg_self_block(rfe_ctx* c, LgBuffers& b, const LgLayerDev& Lw, float* x, const float* csn, const int32_t* lens, int nseq, int L) {
     hipStream_t s = c->stream;
     const int rows = nseq * L;
-    // q,k,v = Wqkv x + b.  Throughput shapes: plain epilogue, the rotary of q and k is applied by the attention kernel as it loads them.
-    // Latency shapes (one / few pairs): the projection's epilogue rotates q and k (gemm_lat.hip) and the attention runs without a table.
-    bool roped = false;
+    // q,k,v = Wqkv x + b, q and k rotated by the projection's epilogue -- gemm_lat.hip at one / few pairs, gemm.hip's ROPE tile at throughput shapes (table
+    // rows staged into LDS by DMA under the K loop) -- so that every attention kernel runs without a table and takes its K tiles straight into LDS
+    // (self blocks: lg_attention_dma_kernel 523 us against 565 us for the form that rotates every staged K tile; +9 us on the projection).
+    // Rotating only K there and q as the attention loads it measured worse on both sides (RFE_QKV_ROPE=2, profiles/r05_ab_notes.md).
+    // RFE_OPT_LG_FP16X2: gemm_h2.hip has no rotary epilogue, lg_attention_h2_kernel rotates both on load.
+    bool roped = false, k_roped = false;
     { ProfScope p(c, "lg_qkv");
-      const GemmArgs a = gemm_lgw(c, x, 256, Lw.wqkv, 256, Lw.bqkv, b.qkv, 768, rows, 768, 256);
+      GemmArgs a = gemm_lgw(c, x, 256, Lw.wqkv, 256, Lw.bqkv, b.qkv, 768, rows, 768, 256);
+      static const int nt_rope = tune_int("RFE_QKV_ROPE", 1);   // tuning switch: 0 = plain epilogue, rotary on load in lg_attention_kernel<.., ROPE>; 2 = only k in the epilogue, q on load
       if (gemm_latency_regime(a) && launch_gemm_lat(s, a, csn, 512)) roped = true;
-      else launch_gemm_nt(s, a); }
+      else {
+          if (nt_rope && csn) {
+              a.rope_c0 = nt_rope == 2 ? 256 : 0; a.rope_c1 = 512;
+              if (gemm_nt_rope_ok(a)) { a.rope_csn = csn; k_roped = true; roped = nt_rope != 2; }
+          }
+          launch_gemm_nt(s, a);
+      } }
     { ProfScope p(c, "lg_attention");
-      launch_lg_attention(s, b.qkv, b.qkv + 256, b.qkv + 512, 768, b.ctx, nseq, L, L, lens, lens, nullptr, lg_part(b, nseq, L), roped ? nullptr : csn, c->opt_lg_fp16x2); }
+      launch_lg_attention(s, b.qkv, b.qkv + 256, b.qkv + 512, 768, b.ctx, nseq, L, L, lens, lens, nullptr, lg_part(b, nseq, L), roped ? nullptr : csn, c->opt_lg_fp16x2, k_roped); }
     if (c->opt_lg_fold) {
         lg_ffn(c, b, x, b.ctx, rows, Lw.w1f, Lw.b1f, Lw.lng, Lw.lnb, Lw.w2, Lw.b2);
     } else {

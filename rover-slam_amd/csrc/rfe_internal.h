@@ -93,6 +93,9 @@ struct GemmArgs {
     // kperm != 0: the caller does not need the k-ascending reduction order (LightGlue: tolerance-checked, not bit-exact).  The 128-row
     // tiles then use the 16-byte-swizzled LDS layout with 128-bit fragment reads, which consume k in the order (s, 16 + s) per K tile.
     int kperm;
+    // rope_csn != null: LightGlue's rotary encoding applied by the epilogue to output columns rope_c0 <= n < rope_c1 (the k columns of the qkv projection;
+    // multiples of 256): (t0, t1) -> (t0 c - t1 s, t1 c + t0 s) on adjacent column pairs, (c, s) = rope_csn[row][(column & 63) / 2].  Plain projections only.
+    const float* rope_csn; int rope_c0, rope_c1;
 #ifdef RFE_TUNING
     int abl;   // timing ablations (wrong results): 1 = global loads of the first K tile only, 2 = LDS stores / barriers of the first K tile only, 4 = no epilogue stores
 #endif
@@ -189,6 +192,7 @@ inline void ensure_dynamic_lds(const void* kernel, int bytes, bool* done) {
 }
 int launch_gemm_h2(hipStream_t s, const GemmArgs& g);   // gemm_h2.hip: split GEMM on the f16 matrix pipe (GemmArgs::Bh / Bl), called by launch_gemm_nt
 void launch_split_f16(hipStream_t s, const float* x, uint16_t* hi, uint16_t* lo, size_t n);
+bool gemm_nt_rope_ok(const GemmArgs& g);                  // may launch_gemm_nt carry GemmArgs::rope_csn for this shape? (set rope_c0 / rope_c1 first)
 int launch_gemm_nt(hipStream_t s, const GemmArgs& g);   // returns the number of partial-statistics pairs per row it wrote (0 without stats_out)
 // The throughput tiles (128-row) take a problem when they give every CU a workgroup; everything smaller is the LATENCY regime (one or a
 // few pairs per call -- what the reference itself runs): gemm_lat.hip / lg_attention_lat.hip serve it, gemm.hip's 64-row tiles what they refuse.
@@ -229,7 +233,8 @@ void launch_lg_attention(hipStream_t s, const float* q, const float* k, const fl
                          const int* kv_map /*seq -> kv seq index, or null = identity*/,
                          float* part /*lg_attention_part_bytes(nseq, Lq) of scratch for the split-key variant, or null*/,
                          const float* rope_csn = nullptr /*self blocks: rotary table [nseq*Lq, 32] of (cos, sin) pairs, applied to q and k on load*/,
-                         bool fp16x2 = false /*RFE_OPT_LG_FP16X2: problems of >= 32 768 query rows take lg_attention_h2.hip's split products on the f16 matrix pipe*/);
+                         bool fp16x2 = false /*RFE_OPT_LG_FP16X2: problems of >= 32 768 query rows take lg_attention_h2.hip's split products on the f16 matrix pipe*/,
+                         bool k_roped = false /*with rope_csn: k is already rotated (gemm.hip's rotary epilogue), only q is rotated on load*/);
 void launch_lg_attention_h2(hipStream_t s, const float* q, const float* k, const float* v, int ld, float* out, int nseq, int Lq, int Lk,
                             const int* qlen, const int* klen, const int* kv_map, const float* rope_csn);   // lg_attention_h2.hip
 size_t lg_attention_part_bytes(int nseq, int Lq);
