@@ -366,6 +366,13 @@ int rfe_k_lightglue_ffn(rfe_ctx* ctx, int layer, int cross, const float* x_dev, 
  * the forward's launcher, so nseq * Lq and RFE_OPT_LG_FP16X2 select the kernel exactly as inside a match call. */
 int rfe_k_attention(rfe_ctx* ctx, const float* q_dev, const float* k_dev, const float* v_dev, int ld, float* out_dev, int nseq, int Lq, int Lk,
                     const int32_t* qlen_dev, const int32_t* klen_dev, const int32_t* kv_map_dev, const float* rope_dev);
+/* Projection + attention of one self block with the loaded weights, through the forward's own code: x_dev [nseq*L, 256] token rows, csn_dev [nseq*L, 32]
+ * (cos, sin) rotary pairs, lens_dev [nseq] valid rows; qkv_out_dev [nseq*L, 768] = [q | k | v] as the attention reads them, ctx_out_dev [nseq*L, 256]
+ * (either may be NULL).  nseq * L selects the path as inside a match call: throughput shapes rotate q | k in the projection's epilogue (gemm.hip) and run
+ * the LDS-DMA attention kernel, one / few pairs take gemm_lat.hip + lg_attention_lat.hip; *qk_rotated = 1 when qkv_out's q | k are rotated (0: the
+ * fallback that rotates on load).  L % 4 == 0. */
+int rfe_k_lightglue_self_attention(rfe_ctx* ctx, int layer, const float* x_dev, const float* csn_dev, const int32_t* lens_dev, int nseq, int L,
+                                   float* qkv_out_dev, float* ctx_out_dev, int32_t* qk_rotated);
 /* One-shot tap for the NEXT LightGlue forward of this ctx, whichever entry point runs it (rfe_match[_dev] with P pairs,
  * rfe_extract_match_stream_dev, rfe_stereo_frame_dev) and therefore whichever tiling it selects: after the last layer the final
  * token states of pair `pair` are copied to x0_dev / x1_dev ([L,256] each, L = max(Mmax,Nmax) rounded up to 4; rows past the

@@ -955,8 +955,9 @@ void lg_ffn(rfe_ctx* c, LgBuffers& b, float* x, const float* second, int rows, c
       launch_gemm_nt(s, a); }
 }
 
-// self block on `nseq` sequences of L tokens held in x (in place); scratch: b.qkv, b.ctx, b.msg, b.h
-void lg_self_block(rfe_ctx* c, LgBuffers& b, const LgLayerDev& Lw, float* x, const float* csn, const int32_t* lens, int nseq, int L) {
+// projection + attention of a self block: b.qkv <- [q | k | v] (q | k rotated, unless the fallback named below ran), b.ctx <- softmax(q k^T / 8) v per head.
+// Returns whether b.qkv holds ROTATED q | k (false: the plain-epilogue fallback, rotary applied by the attention kernel on load).
+bool lg_self_qkv_attention(rfe_ctx* c, LgBuffers& b, const LgLayerDev& Lw, const float* x, const float* csn, const int32_t* lens, int nseq, int L) {
     hipStream_t s = c->stream;
     const int rows = nseq * L;
     // q,k,v = Wqkv x + b, q and k rotated by the projection's epilogue -- gemm_lat.hip at one / few pairs, gemm.hip's ROPE tile at throughput shapes (table
@@ -978,6 +979,14 @@ void lg_self_block(rfe_ctx* c, LgBuffers& b, const LgLayerDev& Lw, float* x, con
       } }
     { ProfScope p(c, "lg_attention");
       launch_lg_attention(s, b.qkv, b.qkv + 256, b.qkv + 512, 768, b.ctx, nseq, L, L, lens, lens, nullptr, lg_part(b, nseq, L), roped ? nullptr : csn, c->opt_lg_fp16x2, k_roped); }
+    return roped;
+}
+
+// self block on `nseq` sequences of L tokens held in x (in place); scratch: b.qkv, b.ctx, b.msg, b.h
+void lg_self_block(rfe_ctx* c, LgBuffers& b, const LgLayerDev& Lw, float* x, const float* csn, const int32_t* lens, int nseq, int L) {
+    hipStream_t s = c->stream;
+    const int rows = nseq * L;
+    lg_self_qkv_attention(c, b, Lw, x, csn, lens, nseq, L);
     if (c->opt_lg_fold) {
         lg_ffn(c, b, x, b.ctx, rows, Lw.w1f, Lw.b1f, Lw.lng, Lw.lnb, Lw.w2, Lw.b2);
     } else {
@@ -1714,6 +1723,29 @@ extern "C" int rfe_k_set_lightglue_tap(rfe_ctx* c, int pair, float* x0, float* x
     if (!c) return RFE_ERR_INVALID;
     if (pair < 0) { c->tap.armed = false; return RFE_OK; }
     c->tap.armed = true; c->tap.pair = pair; c->tap.x0 = x0; c->tap.x1 = x1; c->tap.scores = scores;
+    return RFE_OK;
+}
+
+// projection + attention of layer `layer`'s self block on caller-provided token rows x [nseq * L, 256] with the rotary table csn [nseq * L, 32] (cos, sin),
+// through the forward's own lg_self_qkv_attention -- so nseq * L selects the path (throughput: rotary in gemm.hip's epilogue + lg_attention_dma_kernel;
+// one / few pairs: gemm_lat.hip + lg_attention_lat_kernel; shapes neither takes: plain epilogue + rotary on load).  qkv_out [nseq * L, 768], ctx_out [nseq * L, 256];
+// *qk_rotated = 1 when qkv_out's q | k columns are rotated.
+extern "C" int rfe_k_lightglue_self_attention(rfe_ctx* c, int layer, const float* x, const float* csn, const int32_t* lens, int nseq, int L,
+                                              float* qkv_out, float* ctx_out, int32_t* qk_rotated) {
+    int rc = lg_check(c, 1, 4, 4);
+    if (rc) return rc;
+    if (layer < 0 || layer >= LG_LAYERS || nseq <= 0 || L <= 0 || (L % 4) || !x || !csn || !lens) return fail(c, RFE_ERR_INVALID, "k_lightglue_self_attention: bad argument");
+    RFE_HIP(c, hipSetDevice(c->device));
+    const int P = (nseq + 1) / 2;
+    if ((rc = ensure_ws(c, &c->ws_lg, &c->ws_lg_bytes, lg_ws_bytes(P, L)))) return rc;
+    LgBuffers b;
+    lg_carve(c->ws_lg, P, L, b);
+    const bool rot = lg_self_qkv_attention(c, b, c->lg.L[layer], x, csn, lens, nseq, L);
+    RFE_HIP(c, hipGetLastError());
+    if (qkv_out) RFE_HIP(c, hipMemcpyAsync(qkv_out, b.qkv, (size_t)nseq * L * 768 * 4, hipMemcpyDeviceToDevice, c->stream));
+    if (ctx_out) RFE_HIP(c, hipMemcpyAsync(ctx_out, b.ctx, (size_t)nseq * L * 256 * 4, hipMemcpyDeviceToDevice, c->stream));
+    RFE_HIP(c, hipStreamSynchronize(c->stream));
+    if (qk_rotated) *qk_rotated = rot ? 1 : 0;
     return RFE_OK;
 }
 
