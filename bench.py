@@ -87,7 +87,7 @@ def stage_flops(name, B, lens, launches=None):
     return None
 
 
-STAGE_KERNEL = {"lg_attention": ("lg_attention_kernel (self + cross", "lg_attention_kernel"), "conv1ab": ("conv1ab_fused_kernel",)}
+STAGE_KERNEL = {"lg_attention": ("lg_attention_kernel (self + cross", "lg_attention_dma_kernel", "lg_attention_kernel"), "conv1ab": ("conv1ab_fused_kernel",)}
 
 
 def pmc_traffic(stage):
@@ -100,7 +100,7 @@ def pmc_traffic(stage):
         if not keys or not os.path.exists(path):
             continue
         kernels = json.load(open(path))["kernels"]
-        for key in keys:        # from round 2 on the profiles hold one call-weighted entry for the attention's self (rotary) and cross kernels
+        for key in keys:        # rounds 2-4: one call-weighted entry for the attention's self (rotary) and cross kernels; round 5: one kernel, lg_attention_dma_kernel
             for name, v in kernels.items():
                 if key in name:
                     return v["traffic_bytes"], f"profiles/{rnd}_pmc_traffic.json:" + name

@@ -51,7 +51,7 @@ def main(tag, rnd=None):
 
 Command (MI355X box, tools/profile_round.sh {tag}): `rocprofv3 --kernel-trace --stats -d gpurun_out/{tag}/trace -o t -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variants --no-pool --sustained-steps 0` (1 warm-up + 3 fully instrumented + 3 timed steps of 33 frames + 32 pairs, plus the steps of the PCIe-inclusive loop; rocpd sqlite summarised by tools/rocpd_stats.py).
 
-Un-profiled bench.py line from the same box just before: profiles/{rnd}_bench.json ({d['value']} frames/s, {d['ms_per_step']} ms/step; lg_attention avg {d['roofline']['avg_launch_ms'] * 1e3:.1f} us by HIP events in the timed region, {att_avg:.1f} us in this trace over its self (rotary, register-staged) and cross (LDS-DMA) kernels: {', '.join(f'{n} {a:.1f} us x {c}' for n, c, a in att)}).
+Un-profiled bench.py line from the same box just before: profiles/{rnd}_bench.json ({d['value']} frames/s, {d['ms_per_step']} ms/step; lg_attention avg {d['roofline']['avg_launch_ms'] * 1e3:.1f} us by HIP events in the timed region, {att_avg:.1f} us in this trace: {', '.join(f'{n} {a:.1f} us x {c}' for n, c, a in att)}).
 
 """
     open(os.path.join(P, f"{rnd}_kernel_stats.md"), "w").write(head + stamp_line + "\n" + ks)
@@ -59,7 +59,7 @@ Un-profiled bench.py line from the same box just before: profiles/{rnd}_bench.js
     sq_tab, _ = split(capture(rocpd_pmc.main, [os.path.join(O, "pmc_sq", "s_results.db")]))
     # bench.py's roofline.traffic looks the dominant stage up by kernel-name substring: give the attention one merged entry
     am = [v for k, v in hj.items() if k.startswith("lg_attention_kernel<0, false") or k == "lg_attention_dma_kernel"]
-    if am:
+    if len(am) > 1:   # rounds 2-4: self blocks on the register-staged rotary kernel, cross blocks on the LDS-DMA kernel (round 5: every launch is lg_attention_dma_kernel)
         tot = sum(v["calls"] for v in am)
         hj["lg_attention_kernel (self + cross variants, call-weighted)"] = {k: sum(v[k] * v["calls"] for v in am) / tot for k in ("FETCH_SIZE", "WRITE_SIZE", "traffic_bytes", "avg_us")} | {"calls": tot}
     out = {"note": "per-launch HBM traffic from rocprofv3 PMC, (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes, bench.py workload (33 frames / 32 pairs "
