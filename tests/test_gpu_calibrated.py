@@ -190,3 +190,36 @@ def test_stream_big_batches_of_configs3_strong_scaling(oracle, wcal, B):
             d.free()
     finally:
         c.close()
+
+
+def test_k2048_one_pair_and_three_pairs_calibrated_1e4(ctx, oracle, wcal):
+    """K = 2048 keypoints per image (max_num_keypoints of the published LightGlue-style exports' other setting, tests/test_onnx_hparams.py; the reference reads K off
+    the output tensor, src/Extractors/superpoint_onnx.cc:169-181, and passes whatever it gets to lightglue_sim.onnx): sequences of 2048 tokens through the
+    one-pair path (4096 rows: latency tiles, 2048-key attention) and through a 3-pair call (12 288 rows: throughput tiles, the rotary epilogue of the qkv
+    projection, lg_attention_dma_kernel with 16 query blocks per sequence), ragged lengths included; pairs 0 and 2 against the oracle."""
+    K = 2048
+    lens0, lens1 = [2048, 1800, 1531], [2048, 2048, 1999]
+    k0, k1, d0, d1 = _constructed_batch(3, K, 777, lens0, lens1)
+    S3, pairs3, ms3 = ctx.match(k0, k1, d0, d1, lens0, lens1)
+    S1, pairs1, ms1 = ctx.match(k0[:1], k1[:1], d0[:1], d1[:1], lens0[:1], lens1[:1])
+    for p in (0, 2):
+        r = oracle.lightglue(wcal[1], k0[p, :lens0[p]], k1[p, :lens1[p]], d0[p, :lens0[p]], d1[p, :lens1[p]])
+        same, dev = _identical(pairs3[p, :S3[p]], ms3[p, :S3[p]], r)
+        assert same and dev < LG_SCORE_TOL_CALIBRATED and r["S"] > 0.5 * min(lens0[p], lens1[p]), (p, same, dev, r["S"])
+        print(f"K = 2048, pair {p} of a 3-pair call: {r['S']} matches, lists identical, max |score dev| {dev:.2e}")
+        if p == 0:
+            same, dev = _identical(pairs1[0, :S1[0]], ms1[0, :S1[0]], r)
+            assert same and dev < LG_SCORE_TOL_CALIBRATED, (same, dev)
+            print(f"K = 2048, one pair per call: lists identical, max |score dev| {dev:.2e}")
+
+
+def test_k4096_one_pair_calibrated_1e4(ctx, oracle, wcal):
+    """the largest keypoint budget the C ABI accepts (Kmax <= 4096, include/rover_fe.h): one pair of 4096 / 3900 keypoints = 8192 token rows, the upper
+    edge of the one-pair tilings; a 64 MB log-assignment matrix"""
+    K = 4096
+    k0, k1, d0, d1 = _constructed_batch(1, K, 4242, [4096], [3900])
+    S, pairs, ms = ctx.match(k0, k1, d0, d1, [4096], [3900])
+    r = oracle.lightglue(wcal[1], k0[0], k1[0, :3900], d0[0], d1[0, :3900])
+    same, dev = _identical(pairs[0, :S[0]], ms[0, :S[0]], r)
+    assert same and dev < LG_SCORE_TOL_CALIBRATED and r["S"] > 1500, (same, dev, r["S"])
+    print(f"K = 4096, one pair: {r['S']} matches, lists identical, max |score dev| {dev:.2e}")
