@@ -112,6 +112,37 @@ def test_extract_bitexact_vs_oracle(ctx, oracle, H, W, kmax):
         assert np.array_equal(desc[i], r["desc"])      # stated bar 1e-4; achieved: bit-exact
 
 
+@pytest.mark.parametrize("B,H,W,kmax", [(1, 1080, 1920, 4096), (2, 720, 1280, 2048)])
+def test_extract_large_frames_bitexact_vs_oracle(ctx, oracle, B, H, W, kmax):
+    """frames well above the benchmark's 640 x 480 (the reference accepts any size its ONNX graph does, superpoint_onnx.cc:100: dynamic H, W): one
+    1920 x 1080 frame (135 x 240 cells, 530 MB of conv1 activations) and two 1280 x 720 frames, the largest keypoint budgets -- keypoints, scores and
+    descriptors bit for bit"""
+    frames, _ = synth.make_frames(B, H, W, seed=H + kmax)
+    n, kxy, score, desc = ctx.extract(frames, kmax=kmax)
+    w = Wt.make_superpoint(seed=7)
+    for i in range(B):
+        r = oracle.superpoint(w, frames[i], kmax=kmax)
+        assert n[i] == r["n"] and r["n"] > 1000
+        assert np.array_equal(kxy[i], r["kxy"]) and np.array_equal(score[i], r["score"]) and np.array_equal(desc[i], r["desc"])
+
+
+def test_extract_degenerate_frames_bitexact_vs_oracle(ctx, oracle):
+    """what a camera really delivers now and then: an all-black frame, a saturated one, a frame whose lower half is constant.  A constant region makes the
+    score map constant per cell position, so simple_nms's EQUALITY mask keeps every pixel of it and top-k has to break thousands of exact ties (score descending,
+    pixel index ascending: the published graph's TopK on the row-major candidate list) -- same keypoints, same order, same descriptors as the oracle"""
+    H, W, kmax = 240, 320, 1024
+    frames, _ = synth.make_frames(4, H, W, seed=5)
+    frames[0] = 0
+    frames[1] = 255
+    frames[2, H // 2:] = 37
+    n, kxy, score, desc = ctx.extract(frames, kmax=kmax)
+    w = Wt.make_superpoint(seed=7)
+    for i in range(4):
+        r = oracle.superpoint(w, frames[i], kmax=kmax)
+        assert n[i] == r["n"], (i, n[i], r["n"])
+        assert np.array_equal(kxy[i], r["kxy"]) and np.array_equal(score[i], r["score"]) and np.array_equal(desc[i], r["desc"]), i
+
+
 @pytest.mark.parametrize("H,W,kmax", [(120, 160, 300), (480, 640, 1024), (93, 201, 64)])
 def test_extract_float_entry_bitexact_vs_oracle(ctx, oracle, H, W, kmax):
     """rfe_extract_f32 = the reference's Extractor_Inference on a CV_32F image (superpoint_onnx.cc:88-118): (a) on u8 * (1/255) it is the u8
