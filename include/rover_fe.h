@@ -135,8 +135,10 @@ int rfe_set_hparams(rfe_ctx* ctx, const rfe_hparams* in);
 #define RFE_OPT_LG_FOLD_WO 1
 #define RFE_OPT_LG_FP16X2 2
 /* RFE_OPT_HOST_GRAPH (default 0): the synchronous host entries (rfe_extract_u8 / _bin / _f32, rfe_match / rfe_match_fused) submit their kernel sequence as ONE
- *   replayed hipGraph per call shape instead of 17 .. 100 stream launches (captured on the second call of a shape; weights, hyper-parameters, options, workspaces
- *   and shape are part of the key; profiling falls back).  Results are identical.  The device is busy for 98 % of a one-pair call either way, so the median
+ *   replayed hipGraph per call shape instead of 17 .. 100 stream launches (captured on the THIRD call of a shape, four shapes kept per entry, least recently
+ *   used replaced; weights, hyper-parameters, options, workspaces and shape are part of the key; profiling falls back).  For rfe_match the shape holds Mmax
+ *   and Nmax, so the option only helps FIXED-CAPACITY callers (keypoint counts that saturate, or are padded to, a capacity): a caller whose counts differ on
+ *   every frame never repeats a shape, is never captured and gets ordinary launches.  Results are identical.  The device is busy for 98 % of a one-pair call either way, so the median
  *   does not move; the option is there for hosts whose threads get preempted inside the enqueue burst (tail latency).  Measured: profiles/r05_ab_notes.md. */
 #define RFE_OPT_HOST_GRAPH 3
 int rfe_set_option(rfe_ctx* ctx, int option, int value);

@@ -12,8 +12,8 @@ LIB_PATH = os.environ.get("RFE_LIBRARY") or os.path.join(_HERE, "librover_fe.so"
 
 KIND_SUPERPOINT, KIND_LIGHTGLUE = 1, 2
 OPT_LG_FOLD_WO = 1
-OPT_LG_FP16X2 = 2
-OPT_HOST_GRAPH = 3   # host entries replay a captured hipGraph per call shape (default off)   # LightGlue Linears + attention of batched calls as split products on the f16 matrix pipe (default off)
+OPT_LG_FP16X2 = 2    # LightGlue Linears + attention as split products on the f16 matrix pipe (default off)
+OPT_HOST_GRAPH = 3   # host entries replay a captured hipGraph per repeated call shape (default off; helps fixed-capacity callers only)
 
 EXPORTS = [
     "rfe_init", "rfe_destroy", "rfe_last_error", "rfe_version", "rfe_load_weights", "rfe_load_onnx", "rfe_set_weights",

@@ -85,9 +85,10 @@ bool fields(const Buf& b, F&& f) {
         if (!varint(b, i, key)) return false;
         Field fd{(int)(key >> 3), (int)(key & 7), 0, {nullptr, 0}};
         if (fd.wt == 0) { if (!varint(b, i, fd.v)) return false; }
-        else if (fd.wt == 1) { if (i + 8 > b.n) return false; fd.b = {b.p + i, 8}; i += 8; }
-        else if (fd.wt == 2) { uint64_t ln; if (!varint(b, i, ln) || i + ln > b.n) return false; fd.b = {b.p + i, (size_t)ln}; i += (size_t)ln; }
-        else if (fd.wt == 5) { if (i + 4 > b.n) return false; fd.b = {b.p + i, 4}; i += 4; }
+        // every bound is written as "length > bytes left" (i <= b.n holds here): a 10-byte varint length near 2^64 must not wrap `i + ln`
+        else if (fd.wt == 1) { if (b.n - i < 8) return false; fd.b = {b.p + i, 8}; i += 8; }
+        else if (fd.wt == 2) { uint64_t ln; if (!varint(b, i, ln) || ln > (uint64_t)(b.n - i)) return false; fd.b = {b.p + i, (size_t)ln}; i += (size_t)ln; }
+        else if (fd.wt == 5) { if (b.n - i < 4) return false; fd.b = {b.p + i, 4}; i += 4; }
         else return false;
         f(fd);
     }
@@ -588,8 +589,11 @@ bool fill_lg_blob(const std::map<std::string, Placed>& t, std::vector<float>& bl
     blob.assign(total, 0.f);
     for (const auto& e : man) {
         auto it = t.find(e.name);
-        if (it == t.end() || it->second.shape != e.shape) { missing.push_back(e.name + (it == t.end() ? "" : " (shape)")); continue; }
-        memcpy(blob.data() + e.off, it->second.v.data(), it->second.v.size() * 4);
+        size_t cnt = 1;
+        for (auto d : e.shape) cnt *= (size_t)d;
+        // the copy is sized by the MANIFEST; a placed tensor must have exactly that shape and exactly that many values
+        if (it == t.end() || it->second.shape != e.shape || it->second.v.size() != cnt) { missing.push_back(e.name + (it == t.end() ? "" : " (shape)")); continue; }
+        memcpy(blob.data() + e.off, it->second.v.data(), cnt * 4);
     }
     return missing.empty();
 }
@@ -603,7 +607,7 @@ bool convert_lg_by_structure(const Model& m, const std::string& path, std::vecto
     std::set<std::string> seen;
     auto is512 = [&](const std::string& nm) { const Tensor* t = m.init(nm); return t && t->dtype == 1 && t->ndim() == 1 && t->size() == 512 ? t : nullptr; };
     for (const auto& n : m.nodes) {
-        if (n.op == "LayerNormalization" && n.inputs.size() >= 3 && is512(n.inputs[1])) {
+        if (n.op == "LayerNormalization" && n.inputs.size() >= 3 && is512(n.inputs[1]) && is512(n.inputs[2])) {   // beta validated exactly like gamma
             if (!seen.count(n.inputs[1])) { seen.insert(n.inputs[1]); lns.push_back({m.init(n.inputs[1]), m.init(n.inputs[2])}); }
         } else if (n.op == "Mul") {
             std::vector<std::string> g;
@@ -714,6 +718,7 @@ bool convert_lg(const Model& m, const std::string& path, std::vector<float>& blo
     std::map<std::string, Placed> t;
     {
         const Tensor* wr = m.init("posenc.Wr.weight");
+        if (wr && !(wr->dtype == 1 && (wr->shape_is({32, 2}) || wr->shape_is({2, 32})))) wr = nullptr;    // a tensor of that name with another type / shape is not it
         if (!wr)                                          // bias-free Linear: anonymous MatMul constant [2,32]
             for (const auto& nm : m.order) { const Tensor& c = m.inits.at(nm); if (c.dtype == 1 && (c.shape_is({2, 32}) || c.shape_is({32, 2}))) { wr = &c; break; } }
         if (!wr) missing.push_back("posenc.Wr");
@@ -767,7 +772,7 @@ bool convert_lg(const Model& m, const std::string& path, std::vector<float>& blo
 // kind 1 / 2 -> canonical blob + the graph's hyper-parameters written into *hp (only this kind's fields).  Nothing is guessed: any problem of
 // the readers is an error (the C entry takes no `assume`; a caller who must state a value converts with the Python tool's --assume-* and loads
 // the RFEW file, or calls rfe_set_hparams afterwards).
-bool onnx_convert(const std::string& path, int kind, std::vector<float>& blob, rfe_hparams* hp, std::string& err) {
+static bool onnx_convert_impl(const std::string& path, int kind, std::vector<float>& blob, rfe_hparams* hp, std::string& err) {
     Model m;
     if (!read_model(path, m, err)) return false;
     std::vector<std::string> errors;
@@ -799,10 +804,23 @@ bool onnx_convert(const std::string& path, int kind, std::vector<float>& blob, r
 }
 
 // the weights alone (tools that only need them; the Python convert_superpoint / convert_lightglue)
-bool onnx_convert_weights_only(const std::string& path, int kind, std::vector<float>& blob, std::string& err) {
+static bool onnx_convert_weights_only_impl(const std::string& path, int kind, std::vector<float>& blob, std::string& err) {
     Model m;
     if (!read_model(path, m, err)) return false;
     return kind == RFE_KIND_SUPERPOINT ? convert_sp(m, path, blob, err) : kind == RFE_KIND_LIGHTGLUE ? convert_lg(m, path, blob, err) : false;
+}
+
+// Nothing thrown by the reader (std::bad_alloc / std::length_error of a container sized by a hostile file, std::out_of_range) crosses into the
+// extern "C" entries that call these two: an unreadable graph is `false` + a reason, which the callers turn into RFE_ERR_IO.
+bool onnx_convert(const std::string& path, int kind, std::vector<float>& blob, rfe_hparams* hp, std::string& err) {
+    try { return onnx_convert_impl(path, kind, blob, hp, err); }
+    catch (const std::exception& e) { err = path + ": cannot be read as an ONNX graph (" + e.what() + ")"; return false; }
+    catch (...) { err = path + ": cannot be read as an ONNX graph"; return false; }
+}
+bool onnx_convert_weights_only(const std::string& path, int kind, std::vector<float>& blob, std::string& err) {
+    try { return onnx_convert_weights_only_impl(path, kind, blob, err); }
+    catch (const std::exception& e) { err = path + ": cannot be read as an ONNX graph (" + e.what() + ")"; return false; }
+    catch (...) { err = path + ": cannot be read as an ONNX graph"; return false; }
 }
 
 }  // namespace rfe

@@ -60,32 +60,53 @@ bool is_lib_pinned(const void* p, size_t bytes) {
 }
 
 // RFE_OPT_HOST_GRAPH: run `enqueue` (the kernel launches of a host entry, on c->stream and -- forked and joined by events -- c->side_stream) as a replayed
-// hipGraph.  First call of a key: ordinary launches (workspaces grow, function attributes are set -- neither is legal inside a capture).  Second call:
-// the same launches under hipStreamBeginCapture, instantiated, launched.  From then on one hipGraphLaunch per call.  Anything the kernel arguments bake in
-// is part of the key (shape, thresholds, workspace addresses, settings_gen); profiling and the test tap fall back to ordinary launches.  A failed capture
-// or instantiation falls back too -- the option never changes results, only how the work is submitted.
+// hipGraph.  A key is everything the kernel arguments bake in (shape, thresholds, workspace addresses, settings_gen).  The first HOST_GRAPH_REPEATS - 1
+// calls of a key are ordinary launches (workspaces grow, function attributes are set -- neither is legal inside a capture -- and a shape that never
+// comes back never pays a capture); the next one runs under hipStreamBeginCapture, is instantiated into one of four LRU slots, and launched; from then on
+// one hipGraphLaunch per call.  Alternating shapes (left / right, stereo sizes) keep their graphs; a caller whose keypoint counts differ on every frame
+// gets ordinary launches throughout -- the option only helps FIXED-CAPACITY callers (counts saturating Kmax, or padded to it).  Profiling and the test
+// tap fall back to ordinary launches, and so does a failed capture or instantiation: the option never changes results, only how the work is submitted.
+constexpr int HOST_GRAPH_REPEATS = 3;
 template <typename F>
 int run_host_graph(rfe_ctx* c, rfe_ctx::HostGraph& g, const std::string& key, F&& enqueue) {
     if (!c->opt_host_graph || c->prof || c->tap.armed) return enqueue();
-    if (g.exec && g.key == key) { RFE_HIP(c, hipGraphLaunch(g.exec, c->stream)); return RFE_OK; }
-    if (g.seen != key) { g.seen = key; return enqueue(); }
-    if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; g.key.clear(); }
-    if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return enqueue(); }
+    ++g.tick;
+    for (auto& sl : g.slot)
+        if (sl.exec && sl.key == key) { sl.used = g.tick; RFE_HIP(c, hipGraphLaunch(sl.exec, c->stream)); return RFE_OK; }
+    rfe_ctx::HostGraph::Seen* sn = nullptr;
+    for (auto& q : g.seen) if (q.count > 0 && q.key == key) sn = &q;
+    if (!sn) {                                         // a new key takes the least recently used history entry
+        sn = &g.seen[0];
+        for (auto& q : g.seen) if (q.used < sn->used) sn = &q;
+        sn->key = key; sn->count = 0;
+    }
+    sn->used = g.tick;
+    if (++sn->count < HOST_GRAPH_REPEATS) return enqueue();
+    if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); sn->count = 0; return enqueue(); }
     const int rc = enqueue();
     hipGraph_t graph = nullptr;
     const hipError_t e = hipStreamEndCapture(c->stream, &graph);
     if (rc != RFE_OK || e != hipSuccess || !graph) {
         if (graph) (void)hipGraphDestroy(graph);
         (void)hipGetLastError();
-        g.seen.clear();
+        sn->count = 0;
         return rc != RFE_OK ? rc : enqueue();          // nothing ran during the capture: submit it the ordinary way
     }
-    const hipError_t ei = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
-    if (ei != hipSuccess) { g.exec = nullptr; (void)hipGetLastError(); g.seen.clear(); return enqueue(); }
-    g.key = key;
-    RFE_HIP(c, hipGraphLaunch(g.exec, c->stream));
+    if (ei != hipSuccess || !exec) { (void)hipGetLastError(); sn->count = 0; return enqueue(); }
+    rfe_ctx::HostGraph::Slot* sl = &g.slot[0];
+    for (auto& q : g.slot) { if (!q.exec) { sl = &q; break; } if (q.used < sl->used) sl = &q; }
+    if (sl->exec) (void)hipGraphExecDestroy(sl->exec);
+    sl->exec = exec; sl->key = key; sl->used = g.tick;
+    sn->count = 0; sn->key.clear();                    // the history entry is free again: the slot remembers the key now
+    RFE_HIP(c, hipGraphLaunch(sl->exec, c->stream));
     return RFE_OK;
+}
+static void host_graph_release(rfe_ctx::HostGraph& g) {
+    for (auto& sl : g.slot) { if (sl.exec) (void)hipGraphExecDestroy(sl.exec); sl.exec = nullptr; sl.key.clear(); }
+    for (auto& q : g.seen) { q.key.clear(); q.count = 0; }
 }
 static std::string host_graph_key(const rfe_ctx* c, const char* kind, std::initializer_list<long long> v) {
     std::string k = kind;
@@ -179,8 +200,8 @@ extern "C" void rfe_destroy(rfe_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    if (c->g_extract.exec) (void)hipGraphExecDestroy(c->g_extract.exec);
-    if (c->g_match.exec) (void)hipGraphExecDestroy(c->g_match.exec);
+    host_graph_release(c->g_extract);
+    host_graph_release(c->g_match);
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
     c->sp_hold.reset(); c->lg_hold.reset();   // the last ctx holding a device copy frees it
     fr(c->ws_sp); fr(c->ws_lg); fr(c->ws_io); fr(c->ws_tmp); fr(c->ws_st);

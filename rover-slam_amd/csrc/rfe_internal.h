@@ -119,7 +119,13 @@ struct rfe_ctx {
     bool opt_host_graph = false;         // RFE_OPT_HOST_GRAPH: the synchronous host entries replay a captured hipGraph of their kernel sequence
     // one instantiated graph per host entry kind (extract / match): `key` names the call shape + every pointer and setting baked into the kernel arguments,
     // `seen` the shape of the last ordinary call (a shape is captured on its SECOND call: the first one allocates workspaces and sets function attributes)
-    struct HostGraph { std::string key, seen; hipGraphExec_t exec = nullptr; };
+    // RFE_OPT_HOST_GRAPH: a few instantiated graphs per entry (LRU), and a short history of the keys seen lately with their counts -- a shape is captured
+    // only once it has come back HOST_GRAPH_REPEATS times, so a caller whose shapes never repeat (per-frame keypoint counts) pays no capture at all
+    struct HostGraph {
+        struct Slot { std::string key; hipGraphExec_t exec = nullptr; unsigned long long used = 0; };
+        struct Seen { std::string key; int count = 0; unsigned long long used = 0; };
+        Slot slot[4]; Seen seen[8]; unsigned long long tick = 0;
+    };
     HostGraph g_extract, g_match;
     unsigned long long settings_gen = 0; // bumped by everything a captured graph bakes in: weights, hyper-parameters, options
     rfe_hparams hp = rfe_default_hparams();   // graph hyper-parameters (RFEW v2 header / rfe_set_hparams)

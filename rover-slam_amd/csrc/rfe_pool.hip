@@ -87,6 +87,7 @@ struct rfe_pool {
     RcclApi api;
     bool rccl_up = false;
     std::atomic<bool> rccl_broken{false};                 // a member's gather failed: communicators are torn down, the pool continues on COPY
+    std::mutex abort_mu;                                  // taking a member's handle out of Member::comm for its abort (own abort and a peer's abort may meet)
     std::shared_mutex comm_mu;                            // shared: a member is posting its group (uses its comm handle); exclusive: every communicator is being aborted
     std::atomic<int> inject_fail{-1};                     // test hook (rfe_k_pool_inject_gather_failure): this member's next gather fails inside its group
     std::string rccl_why;                                 // why the RCCL transport is unavailable
@@ -208,9 +209,19 @@ static int run_member(rfe_pool* p, int r) {
         if (first != ncclSuccess) {
             mb.err = std::string(where) + ": " + p->api.GetErrorString(first);
             p->rccl_broken.store(true);
-            std::unique_lock<std::shared_mutex> all(p->comm_mu);
-            for (auto& q : p->m)
-                if (q.comm) { (void)hipSetDevice(q.device); (void)(p->api.CommAbort ? p->api.CommAbort(q.comm) : p->api.CommDestroy(q.comm)); q.comm = nullptr; }
+            auto abort_member = [&](Member& q) {
+                ncclComm_t c;
+                { std::lock_guard<std::mutex> g(p->abort_mu); c = q.comm; q.comm = nullptr; }
+                if (c) { (void)hipSetDevice(q.device); (void)(p->api.CommAbort ? p->api.CommAbort(c) : p->api.CommDestroy(c)); }
+            };
+            // OWN communicator first and at once (only this thread posts on that handle, and it has left its group): a peer whose ncclGroupEnd blocks on
+            // this member -- first-use connection set-up does -- holds the SHARED lock until this abort releases it; waiting for the exclusive lock
+            // before any abort would be a deadlock.  Then, exclusively (no peer between GroupStart and GroupEnd), everybody else's.
+            abort_member(mb);
+            {
+                std::unique_lock<std::shared_mutex> all(p->comm_mu);
+                for (auto& q : p->m) abort_member(q);
+            }
             (void)hipSetDevice(mb.device);
             return RFE_ERR_HIP;
         }

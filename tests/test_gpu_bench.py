@@ -18,7 +18,22 @@ def _bench(*argv, env=None):
         e.pop(k, None)
     e.update(env or {})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=e, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
+    if r.returncode != 0:      # the reason lives in the JSON line on stdout (invalid / invalid_aux / *.error), not only on stderr
+        why = {}
+        try:
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            why = {k: d[k] for k in ("invalid", "invalid_aux", "perf_notes") if k in d}
+            for sect in ("variants", "latency", "pool_c_abi", "pcie_inclusive"):
+                v = d.get(sect)
+                if isinstance(v, dict):
+                    errs = {k: x["error"] for k, x in v.items() if isinstance(x, dict) and "error" in x}
+                    if "error" in v and isinstance(v["error"], str):
+                        errs["error"] = v["error"]
+                    if errs:
+                        why[sect + ".errors"] = errs
+        except (ValueError, IndexError):
+            why = {"stdout_tail": r.stdout[-1500:]}
+        pytest.fail(f"bench.py {' '.join(argv)} exited {r.returncode}\nline says: {json.dumps(why, indent=1)[:3000]}\nstderr tail:\n{r.stderr[-2000:]}")
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
@@ -53,3 +68,5 @@ def test_bench_rccl_code_path_at_world_size_one():
     assert d["n_gpus"] == 1 and d["rccl"]["backend"] == "nccl" and d["rccl"]["world_size"] == 1 and d["rccl"]["allreduce_sum_of_ones"] == 1
     assert d["gather"]["collectives_per_step"] == 1 and d["gather"]["last_step_payload_verified"] is True
     assert abs(d["value"] - 32 * 1e3 / d["ms_per_step"]) / d["value"] < 1e-3
+    assert d["rccl"]["untimed_collective_warmup_rounds"] >= 3          # the timed region never holds a communicator's first collectives
+    assert "r04_pairing_step_time_ratio" not in d.get("perf_notes", {})  # no step-time comparison against a loop that holds collectives

@@ -483,7 +483,7 @@ def test_extract_is_repeatable_when_the_heads_overlap(ctx, oracle, B, H, W, K):
 
 
 def test_host_graph_option_gives_identical_results(ctx, oracle):
-    """RFE_OPT_HOST_GRAPH: the host entries replay a captured hipGraph per call shape (captured on the second call; weights, hyper-parameters, options, shape
+    """RFE_OPT_HOST_GRAPH: the host entries replay a captured hipGraph per call shape (captured on the third call of a shape, four shapes kept; weights, hyper-parameters, options, shape
     and workspace addresses are part of the key).  Same bytes as ordinary launches for extract (u8 / float / binarised) and match, across shape changes,
     a weight change, a hyper-parameter change and back."""
     from rover_slam_amd import capi
