@@ -354,6 +354,9 @@ int rfe_k_scoremap(rfe_ctx* ctx, const uint8_t* img_dev, int H, int W, int strid
 /* keypoint selection alone on a post-NMS map (H, W multiples of 8 as the score-map frame always is): n [B], kxy [B,Kmax,2], score [B,Kmax] */
 int rfe_k_select(rfe_ctx* ctx, const float* nms_dev /*[B,H,W]*/, int B, int H, int W, int Kmax, float thr, int topk_always,
                  int32_t* n_dev, int32_t* kxy_dev, float* score_dev);
+/* the same through the form one to four frames take in the forward: an UNORDERED list of 64-bit candidate keys (as the fused detector tail leaves it), ranked */
+int rfe_k_select_keys(rfe_ctx* ctx, const float* nms_dev /*[B,H,W], B <= 4*/, int B, int H, int W, int Kmax, float thr, int topk_always,
+                      int32_t* n_dev, int32_t* kxy_dev, float* score_dev);
 int rfe_k_lightglue_taps(rfe_ctx* ctx, const float* k0n, const float* k1n, const float* d0,
                          const float* d1, int M, int N, float* x0_dev, float* x1_dev,
                          float* scores_dev /*[M,N]*/);

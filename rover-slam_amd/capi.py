@@ -25,7 +25,7 @@ EXPORTS = [
     "rfe_pool_create", "rfe_pool_destroy", "rfe_pool_last_error", "rfe_pool_size", "rfe_pool_ctx", "rfe_pool_has_rccl", "rfe_pool_set_weights",
     "rfe_pool_load_weights", "rfe_pool_set_option", "rfe_pool_set_hparams", "rfe_pool_shard", "rfe_pool_extract_match_stream",
     "rfe_profile_enable", "rfe_profile_filter", "rfe_profile_reset", "rfe_profile_read",
-    "rfe_k_conv3x3", "rfe_k_linear", "rfe_k_scoremap", "rfe_k_select", "rfe_k_lightglue_taps", "rfe_k_set_lightglue_tap", "rfe_k_lightglue_ffn", "rfe_k_attention", "rfe_k_lightglue_self_attention", "rfe_k_pool_inject_gather_failure", "rfe_k_onnx_convert",
+    "rfe_k_conv3x3", "rfe_k_linear", "rfe_k_scoremap", "rfe_k_select", "rfe_k_select_keys", "rfe_k_lightglue_taps", "rfe_k_set_lightglue_tap", "rfe_k_lightglue_ffn", "rfe_k_attention", "rfe_k_lightglue_self_attention", "rfe_k_pool_inject_gather_failure", "rfe_k_onnx_convert",
 ]
 
 if not os.path.exists(LIB_PATH):
@@ -104,6 +104,7 @@ lib.rfe_k_conv3x3.argtypes = [C.c_void_p, _fp, C.c_int, C.c_int, C.c_int, C.c_in
 lib.rfe_k_linear.argtypes = [C.c_void_p, _fp, C.c_int, C.c_int, _fp, _fp, C.c_int, C.c_int, _fp]
 lib.rfe_k_scoremap.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]
 lib.rfe_k_select.argtypes = [C.c_void_p, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _ip, _ip, _fp]
+lib.rfe_k_select_keys.argtypes = lib.rfe_k_select.argtypes
 lib.rfe_k_lightglue_taps.argtypes = [C.c_void_p, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]
 lib.rfe_k_set_lightglue_tap.argtypes = [C.c_void_p, C.c_int, _fp, _fp, _fp]
 lib.rfe_k_lightglue_ffn.argtypes = [C.c_void_p, C.c_int, C.c_int, _fp, _fp, C.c_int, _fp]

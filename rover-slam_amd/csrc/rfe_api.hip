@@ -204,7 +204,7 @@ extern "C" void rfe_destroy(rfe_ctx* c) {
     host_graph_release(c->g_match);
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
     c->sp_hold.reset(); c->lg_hold.reset();   // the last ctx holding a device copy frees it
-    fr(c->ws_sp); fr(c->ws_lg); fr(c->ws_io); fr(c->ws_tmp); fr(c->ws_st);
+    fr(c->ws_sp); fr(c->ws_lg); fr(c->ws_io); fr(c->ws_tmp); fr(c->ws_st); fr(c->sp_cnt);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -656,6 +656,7 @@ struct SpBuffers {
     uint8_t *mask, *supp;
     float* cand_score; int32_t* cand_idx;
     unsigned long long* sel_keys; int32_t* sel_n;     // selected (score, pixel) keys between select_kernel and select_rank_kernel
+    bool tail_fused = false;                          // sp_tail_lat_kernel ran: candidates are 64-bit keys at cand_score (cand_score | cand_idx = 8 B per pixel)
 };
 
 // conv1a as its own launch (78.6 MB/frame activation in HBM) instead of recomputed inside conv1b: A/B and test switch
@@ -730,7 +731,8 @@ int sp_check(rfe_ctx* c, int H, int W, int B, int Kmax) {
 // join = false: the caller still has detector-only work to enqueue and joins the descriptor stream itself
 // (hipStreamWaitEvent(c->stream, c->ev_join)) when `forked` comes back true
 int sp_forward_maps(rfe_ctx* c, const void* img, int H, int W, int stride, int B, SpBuffers& b, bool join, bool& forked, bool img_f32 = false,
-                    long long frame_step = 0 /*pixels from frame b to b + 1; 0 = stride * H*/) {
+                    long long frame_step = 0 /*pixels from frame b to b + 1; 0 = stride * H*/, float thr = 0.0005f /*candidate threshold of the fused tail*/,
+                    bool want_maps = false /*test hook: the fused tail also writes the score map and the NMS'ed map*/) {
     forked = false;
     int rc = ensure_ws(c, &c->ws_sp, &c->ws_sp_bytes, sp_ws_bytes(B, H, W));
     if (rc) return rc;
@@ -771,8 +773,18 @@ int sp_forward_maps(rfe_ctx* c, const void* img, int H, int W, int stride, int B
     { ProfScope p(c, "convPa"); launch_conv3x3(s, b.f4, B, Hc, Wc, 128, w.packed[L_PA], w.bias[L_PA], 256, true, false, b.pa, L_PA); }
     { ProfScope p(c, "convPb"); launch_gemm_nt(s, gemm_plain(b.pa, 256, w.packed[L_PB], 256, w.bias[L_PB], b.logits, 65, cells, 65, 256)); }
     { ProfScope p(c, "sp_post");
-      launch_softmax65_d2s(s, b.logits, 65, B, Hc, Wc, b.smap);
-      launch_nms(s, b.smap, B, 8 * Hc, 8 * Wc, c->hp.sp_nms_radius, c->hp.sp_remove_borders, b.ss, b.mask, b.supp, b.nmap); }
+      // one to four frames, published radius: softmax + NMS + candidate compaction in ONE launch (sp_post.hip: sp_tail_lat_kernel); otherwise the separate launches
+      if (B <= 4 && c->hp.sp_nms_radius == 4) {
+          if (!c->sp_cnt) { RFE_HIP(c, hipMalloc((void**)&c->sp_cnt, 8 * sizeof(int32_t))); c->sp_cnt_dirty = true; }
+          if (c->sp_cnt_dirty) { RFE_HIP(c, hipMemsetAsync(c->sp_cnt, 0, 8 * sizeof(int32_t), s)); c->sp_cnt_dirty = false; }
+          b.tail_fused = launch_sp_tail_lat(s, b.logits, B, Hc, Wc, c->hp.sp_nms_radius, c->hp.sp_remove_borders, thr, (unsigned long long*)b.cand_score, c->sp_cnt,
+                                            want_maps ? b.smap : nullptr, want_maps ? b.nmap : nullptr);
+          if (b.tail_fused) c->sp_cnt_dirty = true;      // until the ranking kernel (which zeroes the counters) is enqueued behind it
+      }
+      if (!b.tail_fused) {
+          launch_softmax65_d2s(s, b.logits, 65, B, Hc, Wc, b.smap);
+          launch_nms(s, b.smap, B, 8 * Hc, 8 * Wc, c->hp.sp_nms_radius, c->hp.sp_remove_borders, b.ss, b.mask, b.supp, b.nmap);
+      } }
     if (fork && join) RFE_HIP(c, hipStreamWaitEvent(s, c->ev_join, 0));
     forked = fork && !join;
     RFE_HIP(c, hipGetLastError());
@@ -783,10 +795,14 @@ int sp_forward(rfe_ctx* c, const void* img, int H, int W, int stride, int B, int
                int32_t* n, int32_t* kxy, float* score, float* desc, uint8_t* desc_bin = nullptr, bool img_f32 = false, long long frame_step = 0) {
     SpBuffers b;
     bool forked;
-    int rc = sp_forward_maps(c, img, H, W, stride, B, b, false, forked, img_f32, frame_step);
+    int rc = sp_forward_maps(c, img, H, W, stride, B, b, false, forked, img_f32, frame_step, thr);
     if (rc) return rc;
     const int Hc = H / 2 / 2 / 2, Wc = W / 2 / 2 / 2, Hs = 8 * Hc, Ws = 8 * Wc;   // score-map frame, see sp_forward_maps
     { ProfScope p(c, "sp_select");
+      if (b.tail_fused) {
+          launch_select_keys(c->stream, (const unsigned long long*)b.cand_score, c->sp_cnt, B, Hs, Ws, Kmax, c->hp.sp_topk_always != 0, n, kxy, score);
+          c->sp_cnt_dirty = false;
+      } else
       launch_select(c->stream, b.nmap, B, Hs, Ws, Kmax, thr, b.cand_score, b.cand_idx, n, kxy, score, (int32_t*)b.ss /*NMS scratch, free by now*/, c->hp.sp_topk_always != 0, b.sel_keys, b.sel_n);
       if (forked) RFE_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));   // descriptor map ready
       launch_desc_sample(c->stream, b.dmap, B, Hc, Wc, Hs, Ws, n, kxy, Kmax, desc, desc_bin); }
@@ -1676,7 +1692,7 @@ extern "C" int rfe_k_scoremap(rfe_ctx* c, const uint8_t* img, int H, int W, int 
     RFE_HIP(c, hipSetDevice(c->device));
     SpBuffers b;
     bool forked;
-    if ((rc = sp_forward_maps(c, img, H, W, stride, B, b, true, forked))) return rc;
+    if ((rc = sp_forward_maps(c, img, H, W, stride, B, b, true, forked, false, 0, 0.0005f, true))) return rc;   // sp_cnt stays dirty: zeroed before the next forward
     const size_t hw = (size_t)B * (H / 8 * 8) * (W / 8 * 8);   // maps are on the score-map frame: [B, 8*(H/8), 8*(W/8)]
     if (scoremap) RFE_HIP(c, hipMemcpyAsync(scoremap, b.smap, hw * 4, hipMemcpyDeviceToDevice, c->stream));
     if (nms) RFE_HIP(c, hipMemcpyAsync(nms, b.nmap, hw * 4, hipMemcpyDeviceToDevice, c->stream));
@@ -1700,6 +1716,30 @@ extern "C" int rfe_k_select(rfe_ctx* c, const float* nms, int B, int H, int W, i
     launch_select(c->stream, nms, B, H, W, Kmax, thr, b.cand_score, b.cand_idx, n, kxy, score, (int32_t*)b.ss, topk_always != 0, b.sel_keys, b.sel_n);
     RFE_HIP(c, hipGetLastError());
     RFE_HIP(c, hipStreamSynchronize(c->stream));
+    return RFE_OK;
+}
+
+// the same selection through the latency regime's key form (B <= 4): the map's candidates are appended as 64-bit keys in a scrambled order by a helper
+// kernel (one atomic per candidate -- the order sp_tail_lat_kernel's workgroups leave is just as arbitrary), then select_rankall_keys_kernel ranks them
+extern "C" int rfe_k_select_keys(rfe_ctx* c, const float* nms, int B, int H, int W, int Kmax, float thr, int topk_always, int32_t* n, int32_t* kxy,
+                                 float* score) {
+    int rc = sp_check(c, H, W, B, Kmax);
+    if (rc) return rc;
+    if (!nms || !n || !kxy || !score || B > 4) return fail(c, RFE_ERR_INVALID, "k_select_keys: null pointer or more than four frames");
+    RFE_HIP(c, hipSetDevice(c->device));
+    if ((rc = ensure_ws(c, &c->ws_sp, &c->ws_sp_bytes, sp_ws_bytes(B, H, W)))) return rc;
+    SpBuffers b;
+    sp_carve(c->ws_sp, B, H, W, b);
+    if (!c->sp_cnt) RFE_HIP(c, hipMalloc((void**)&c->sp_cnt, 8 * sizeof(int32_t)));
+    RFE_HIP(c, hipMemsetAsync(c->sp_cnt, 0, 8 * sizeof(int32_t), c->stream));
+    launch_keys_from_map(c->stream, nms, B, H * W, thr, (unsigned long long*)b.cand_score, c->sp_cnt);
+    launch_select_keys(c->stream, (const unsigned long long*)b.cand_score, c->sp_cnt, B, H, W, Kmax, topk_always != 0, n, kxy, score);
+    c->sp_cnt_dirty = false;
+    RFE_HIP(c, hipGetLastError());
+    RFE_HIP(c, hipStreamSynchronize(c->stream));
+    int32_t left[8];
+    RFE_HIP(c, hipMemcpy(left, c->sp_cnt, sizeof(left), hipMemcpyDeviceToHost));
+    for (int q = 0; q < 8; ++q) if (left[q] != 0) return fail(c, RFE_ERR_HIP, "k_select_keys: the ranking kernel did not leave the candidate counters at zero");
     return RFE_OK;
 }
 

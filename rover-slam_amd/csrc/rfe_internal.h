@@ -138,6 +138,8 @@ struct rfe_ctx {
     void* ws_io = nullptr; size_t ws_io_bytes = 0;   // staging for host-pointer entry points
     void* h_pin = nullptr; size_t h_pin_bytes = 0;   // pinned host mirror of ws_io for the per-frame host entries (extract / match): one DMA each way
     void* ws_tmp = nullptr; size_t ws_tmp_bytes = 0; // test hooks
+    int32_t* sp_cnt = nullptr;           // [4][2] (count, tickets) of the fused detector tail (sp_post.hip: sp_tail_lat_kernel); zero between calls
+    bool sp_cnt_dirty = false;           // the tail ran and its ranking kernel was not enqueued behind it (an error in between): zeroed before the next use
     void* ws_st = nullptr; size_t ws_st_bytes = 0;   // stereo stream state: staged views, previous left view's features
     int st_H = 0, st_W = 0, st_K = 0; bool st_have_prev = false; int st_flip = 0;   // st_flip: which of the two state slots holds the previous left view
     // one-shot test tap (rfe_k_set_lightglue_tap): the next LightGlue forward of this ctx, whatever entry point runs it,
@@ -229,6 +231,13 @@ void launch_select(hipStream_t s, const float* nms, int B, int H, int W, int Kma
                    float* cand_score, int32_t* cand_idx, int32_t* n_out, int32_t* kxy, float* score,
                    int32_t* chunk_cnt /*B * ceil(H*W/4096) ints of scratch*/, bool topk_always /*rfe_hparams::sp_topk_always*/,
                    unsigned long long* sel_keys /*[B,Kmax] scratch*/, int32_t* sel_n /*[B] scratch*/);
+// the detector tail of one to four frames in one launch (softmax65 + depth-to-space + simple_nms(4) + border + threshold -> unordered 64-bit candidate keys)
+// and the ranking that consumes it; cand_cnt = two ints per frame, zero between calls (the ranking kernel resets them).  false = not served.
+bool launch_sp_tail_lat(hipStream_t s, const float* logits, int B, int Hc, int Wc, int radius, int border, float thr, unsigned long long* cand_keys /*[B, 64 Hc Wc]*/,
+                        int32_t* cand_cnt /*[B, 2]*/, float* smap_out /*optional [B, 8 Hc, 8 Wc]*/, float* nmap_out /*optional*/);
+void launch_select_keys(hipStream_t s, const unsigned long long* cand_keys, int32_t* cand_cnt, int B, int H, int W, int Kmax, bool topk_always,
+                        int32_t* n_out, int32_t* kxy, float* score);
+void launch_keys_from_map(hipStream_t s, const float* nms, int B, int HW, float thr, unsigned long long* cand_keys, int32_t* cand_cnt);   // test hook
 void launch_descmap_norm(hipStream_t s, float* dmap, int64_t cells);
 void launch_desc_sample(hipStream_t s, const float* dmap, int B, int Hc, int Wc, int H, int W,
                         const int32_t* n, const int32_t* kxy, int Kmax, float* desc, uint8_t* desc_bin /*optional u8 [B,Kmax,256] = desc > 0*/);

@@ -182,10 +182,10 @@ __device__ __forceinline__ void max9x4(const float (&v)[12], float (&o)[4]) {
     o[2] = fmaxf(fmaxf(l2, mid), r10); o[3] = fmaxf(fmaxf(l3, mid), r11);
 }
 // row pass: src valid on the frame of margin M -> T[y][x] = max(src[y][x - 4 .. x + 4]) for rows of that frame, columns of margin M + 4
-template <int M, int NF_IH>
+template <int M, int NF_IH, int NT = 256>
 __device__ __forceinline__ void nf_rowpass(const float* __restrict__ src, float* __restrict__ T, int tid) {
     constexpr int ROWS = NF_IH - 2 * M, QUADS = (NF_IW - 2 * (M + NF_R)) / 4;
-    for (int idx = tid; idx < ROWS * QUADS; idx += 256) {
+    for (int idx = tid; idx < ROWS * QUADS; idx += NT) {
         const int py = M + idx / QUADS, px = M + NF_R + 4 * (idx % QUADS);
         const f32x4* p = reinterpret_cast<const f32x4*>(src + py * NF_IW + px);
         const f32x4 a = p[-1], b = p[0], c = p[1];
@@ -197,10 +197,10 @@ __device__ __forceinline__ void nf_rowpass(const float* __restrict__ src, float*
 }
 // column pass over T on the frame of margin M (a multiple of 4): calls f(py, px, pooled value) for every pixel of that frame; an item is
 // four consecutive rows of one column, lanes run along x (conflict-free reads)
-template <int M, int NF_IH, typename F>
+template <int M, int NF_IH, int NT = 256, typename F>
 __device__ __forceinline__ void nf_colpass(const float* __restrict__ T, int tid, F f) {
     constexpr int COLS = NF_IW - 2 * M, QROWS = (NF_IH - 2 * M) / 4;
-    for (int idx = tid; idx < QROWS * COLS; idx += 256) {
+    for (int idx = tid; idx < QROWS * COLS; idx += NT) {
         const int py = M + 4 * (idx / COLS), px = M + idx % COLS;
         const float* p = T + (py - NF_R) * NF_IW + px;
         float v[12];
@@ -642,6 +642,288 @@ void launch_select(hipStream_t s, const float* nms, int B, int H, int W, int Kma
     hipLaunchKernelGGL(select_kernel, dim3(B), dim3(SEL_T), (size_t)P2 * 8, s, nms, H, W, Kmax, P2, thr,
                        cand_score, cand_idx, n_out, kxy, score, chunk_cnt, nch, topk_always ? 1 : 0, sel_keys, sel_n);
     hipLaunchKernelGGL(select_rank_kernel, dim3((Kmax + 63) / 64, B), dim3(256), (size_t)Kmax * 8, s, sel_keys, sel_n, W, Kmax, kxy, score);
+}
+
+
+// ---------------------------------------------------------------- the detector tail of the latency regime in ONE launch
+// One to four frames per call -- the reference's own call pattern (batch 1, src/Extractors/superpoint_onnx.cc:100).  What used to be five launches
+// between convPb and the ranking (softmax65_d2s 10 us, nms_fused 27.6, select_count 4.7, select_compact 5.1 at one VGA frame: 47 us in which no
+// matrix instruction runs, profiles/r05_latency_kernel_stats.md) is one kernel of 1024-thread workgroups:
+//   head: the 65-way softmax of the cells under the haloed tile straight from convPb's logits -- the logits of the tile's cell rows are copied into LDS
+//         (coalesced, 260 B per cell), one thread per cell takes the maximum and, after the all-thread exponentials, the sum IN INDEX ORDER (the oracle's
+//         order: rfo softmax), every pixel is e / sum with the same division -- bit-identical to softmax65_d2s_kernel, and the score map never visits HBM;
+//   body: nms_fused_kernel's five max-pool rounds, 1024 threads instead of 256 on the same LDS planes (each pass is a handful of items per thread);
+//   tail: threshold + border on the output tile, block scan, ONE atomicAdd per workgroup on the frame's candidate counter, candidates appended as
+//         64-bit keys (score bits << 32 | ~pixel index) in ARBITRARY order -- select_rankall_keys_kernel places every candidate by its rank, so the order
+//         of the list never reaches a result (the row-major case ranks by pixel index).
+// cand_cnt: two ints per frame (count, tickets), zero between calls: the ranking kernel's last workgroup resets them (see there).
+constexpr int ST_NT = 1024;
+template <int TH_>
+__global__ __launch_bounds__(ST_NT, 1) void sp_tail_lat_kernel(const float* __restrict__ logits, int Hc, int Wc, int border, float thr,
+                                                               unsigned long long* __restrict__ cand_keys, int32_t* __restrict__ cand_cnt,
+                                                               float* __restrict__ smap_out, float* __restrict__ nmap_out) {
+    constexpr int NF_IH = TH_ + 2 * NF_HALO;
+    constexpr int NCY = (NF_IH + 7) / 8 + 1, NCX = (NF_IW + 7) / 8 + 1;     // cell rows / columns a haloed tile can touch
+    static_assert(NF_IH % 4 == 0, "quad items");
+    static_assert(NCY * NCX * 65 <= 3 * NF_IH * NF_IW, "the exponentials live in the T | Mk | SS planes");
+    static_assert(ST_NT == SEL_T, "block scan");
+    extern __shared__ __attribute__((aligned(16))) float nf_lds[];
+    float* const S = nf_lds;                       // scores
+    float* const T = S + NF_IH * NF_IW;            // row-pass scratch
+    float* const Mk = T + NF_IH * NF_IW;           // max_mask as 1 / 0 (-inf outside the image); at the end: the NMS'ed scores of the output tile
+    float* const SS = Mk + NF_IH * NF_IW;          // supp_scores
+    uint8_t* const SUP = reinterpret_cast<uint8_t*>(SS + NF_IH * NF_IW);   // supp_mask
+    float* const E = T;                            // head: logits, then exponentials, of the tile's cells [cell][65]
+    __shared__ float cmax[NCY * NCX], csum[NCY * NCX];
+    __shared__ int wtot[ST_NT / 64];
+    __shared__ int sbase;
+    const int H = 8 * Hc, W = 8 * Wc, HW = H * W;
+    const int b = blockIdx.z;
+    const size_t fo = (size_t)b * HW;
+    const int y0 = blockIdx.y * TH_ - NF_HALO, x0 = blockIdx.x * NTW - NF_HALO;
+    const int tid = threadIdx.x;
+    // ---- head
+    const int cy_lo = y0 > 0 ? y0 >> 3 : 0, cx_lo = x0 > 0 ? x0 >> 3 : 0;
+    int cy_hi = (y0 + NF_IH - 1) >> 3; cy_hi = cy_hi < Hc - 1 ? cy_hi : Hc - 1;
+    int cx_hi = (x0 + NF_IW - 1) >> 3; cx_hi = cx_hi < Wc - 1 ? cx_hi : Wc - 1;
+    const int ncy = cy_hi - cy_lo + 1, ncx = cx_hi - cx_lo + 1, ncell = ncy * ncx, rowlen = ncx * 65;
+    {
+        const float* lb = logits + ((size_t)b * Hc * Wc) * 65;
+        for (int r = 0; r < ncy; ++r) {
+            const float* src = lb + ((size_t)(cy_lo + r) * Wc + cx_lo) * 65;
+            for (int j = tid; j < rowlen; j += ST_NT) E[r * rowlen + j] = src[j];
+        }
+    }
+    __syncthreads();
+    for (int cell = tid; cell < ncell; cell += ST_NT) {
+        const float* e = E + cell * 65;
+        float m = e[0];
+#pragma unroll
+        for (int c = 0; c < 65; ++c) m = fmaxf(m, e[c]);
+        cmax[cell] = m;
+    }
+    __syncthreads();
+    for (int i = tid; i < ncell * 65; i += ST_NT) E[i] = rfe_expf(E[i] - cmax[i / 65]);
+    __syncthreads();
+    for (int cell = tid; cell < ncell; cell += ST_NT) {
+        const float* e = E + cell * 65;
+        float sm = 0.f;
+#pragma unroll
+        for (int c = 0; c < 65; ++c) sm = sm + e[c];
+        csum[cell] = sm;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < NF_IH * NF_IW; idx += ST_NT) {
+        const int py = idx / NF_IW, px = idx % NF_IW, gy = y0 + py, gx = x0 + px;
+        float v = -INFINITY;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            const int cell = ((gy >> 3) - cy_lo) * ncx + ((gx >> 3) - cx_lo);
+            v = E[cell * 65 + (gy & 7) * 8 + (gx & 7)] / csum[cell];
+            if (smap_out && py >= NF_HALO && py < NF_HALO + TH_ && px >= NF_HALO && px < NF_HALO + NTW) smap_out[fo + (size_t)gy * W + gx] = v;
+        }
+        S[idx] = v;
+    }
+    __syncthreads();     // (also: everybody is done with E before the first row pass overwrites T)
+    // ---- body: nms_fused_kernel's recurrence
+    auto inside = [&](int py, int px) { const int gy = y0 + py, gx = x0 + px; return gy >= 0 && gy < H && gx >= 0 && gx < W; };
+    nf_rowpass<0, NF_IH, ST_NT>(S, T, tid);
+    __syncthreads();
+    nf_colpass<NF_R, NF_IH, ST_NT>(T, tid, [&](int py, int px, float m) {
+        const int o = py * NF_IW + px;
+        Mk[o] = inside(py, px) ? (S[o] == m ? 1.f : 0.f) : -INFINITY;
+    });
+    __syncthreads();
+    nf_rowpass<NF_R, NF_IH, ST_NT>(Mk, T, tid);
+    __syncthreads();
+    nf_colpass<2 * NF_R, NF_IH, ST_NT>(T, tid, [&](int py, int px, float m) {
+        const int o = py * NF_IW + px;
+        const bool sp = m > 0.f;
+        SUP[o] = sp ? 1 : 0;
+        SS[o] = inside(py, px) ? (sp ? 0.f : S[o]) : -INFINITY;
+    });
+    __syncthreads();
+    nf_rowpass<2 * NF_R, NF_IH, ST_NT>(SS, T, tid);
+    __syncthreads();
+    nf_colpass<3 * NF_R, NF_IH, ST_NT>(T, tid, [&](int py, int px, float m) {
+        const int o = py * NF_IW + px;
+        if (inside(py, px)) Mk[o] = (Mk[o] != 0.f || (SS[o] == m && !SUP[o])) ? 1.f : 0.f;
+    });
+    __syncthreads();
+    nf_rowpass<3 * NF_R, NF_IH, ST_NT>(Mk, T, tid);
+    __syncthreads();
+    nf_colpass<4 * NF_R, NF_IH, ST_NT>(T, tid, [&](int py, int px, float m) {
+        const int o = py * NF_IW + px;
+        const bool sp = m > 0.f;
+        SUP[o] = sp ? 1 : 0;
+        SS[o] = inside(py, px) ? (sp ? 0.f : S[o]) : -INFINITY;
+    });
+    __syncthreads();
+    nf_rowpass<4 * NF_R, NF_IH, ST_NT>(SS, T, tid);
+    __syncthreads();
+    nf_colpass<5 * NF_R, NF_IH, ST_NT>(T, tid, [&](int py, int px, float m) {
+        const int o = py * NF_IW + px;
+        if (!inside(py, px)) return;                 // Mk stays -inf there: never a candidate
+        const bool mk = Mk[o] != 0.f || (SS[o] == m && !SUP[o]);
+        const int gy = y0 + py, gx = x0 + px;
+        float v = mk ? S[o] : 0.f;
+        if (gy < border || gy >= H - border || gx < border || gx >= W - border) v = -1.f;
+        Mk[o] = v;                                    // this thread owns o in this pass
+        if (nmap_out) nmap_out[fo + (size_t)gy * W + gx] = v;
+    });
+    __syncthreads();
+    // ---- tail: the candidates of the TH_ x 64 output tile
+    constexpr int PPT = (TH_ * NTW + ST_NT - 1) / ST_NT;
+    float cv[PPT]; int ci[PPT];
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int p = tid + k * ST_NT;
+        cv[k] = -INFINITY; ci[k] = 0;
+        if (p < TH_ * NTW) {
+            const int py = NF_HALO + p / NTW, px = NF_HALO + p % NTW;
+            const float v = Mk[py * NF_IW + px];
+            cv[k] = v; ci[k] = (y0 + py) * W + (x0 + px);
+        }
+        cnt += cv[k] > thr ? 1 : 0;
+    }
+    int total;
+    int pos = block_excl_scan_int(cnt, wtot, total);
+    if (tid == 0) sbase = total > 0 ? atomicAdd(cand_cnt + 2 * b, total) : 0;
+    __syncthreads();
+    pos += sbase;
+    unsigned long long* ck = cand_keys + fo;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k)
+        if (cv[k] > thr) { ck[pos] = ((unsigned long long)__float_as_uint(cv[k]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)ci[k]); ++pos; }
+}
+
+// Ranking of the unordered key list sp_tail_lat_kernel leaves: select_rankall_kernel's rank computation (see there) with
+//   * the keys read as they are (one 16-byte load per two candidates, every load of a thread in flight at once: the two 4-byte gathers per key behind a
+//     seven-iteration loop were 14 of that kernel's 19.6 us);
+//   * the row-major case (count <= Kmax, no unconditional top-k) ranked too -- by ascending pixel index (key halves swapped), since the list has no order;
+//   * the frame's (count, tickets) pair reset by the LAST workgroup of the frame to leave: every workgroup reads the count first and takes a ticket when it
+//     is done, so whoever draws the last ticket knows nobody will read the count again, and the next call finds zeros without a memset on the stream.
+__global__ __launch_bounds__(256) void select_rankall_keys_kernel(const unsigned long long* __restrict__ cand_keys, int32_t* __restrict__ cand_cnt,
+                                                                  int HW, int W, int Kmax, int topk_always, int32_t* __restrict__ n_out,
+                                                                  int32_t* __restrict__ kxy, float* __restrict__ score) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int count = cand_cnt[2 * b];
+    const unsigned long long* ck = cand_keys + (size_t)b * HW;
+    int32_t* okxy = kxy + (size_t)b * Kmax * 2;
+    float* osc = score + (size_t)b * Kmax;
+    const int nsel = count < Kmax ? count : Kmax;
+    if (blockIdx.x == 0 && tid == 0) n_out[b] = nsel;
+    const int span = count > Kmax ? count : Kmax;
+    const int nwin = (count + RA_MAX - 1) / RA_MAX;
+    const bool rowmajor = count <= Kmax && !topk_always;      // nothing to cut: row-major order = rank by ascending pixel index
+    auto xf = [&](unsigned long long k) { return rowmajor ? (k << 32) | (k >> 32) : k; };
+    auto load_window = [&](int w0, int wn) {                   // w0 is a multiple of RA_MAX: 16-byte aligned
+        const u64x2* src = reinterpret_cast<const u64x2*>(ck + w0);
+        u64x2* dst = reinterpret_cast<u64x2*>(keys);
+        const int npair = wn >> 1;
+        for (int j0 = tid; j0 < npair; j0 += 8 * 256) {
+            u64x2 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int j = j0 + u * 256; t[u] = j < npair ? src[j] : u64x2{0ull, 0ull}; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int j = j0 + u * 256; if (j < npair) dst[j] = u64x2{xf(t[u][0]), xf(t[u][1])}; }
+        }
+        if ((wn & 1) && tid == 0) keys[wn - 1] = xf(ck[w0 + wn - 1]);
+    };
+    bool loaded = false;
+    for (int t0 = blockIdx.x * RA_PER; t0 < span; t0 += gridDim.x * RA_PER) {
+        const int t = t0 + (tid >> 3), part = tid & 7;      // eight threads per candidate, each scans an eighth of the key pairs
+        if (part == 0 && t >= nsel && t < Kmax) { okxy[2 * t] = 0; okxy[2 * t + 1] = 0; osc[t] = 0.f; }   // rows [nsel, Kmax) of the padded outputs
+        if (t0 >= count) continue;
+        const bool live = t < count;
+        const unsigned long long key = live ? xf(ck[t]) : ~0ull;
+        const u64x2* kp = reinterpret_cast<const u64x2*>(keys);
+        int rank = 0;
+        for (int w = 0; w < nwin; ++w) {
+            const int w0 = w * RA_MAX, wn = count - w0 < RA_MAX ? count - w0 : RA_MAX;
+            if (nwin > 1 || !loaded) {
+                if (loaded) __syncthreads();                 // everybody has left the previous window
+                load_window(w0, wn);
+                loaded = true;
+                __syncthreads();
+            }
+            const int npair = wn >> 1;
+#pragma unroll 8
+            for (int j = part; j < npair; j += 8) { const u64x2 kk = kp[j]; rank += (kk[0] > key ? 1 : 0) + (kk[1] > key ? 1 : 0); }
+            if ((wn & 1) && part == 0) rank += keys[wn - 1] > key ? 1 : 0;
+        }
+        rank += __shfl_xor(rank, 1);
+        rank += __shfl_xor(rank, 2);
+        rank += __shfl_xor(rank, 4);
+        if (live && part == 0 && rank < Kmax) {
+            const unsigned long long k0 = rowmajor ? (key << 32) | (key >> 32) : key;      // back to (score bits, ~index)
+            const int idx = (int)(0xFFFFFFFFu - (unsigned int)(k0 & 0xFFFFFFFFull));
+            okxy[2 * rank] = idx % W; okxy[2 * rank + 1] = idx / W;
+            osc[rank] = __uint_as_float((unsigned int)(k0 >> 32));
+        }
+    }
+    // ---- ticket: the last workgroup of the frame to get here zeroes (count, tickets) for the next call
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        const int tk = atomicAdd(cand_cnt + 2 * b + 1, 1);
+        if (tk == (int)gridDim.x - 1) { cand_cnt[2 * b] = 0; cand_cnt[2 * b + 1] = 0; __threadfence(); }
+    }
+}
+
+// false = not served (more than four frames, another NMS radius): the caller runs the separate launches
+bool launch_sp_tail_lat(hipStream_t st, const float* logits, int B, int Hc, int Wc, int radius, int border, float thr, unsigned long long* cand_keys,
+                        int32_t* cand_cnt, float* smap_out, float* nmap_out) {
+    static const int frames = tune_int("RFE_SP_TAIL_FUSED", 4);   // tuning build: 0 = the separate launches at every batch size
+    if (radius != NF_R || B > frames || B < 1) return false;
+    const int H = 8 * Hc, W = 8 * Wc;
+    const int gx = (W + NTW - 1) / NTW;
+    auto wgs = [&](int th) { return (long long)gx * ((H + th - 1) / th) * B; };
+    static const int th_env = tune_int("RFE_NMS_TH", 0);
+    const int th = th_env ? th_env : (wgs(32) <= 256 ? 32 : wgs(40) <= 256 ? 40 : wgs(48) <= 256 ? 48 : 32);
+#define RFE_SP_TAIL_GO(TH_)                                                                                                                  \
+    do {                                                                                                                                     \
+        constexpr int bytes = (TH_ + 2 * NF_HALO) * NF_IW * 17;                                                                               \
+        static bool ls_[64];                                                                                                                 \
+        ensure_dynamic_lds((const void*)sp_tail_lat_kernel<TH_>, bytes, ls_);                                                                \
+        hipLaunchKernelGGL(sp_tail_lat_kernel<TH_>, dim3(gx, (H + TH_ - 1) / TH_, B), dim3(ST_NT), bytes, st, logits, Hc, Wc, border, thr,   \
+                           cand_keys, cand_cnt, smap_out, nmap_out);                                                                         \
+    } while (0)
+    if (th == 48) RFE_SP_TAIL_GO(48);
+    else if (th == 40) RFE_SP_TAIL_GO(40);
+    else RFE_SP_TAIL_GO(32);
+#undef RFE_SP_TAIL_GO
+    return true;
+}
+
+// test hook (rfe_k_select_keys): the candidates of a caller's post-NMS map as an unordered key list -- pixels visited in a scrambled order, one atomic each
+__global__ __launch_bounds__(256) void keys_from_map_kernel(const float* __restrict__ nms, int HW, float thr, unsigned long long* __restrict__ cand_keys,
+                                                            int32_t* __restrict__ cand_cnt) {
+    const int b = blockIdx.y;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= HW) return;
+    const int p = (int)((t * 7919 + 13) % HW);            // 7919 is prime: a permutation of [0, HW) whenever 7919 does not divide HW
+    const float v = nms[(size_t)b * HW + p];
+    if (v > thr) {
+        const int pos = atomicAdd(cand_cnt + 2 * b, 1);
+        cand_keys[(size_t)b * HW + pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)p);
+    }
+}
+void launch_keys_from_map(hipStream_t s, const float* nms, int B, int HW, float thr, unsigned long long* cand_keys, int32_t* cand_cnt) {
+    hipLaunchKernelGGL(keys_from_map_kernel, dim3((HW + 255) / 256, B), dim3(256), 0, s, nms, HW, thr, cand_keys, cand_cnt);
+}
+
+void launch_select_keys(hipStream_t s, const unsigned long long* cand_keys, int32_t* cand_cnt, int B, int H, int W, int Kmax, bool topk_always,
+                        int32_t* n_out, int32_t* kxy, float* score) {
+    const int HW = H * W;
+    const int cap = HW < RA_MAX ? HW : RA_MAX, span = cap > Kmax ? cap : Kmax;
+    static bool ls_[64];
+    ensure_dynamic_lds((const void*)select_rankall_keys_kernel, RA_MAX * 8, ls_);
+    hipLaunchKernelGGL(select_rankall_keys_kernel, dim3((span + RA_PER - 1) / RA_PER, B), dim3(256), (size_t)cap * 8, s, cand_keys, cand_cnt, HW, W, Kmax,
+                       topk_always ? 1 : 0, n_out, kxy, score);
 }
 
 // ---------------------------------------------------------------- 256-d L2 normalisation

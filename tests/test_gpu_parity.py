@@ -604,13 +604,15 @@ def _select_reference(m, kmax, thr, always):
     return n, kxy, score
 
 
-@pytest.mark.parametrize("B", [1, 2, 5])
+@pytest.mark.parametrize("B,form", [(1, "ordered"), (2, "ordered"), (5, "ordered"), (1, "keys"), (3, "keys"), (4, "keys")])
 @pytest.mark.parametrize("density,levels,kmax,always", [(0.5, 7, 1024, 0), (0.9, 3, 4096, 0), (0.02, 5, 1024, 0), (0.02, 5, 1024, 1), (0.6, 0, 333, 0)])
-def test_select_kernels_any_candidate_count(ctx, B, density, levels, kmax, always):
+def test_select_kernels_any_candidate_count(ctx, B, form, density, levels, kmax, always):
     """The selection stage alone on synthetic post-NMS maps (rfe_k_select): far more candidates than one LDS window of the rank-all form
     holds (B <= 4; > 16 384 per frame, which only tie-rich maps produce) and than the radix-select form's Kmax (B = 5), with only a few
     distinct score levels so that the cut falls INSIDE a run of equal scores and is decided by the pixel index; also counts below Kmax
-    (row-major order, or score order when the graph's TopK is unconditional)."""
+    (row-major order, or score order when the graph's TopK is unconditional).  form = "keys": the same maps through rfe_k_select_keys -- the unordered
+    64-bit key list of the forward's fused detector tail (one to four frames), ranked by select_rankall_keys_kernel, which must also leave the
+    candidate counters at zero for the next call (the hook checks that)."""
     from rover_slam_amd import capi
     H, W = 160, 232
     rng = np.random.default_rng(B * 1000 + kmax + int(density * 100) + always)
@@ -623,7 +625,8 @@ def test_select_kernels_any_candidate_count(ctx, B, density, levels, kmax, alway
         assert int((m[0] > 0.0005).sum()) > 16384
     dm = _dev(ctx, m)
     dn, dk, ds = ctx.alloc(B * 4), ctx.alloc(B * kmax * 8), ctx.alloc(B * kmax * 4)
-    ctx._chk(capi.lib.rfe_k_select(ctx.h, dm.ptr, B, H, W, kmax, 0.0005, always, dn.ptr, dk.ptr, ds.ptr))
+    fn = capi.lib.rfe_k_select if form == "ordered" else capi.lib.rfe_k_select_keys
+    ctx._chk(fn(ctx.h, dm.ptr, B, H, W, kmax, 0.0005, always, dn.ptr, dk.ptr, ds.ptr))
     n = dn.download((B,), np.int32); kxy = dk.download((B, kmax, 2), np.int32); score = ds.download((B, kmax), np.float32)
     for i in range(B):
         rn, rk, rs = _select_reference(m[i], kmax, 0.0005, always)

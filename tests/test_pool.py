@@ -291,3 +291,75 @@ def test_pool_gather_failure_falls_back_to_copy(wsets):
             assert not pool.has_rccl and _same_matches(got, ref)
         finally:
             pool.close()
+
+
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.gpu
+def test_pool_over_every_visible_device_through_rccl(wsets):
+    """RCCL between DISTINCT devices (ncclCommInitAll over all of them, grouped ncclSend / ncclRecv into member 0's root buffer over xGMI): runs by
+    itself the day the suite lands on a multi-GPU box -- on the 1-GPU pool of this build it is skipped, and says so.  Every device count from 2 up to
+    the visible one; shards that are ragged (11 frames over 2 .. 8 members) so that the per-member row counts and offsets differ."""
+    from rover_slam_amd import capi
+    n = _n_gpus()
+    if n < 2:
+        pytest.skip(f"{n} GPU visible: RCCL between distinct devices needs at least two (the world-size-1 RCCL path is test_pool_of_one_through_rccl_equals_single_ctx)")
+    frames, _ = synth.make_frames(11, 160, 208, seed=5)
+    kmax = 256
+    ctx = capi.Context(0)
+    ctx.set_weights(capi.KIND_SUPERPOINT, wsets[0]); ctx.set_weights(capi.KIND_LIGHTGLUE, wsets[1])
+    ref = _single_ctx_stream(ctx, frames, kmax)
+    ctx.close()
+    for m in sorted({2, n}):
+        pool = capi.Pool(list(range(m)))
+        try:
+            assert pool.size == m and pool.has_rccl
+            pool.set_weights(capi.KIND_SUPERPOINT, wsets[0]); pool.set_weights(capi.KIND_LIGHTGLUE, wsets[1])
+            first = pool.extract_match_stream(frames, kmax=kmax, transport=capi.POOL_RCCL)     # the communicators' first collective (connection set-up)
+            again = pool.extract_match_stream(frames, kmax=kmax, transport=capi.POOL_RCCL)
+            copy = pool.extract_match_stream(frames, kmax=kmax, transport=capi.POOL_COPY)
+        finally:
+            pool.close()
+        for got in (first, again, copy):
+            for k in ("n", "kxy", "score", "desc"):
+                assert np.array_equal(got[k], ref[k]), (m, k)
+            assert _same_matches(got, ref), m
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("members", [1, 2])
+def test_pool_failure_on_the_very_first_gather(wsets, members):
+    """the failing member aborts its OWN communicator at once, before it asks for the exclusive lock -- a peer whose ncclGroupEnd is
+    still inside first-use connection set-up with the failed member holds the shared lock until that abort releases it.  The failure is therefore
+    injected into the FIRST gather a fresh pool ever runs (no connection exists yet); the call must come back -- through COPY under AUTO -- and the
+    pool must keep working.  Two members need two GPUs (skipped otherwise)."""
+    from rover_slam_amd import capi
+    if _n_gpus() < members:
+        pytest.skip(f"{members} members on distinct devices need {members} GPUs")
+    frames, _ = synth.make_frames(5, 160, 208, seed=5)
+    kmax = 256
+    ctx = capi.Context(0)
+    ctx.set_weights(capi.KIND_SUPERPOINT, wsets[0]); ctx.set_weights(capi.KIND_LIGHTGLUE, wsets[1])
+    ref = _single_ctx_stream(ctx, frames, kmax)
+    ctx.close()
+    pool = capi.Pool(list(range(members)))
+    try:
+        assert pool.has_rccl
+        pool.set_weights(capi.KIND_SUPERPOINT, wsets[0]); pool.set_weights(capi.KIND_LIGHTGLUE, wsets[1])
+        assert capi.lib.rfe_k_pool_inject_gather_failure(pool.h, members - 1) == 0
+        if members == 1:
+            with pytest.raises(capi.RfeError, match="injected"):
+                pool.extract_match_stream(frames, kmax=kmax, transport=capi.POOL_RCCL)
+        else:
+            got = pool.extract_match_stream(frames, kmax=kmax)          # AUTO takes RCCL with two members: the failure is absorbed inside the call
+            assert _same_matches(got, ref)
+        assert not pool.has_rccl
+        after = pool.extract_match_stream(frames, kmax=kmax)
+    finally:
+        pool.close()
+    for k in ("n", "kxy", "score", "desc"):
+        assert np.array_equal(after[k], ref[k]), k
+    assert _same_matches(after, ref)
