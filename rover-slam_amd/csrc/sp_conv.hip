@@ -365,7 +365,11 @@ __device__ __attribute__((aligned(64))) float t16d_zero_line[16];   // zero-init
 
 // NC: output channels per workgroup, 32 (two accumulator chains per wave) or 16 (ONE chain per wave, twice the workgroups: round 5, for the launches whose
 // 32-channel grid leaves SIMDs idle or badly balanced -- a 60 x 80 layer of one frame is 300 workgroups for 256 CUs; the arithmetic and its order are the same).
-template <int CIN, bool RELU, int NC = T16_NC>
+// POOL (round 6): the fused 2 x 2 / 2 max-pool of conv2b / conv3b.  In the D layout a lane holds four output channels of ONE pixel (row = wave, column = lane & 15):
+// the horizontal neighbour is lane ^ 1 (one DPP move), the vertical one sits in wave ^ 1 -- the even-column lanes park their horizontal maxima in the (by then
+// idle) first ring stage, one barrier, and 2 x 8 x NC / 4 threads write the pooled 2 x 8 pixel block with 16-byte stores.  max and ReLU commute: ReLU first, as
+// the epilogue already does.
+template <int CIN, bool RELU, int NC = T16_NC, bool POOL = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_t16d_kernel(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ out, int H, int W, int COUT, int gx, int gy, int ntiles) {
@@ -464,6 +468,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_t16d_kernel(
     if (RELU) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) { acc[nb][0] = fmaxf(acc[nb][0], 0.f); acc[nb][1] = fmaxf(acc[nb][1], 0.f); acc[nb][2] = fmaxf(acc[nb][2], 0.f); acc[nb][3] = fmaxf(acc[nb][3], 0.f); }
+    }
+    if (POOL) {
+        // every wave has left the last stage's buffers before stage 0's are overwritten: the last stage is (NST - 1) % 3, stage 0's buffer is only reused when that is
+        // not 0 -- a barrier makes it safe either way
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        float* ex = lds;                                    // [4 rows][8 pooled columns][NC]
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            f32x4 hm;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hm[e] = fmaxf(acc[nb][e], __shfl_xor(acc[nb][e], 1));
+            if (!(px & 1)) *reinterpret_cast<f32x4*>(ex + (wave * 8 + (px >> 1)) * NC + nb * 16 + 4 * q) = hm;
+        }
+        __syncthreads();
+        constexpr int CG = NC / 4;                          // 16-byte channel groups per pixel
+        if (tid < 2 * 8 * CG) {
+            const int cg = tid % CG, ppx = (tid / CG) & 7, prow = tid / (8 * CG);
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ex + ((2 * prow) * 8 + ppx) * NC + cg * 4);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(ex + ((2 * prow + 1) * 8 + ppx) * NC + cg * 4);
+            const int Ho = H >> 1, Wo = W >> 1, yo = (y0 >> 1) + prow, xo = (x0 >> 1) + ppx;
+            if (yo < Ho && xo < Wo)
+                *reinterpret_cast<f32x4*>(out + (((size_t)b * Ho + yo) * Wo + xo) * COUT + co0 + cg * 4) =
+                    f32x4{fmaxf(a[0], c[0]), fmaxf(a[1], c[1]), fmaxf(a[2], c[2]), fmaxf(a[3], c[3])};
+        }
+        return;
     }
     const int y = y0 + wave, x = x0 + px;
     if (y < H && x < W) {
@@ -734,6 +765,28 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
             ensure_dynamic_lds((const void*)conv3x3_t16d_kernel<64, true>, bytes, ls_[1]);
             hipLaunchKernelGGL((conv3x3_t16d_kernel<64, true>), gs, dim3(256), bytes, s, in, wp, bias, out, H, W, cout, sx, sy, sx * sy * B);
         }
+        return;
+    }
+    // the pooling layers of one or two frames on the 16 x 16 x 4 tiles (round 6, conv3x3_t16d_kernel<.., POOL>): pixel budgets per Cin, 0 = off
+    static const int t16p_px64 = tune_int("RFE_CONV_T16P_64", 0), t16p_px128 = tune_int("RFE_CONV_T16P_128", 0), t16p_nc16 = tune_int("RFE_CONV_T16P_NC16", 0);
+    if (ck8 && relu && pool && (cin == 64 || cin == 128) && (long long)B * H * W <= (cin == 64 ? t16p_px64 : t16p_px128) && cout % T16_NC == 0 && H % 2 == 0 && W % 2 == 0) {
+        const int sx = (W + T16_W - 1) / T16_W, sy = (H + T16_H - 1) / T16_H;
+        static bool lp_[4][64];
+        if (t16p_nc16) {
+            constexpr int b16 = 3 * (T16D_PIX * T16_CK + T16D_WROWS * 16) * 4;
+            const dim3 g16(conv_grid(sx, sy, B, cout / 16));
+            if (cin == 128) { ensure_dynamic_lds((const void*)conv3x3_t16d_kernel<128, true, 16, true>, b16, lp_[0]);
+                              hipLaunchKernelGGL((conv3x3_t16d_kernel<128, true, 16, true>), g16, dim3(256), b16, s, in, wp, bias, out, H, W, cout, sx, sy, sx * sy * B); }
+            else { ensure_dynamic_lds((const void*)conv3x3_t16d_kernel<64, true, 16, true>, b16, lp_[1]);
+                   hipLaunchKernelGGL((conv3x3_t16d_kernel<64, true, 16, true>), g16, dim3(256), b16, s, in, wp, bias, out, H, W, cout, sx, sy, sx * sy * B); }
+            return;
+        }
+        constexpr int bytes = 3 * (T16D_PIX * T16_CK + T16D_WROWS * T16_NC) * 4;
+        const dim3 gs(conv_grid(sx, sy, B, cout / T16_NC));
+        if (cin == 128) { ensure_dynamic_lds((const void*)conv3x3_t16d_kernel<128, true, T16_NC, true>, bytes, lp_[2]);
+                          hipLaunchKernelGGL((conv3x3_t16d_kernel<128, true, T16_NC, true>), gs, dim3(256), bytes, s, in, wp, bias, out, H, W, cout, sx, sy, sx * sy * B); }
+        else { ensure_dynamic_lds((const void*)conv3x3_t16d_kernel<64, true, T16_NC, true>, bytes, lp_[3]);
+               hipLaunchKernelGGL((conv3x3_t16d_kernel<64, true, T16_NC, true>), gs, dim3(256), bytes, s, in, wp, bias, out, H, W, cout, sx, sy, sx * sy * B); }
         return;
     }
     if (ck8 && (!pool || relu) && (long long)gx * gy * B * (cout / NT) < small_thr && (cin == 64 || cin == 128)) {
