@@ -767,8 +767,12 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
         }
         return;
     }
-    // the pooling layers of one or two frames on the 16 x 16 x 4 tiles (round 6, conv3x3_t16d_kernel<.., POOL>): pixel budgets per Cin, 0 = off
-    static const int t16p_px64 = tune_int("RFE_CONV_T16P_64", 0), t16p_px128 = tune_int("RFE_CONV_T16P_128", 0), t16p_nc16 = tune_int("RFE_CONV_T16P_NC16", 0);
+    // the pooling layer with 128 input channels (conv3b) of ONE frame on the 16 x 16 x 4 tiles with 16 output channels per workgroup (round 6,
+    // conv3x3_t16d_kernel<128, true, 16, POOL>): 120 x 160 x 128 channels = 2400 workgroups of one accumulator chain per wave instead of 600 workgroups of
+    // 32 x 32 x 2 chains that leave 88 CUs with three and 168 with two.  Measured (tools/tune_sweep.py, c2, 200 steps, two alternating runs, profiles/r06_ab_notes.md):
+    // conv3b 73.4 -> 64.0 us (32 channels per workgroup: 69.3); two frames with 32 channels 110 -> 128 us, the 64-input-channel layer (conv2b, 240 x 320)
+    // 59.4 -> 68.3 us -- neither is taken.  Pixel budgets per Cin, 0 = off.
+    static const int t16p_px64 = tune_int("RFE_CONV_T16P_64", 0), t16p_px128 = tune_int("RFE_CONV_T16P_128", 20000), t16p_nc16 = tune_int("RFE_CONV_T16P_NC16", 1);
     if (ck8 && relu && pool && (cin == 64 || cin == 128) && (long long)B * H * W <= (cin == 64 ? t16p_px64 : t16p_px128) && cout % T16_NC == 0 && H % 2 == 0 && W % 2 == 0) {
         const int sx = (W + T16_W - 1) / T16_W, sy = (H + T16_H - 1) / T16_H;
         static bool lp_[4][64];

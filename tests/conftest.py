@@ -1,6 +1,13 @@
 import os
 import sys
 
+# The oracle (oracle/librfe_oracle.so) is OpenMP code: with libgomp's default ACTIVE wait policy its threads spin at every barrier, and on a host whose cores
+# are busy with something else (the round-6 "noisy host" run: a busy loop on every core) each barrier then waits for descheduled spinners -- the GPU suite
+# went from 3.4 to > 25 minutes.  Blocking waits keep the checker usable there; set before libgomp is first loaded.  (bench.py's cpu_baseline leg, which TIMES
+# the oracle, does not go through this file and keeps the default policy.)
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -57,7 +57,8 @@ def test_linear_bitexact(ctx, oracle, M, K, N):
 
 @pytest.mark.parametrize("H,W,Cin,Cout,relu,pool", [
     (16, 32, 16, 64, 1, 0), (24, 40, 64, 64, 1, 1), (60, 80, 128, 128, 1, 0), (20, 24, 64, 128, 0, 0),
-    (30, 46, 32, 64, 1, 1), (60, 80, 128, 256, 1, 0)])
+    (30, 46, 32, 64, 1, 1), (60, 80, 128, 256, 1, 0),
+    (28, 44, 128, 128, 1, 1), (30, 38, 128, 64, 1, 1), (120, 80, 128, 128, 1, 1), (27, 45, 128, 128, 1, 1)])     # the pooled 16 x 16 x 4 tiles (ragged edges; odd sizes fall back)
 def test_conv3x3_bitexact(ctx, oracle, H, W, Cin, Cout, relu, pool):
     from rover_slam_amd import capi
     rng = np.random.default_rng(H * W + Cin)
