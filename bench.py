@@ -95,7 +95,7 @@ def pmc_traffic(stage):
     bench command (profiles/rNN_pmc_traffic.json, made by tools/profile_round.sh + tools/rocpd_pmc.py):
     (2*FETCH_SIZE + WRITE_SIZE)*1024 as the MI355X guide prescribes.  None when no PMC pass covers it."""
     keys = STAGE_KERNEL.get(stage)
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
         if not keys or not os.path.exists(path):
             continue
