@@ -16,7 +16,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from tolerances import borderline, _top2_gap as top2_gap  # noqa: E402  (the one statement of the borderline rule)
 
 
-def main(seconds=60.0, seed=0):
+def main(seconds=60.0, seed=0, max_cases=None):
+    """max_cases: stop after that many cases whatever the clock says (the pytest short run: the SAME cases on every box, fast or busy)"""
     rng = np.random.default_rng(seed)
     O.build()
     c = capi.Context(0)
@@ -24,7 +25,7 @@ def main(seconds=60.0, seed=0):
     wsp2 = Wt.make_superpoint(seed=9, dustbin_bias=7.0)
     c.set_weights(capi.KIND_LIGHTGLUE, wlg)
     t0, it, fails = time.time(), 0, 0
-    while time.time() - t0 < seconds:
+    while time.time() - t0 < seconds and (max_cases is None or it < max_cases):
         it += 1
         kind = it % 5
         if kind == 0:                                             # ---- SuperPoint
