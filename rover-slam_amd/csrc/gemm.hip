@@ -75,7 +75,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     const int wm = wave >> 1, wn = wave & 1;
     const int i = lane & 31, h = lane >> 5;
     const int z = blockIdx.z;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    int bxt = blockIdx.x, byt = blockIdx.y;      // column tile, row panel
+    if (g.xcd) {   // launch order is x fastest: linear id L -> XCD L & 7; the nct column tiles of row panel ((slot / nct) * 8 + xcd) sit in consecutive slots of that XCD
+        const int L = blockIdx.y * gridDim.x + blockIdx.x, nct = gridDim.x;
+        const int slot = L >> 3;
+        byt = (slot / nct) * 8 + (L & 7);
+        bxt = slot % nct;
+    }
+    const int m0 = byt * BM, n0 = bxt * BN;
     int M = g.M;
     if (g.m_valid) { M = g.m_valid[z]; if (M > g.M) M = g.M; }
     if (m0 >= M) return;
@@ -432,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
             const int m = m0 + (wm * MB + (i >> 4)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (m < M) {
                 const int P = (int)gridDim.x * 2;
-                float* sp = g.stats_out + (((size_t)m + (size_t)z * g.M) * P + blockIdx.x * 2 + wn) * 2;
+                float* sp = g.stats_out + (((size_t)m + (size_t)z * g.M) * P + bxt * 2 + wn) * 2;
                 sp[0] = sm[0]; sp[1] = s2[0];
             }
         }
@@ -449,6 +456,7 @@ bool gemm_nt_rope_ok(const GemmArgs& g) {
 
 int launch_gemm_nt(hipStream_t s, const GemmArgs& g_in) {
     GemmArgs g = g_in;
+    g.xcd = 0;
 #ifdef RFE_TUNING
     g.abl = tune_int("RFE_DBG_GEMM_ABL", 0);
 #endif
@@ -502,7 +510,13 @@ int launch_gemm_nt(hipStream_t s, const GemmArgs& g_in) {
     const bool big = (g.N % 256 == 0 && tiles(128, 256) >= 256) || tiles(128, 128) >= 256 || g.M > 8192;
     if (!big || g.N % 256) g.stats_out = nullptr;   // partials cover whole column tiles only
     int ntiles;
-    if (g.N % 256 == 0 && tiles(128, 256) >= 256) { ntiles = g.N / 256; RFE_GEMM_GO(2, 4, dim3(g.N / 256, (g.M + 127) / 128, batch)); }
+    // XCD-aware tile decode (round 6; tuning build only, OFF in the product): only where it is a bijection and there is something to share -- several column tiles, a
+    // whole number of 8 row panels, one batch.  Measured (tools/tune_sweep.py, three alternating runs, profiles/r06_ab_notes.md): qkv 1.991 -> 1.963 ms per step,
+    // cross-qkv 1.333 -> 1.329, ffn.0 4.902 -> 4.918, and ffn.3 -- whose own decode does not change -- 3.113 -> 3.191: the step does not move (34.15 - 34.21 against
+    // 34.11 - 34.18 ms).  The panels are not HBM-bound (440 MB in 224 us), so saving the A re-reads buys nothing.
+    static const bool xcd_on = tune_int("RFE_GEMM_XCD", 0) != 0;
+    auto xcd_ok = [&](int bm, int bn) { const int nct = (g.N + bn - 1) / bn, gy = (g.M + bm - 1) / bm; return xcd_on && batch == 1 && nct > 1 && gy % 8 == 0 && !g.m_valid; };
+    if (g.N % 256 == 0 && tiles(128, 256) >= 256) { ntiles = g.N / 256; g.xcd = xcd_ok(128, 256) ? 1 : 0; RFE_GEMM_GO(2, 4, dim3(g.N / 256, (g.M + 127) / 128, batch)); }
     else if (tiles(128, 128) >= 256 || g.M > 8192) { ntiles = (g.N + 127) / 128; RFE_GEMM_GO(2, 2, dim3((g.N + 127) / 128, (g.M + 127) / 128, batch)); }
     else if (tiles(64, 128) >= 256) { ntiles = (g.N + 127) / 128; RFE_GEMM_GO(1, 2, dim3((g.N + 127) / 128, (g.M + 63) / 64, batch)); }
     else { ntiles = (g.N + 63) / 64; RFE_GEMM_GO(1, 1, dim3((g.N + 63) / 64, (g.M + 63) / 64, batch)); }

@@ -96,6 +96,10 @@ struct GemmArgs {
     // rope_csn != null: LightGlue's rotary encoding applied by the epilogue to output columns rope_c0 <= n < rope_c1 (the k columns of the qkv projection;
     // multiples of 256): (t0, t1) -> (t0 c - t1 s, t1 c + t0 s) on adjacent column pairs, (c, s) = rope_csn[row][(column & 63) / 2].  Plain projections only.
     const float* rope_csn; int rope_c0, rope_c1;
+    // xcd != 0 (set by launch_gemm_nt when the grid allows it): workgroups are dealt round-robin over the 8 XCDs in launch order, so the column tiles of ONE row
+    // panel -- which read the same A rows -- are decoded onto one XCD (one L2 fetch of the panel instead of gridDim.x of them); the tiles are the same, only which
+    // workgroup computes which tile changes
+    int xcd;
 #ifdef RFE_TUNING
     int abl;   // timing ablations (wrong results): 1 = global loads of the first K tile only, 2 = LDS stores / barriers of the first K tile only, 4 = no epilogue stores
 #endif
