@@ -39,8 +39,10 @@ def golden_dir():
 # files next, and the bench.py subprocess tests (the most environment-sensitive code of the repo: child processes, process groups,
 # wall clocks) LAST -- a hiccup there must never keep a parity test from running.  Files not named keep their alphabetical place in the middle.
 _ORDER_FIRST = ["test_gpu_parity", "test_gpu_calibrated", "test_gpu_throughput_parity", "test_stereo", "test_gpu_shim", "test_gpu_onnx_graph",
-                "test_onnx_cpp", "test_onnx_weights", "test_onnx_hparams", "test_onnx_exporter", "test_ort_parity", "test_pool"]
-_ORDER_LAST = ["test_gpu_bench"]
+                "test_onnx_cpp", "test_onnx_weights", "test_onnx_hparams", "test_onnx_exporter", "test_ort_parity"]
+# test_pool.py: oracle-checked too, but on a box with SEVERAL GPUs it runs RCCL between distinct devices -- code no box of this build has ever executed --
+# so it goes behind every single-GPU file and in front of the bench subprocess tests only
+_ORDER_LAST = ["test_pool", "test_gpu_bench"]
 
 
 def _rank(item):
