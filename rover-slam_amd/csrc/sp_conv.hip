@@ -231,24 +231,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
 // workgroups on 60 x 80) and each wave's serial MFMA chain is 4x shorter.  Reads the same packed weights (half of each
 // 64-wide row).  Same reduction order (bit-exact).  POOL: the 2x2 windows span two waves (rows w, w+1), so the ReLU'd tile is
 // exchanged through LDS (4 x 32 px x 32 channels, the staging buffers are free by then) and pooled from there.
-constexpr int STH = 4, SIH = STH + 2, SPLANE = SIH * TWS, SNT = 32;
+constexpr int STH = 4, SNT = 32;
 
-template <int CIN, bool RELU, int CK, bool POOL = false>
-__global__ __launch_bounds__(256, 4) void conv3x3_small_kernel(
+// ROWS (round 6): rows per tile = waves per workgroup, 4 or 5 (no pool).  240 x 320 x 64 channels of ONE frame are 1200 four-row workgroups for 1024 resident slots -- four
+// rounds' worth run together, 176 stragglers follow alone -- but 960 five-row workgroups, all resident at once (conv2a of one frame).
+template <int CIN, bool RELU, int CK, bool POOL = false, int ROWS = STH>
+__global__ __launch_bounds__(64 * ROWS, 4) void conv3x3_small_kernel(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ out, int H, int W, int COUT, int gx, int gy, int ntiles) {
     constexpr int KCH = CK * 9;
-    constexpr int LDS_WORDS = (CK * SPLANE + KCH * SNT) > (POOL ? STH * TW * SNT : 0) ? (CK * SPLANE + KCH * SNT) : STH * TW * SNT;
+    static_assert(ROWS == STH || !POOL, "the pooling exchange is written for four rows");
+    constexpr int NTH = 64 * ROWS, RIH = ROWS + 2, RPLANE = RIH * TWS;     // threads, haloed rows, words per input-channel plane
+    constexpr int LDS_WORDS = (CK * RPLANE + KCH * SNT) > (POOL ? STH * TW * SNT : 0) ? (CK * RPLANE + KCH * SNT) : STH * TW * SNT;
     __shared__ __attribute__((aligned(16))) float lds[LDS_WORDS];
     float* lds_in = lds;
-    float* lds_w = lds + CK * SPLANE;
+    float* lds_w = lds + CK * RPLANE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, h = lane >> 5;
     const ConvBlock blk = conv_decode(COUT / SNT, gx, gy, ntiles);
     if (!blk.valid) return;
     const int b = blk.b, ct = blk.ct;
-    const int x0 = blk.bx * TW, y0 = blk.by * STH;
+    const int x0 = blk.bx * TW, y0 = blk.by * ROWS;
     const int co0 = ct * SNT;
 
     f32x16 acc;
@@ -261,8 +265,8 @@ __global__ __launch_bounds__(256, 4) void conv3x3_small_kernel(
 #pragma unroll
     for (int s = 0; s < 9; ++s) {
         const int k0 = 2 * s, k1 = 2 * s + 1;
-        const int o0 = (k0 / 9) * SPLANE + ((k0 % 9) / 3) * TWS + (k0 % 9) % 3;
-        const int o1 = (k1 / 9) * SPLANE + ((k1 % 9) / 3) * TWS + (k1 % 9) % 3;
+        const int o0 = (k0 / 9) * RPLANE + ((k0 % 9) / 3) * TWS + (k0 % 9) % 3;
+        const int o1 = (k1 / 9) * RPLANE + ((k1 % 9) / 3) * TWS + (k1 % 9) % 3;
         aoff[s] = (h ? o1 : o0) + wave * TWS + col;
     }
     const int boff = h * SNT + col;
@@ -272,19 +276,19 @@ __global__ __launch_bounds__(256, 4) void conv3x3_small_kernel(
 
     for (int ch = 0; ch < CIN / CK; ++ch) {
         __syncthreads();
-        for (int idx = tid; idx < SIH * IW * (CK / 4); idx += 256) {
+        for (int idx = tid; idx < RIH * IW * (CK / 4); idx += NTH) {
             const int cq = idx % (CK / 4), pix = idx / (CK / 4);
             const int py = pix / IW, px = pix % IW;
             const int gy = y0 - 1 + py, gx = x0 - 1 + px;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gy >= 0 && gy < H && gx >= 0 && gx < W)
                 v = *reinterpret_cast<const float4*>(in_b + ((size_t)gy * W + gx) * CIN + ch * CK + cq * 4);
-            float* d = lds_in + (cq * 4) * SPLANE + py * TWS + px;
-            d[0] = v.x; d[SPLANE] = v.y; d[2 * SPLANE] = v.z; d[3 * SPLANE] = v.w;
+            float* d = lds_in + (cq * 4) * RPLANE + py * TWS + px;
+            d[0] = v.x; d[RPLANE] = v.y; d[2 * RPLANE] = v.z; d[3 * RPLANE] = v.w;
         }
         {
             const float* src = wp_ct + (size_t)ch * KCH * NT;
-            for (int idx = tid; idx < KCH * (SNT / 4); idx += 256) {
+            for (int idx = tid; idx < KCH * (SNT / 4); idx += NTH) {
                 const int kl = idx / (SNT / 4), q = idx % (SNT / 4);
                 reinterpret_cast<float4*>(lds_w)[idx] = *reinterpret_cast<const float4*>(src + kl * NT + q * 4);
             }
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_small_kernel(
         __syncthreads();
 #pragma unroll 1
         for (int cp = 0; cp < CK / 2; ++cp) {
-            const float* ap = lds_in + cp * 2 * SPLANE;
+            const float* ap = lds_in + cp * 2 * RPLANE;
             const float* bp = lds_w + cp * 18 * SNT + boff;
 #pragma unroll
             for (int s = 0; s < 9; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[aoff[s]], bp[2 * s * SNT], acc, 0, 0, 0);
@@ -799,6 +803,13 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
         if (pool) {   // (every pooling layer of SuperPoint has a ReLU)
             if (cin == 128) hipLaunchKernelGGL((conv3x3_small_kernel<128, true, 8, true>), gs, dim3(256), 0, s, in, wp, bias, out, H, W, cout, sx, sy, sx * sy * B);
             else hipLaunchKernelGGL((conv3x3_small_kernel<64, true, 8, true>), gs, dim3(256), 0, s, in, wp, bias, out, H, W, cout, sx, sy, sx * sy * B);
+            return;
+        }
+        // five-row tiles (round 6, tuning switch): the 64-channel pool-less layer of ONE 240 x 320 map (conv2a of one frame) as 960 workgroups of five waves
+        static const int r5_px = tune_int("RFE_CONV_SMALL_R5", 0);   // pixel budget, 0 = off
+        if (cin == 64 && relu && (long long)B * H * W <= r5_px) {
+            const int sy5 = (H + 4) / 5;
+            hipLaunchKernelGGL((conv3x3_small_kernel<64, true, 8, false, 5>), dim3(conv_grid(sx, sy5, B, cout / SNT)), dim3(320), 0, s, in, wp, bias, out, H, W, cout, sx, sy5, sx * sy5 * B);
             return;
         }
         if (cin == 128 && relu) hipLaunchKernelGGL((conv3x3_small_kernel<128, true, 8>), gs, dim3(256), 0, s, in, wp, bias, out, H, W, cout, sx, sy, sx * sy * B);
