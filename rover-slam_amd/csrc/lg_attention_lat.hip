@@ -18,6 +18,7 @@
 //     written ONCE with 16-byte stores -- no partials in HBM, no second launch.
 // The rotary encoding is NOT applied here: the one-pair qkv projection (gemm_lat.hip, ROPE epilogue) has already rotated q and k.
 // Roofline: fp32 MFMA peak; algorithmic 4 heads * 4 * 64 * sum n_q n_k FLOP.
+#include <type_traits>
 #include "rfe_internal.h"
 #include "h2_split.h"
 
@@ -332,6 +333,242 @@ __global__ __launch_bounds__(64 * NW, 1) void lg_attention_lat_kernel(
     RFE_ATS(3);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------------------------
+// PIPE form (round 6, fp32): the same tiles, arithmetic and merge with the NEXT tile's operands read from LDS in the shadow of this tile's PV products.
+// In lg_attention_lat_kernel a wave reads the eight K fragments and 32 V values of tile t, waits for them, and only then starts tile t's 64 matrix
+// instructions: with one wave per SIMD nobody covers those 40 LDS round trips (-3 700 of 51 700 cycles when they are ablated, profiles/r04_ab_notes.md).
+// The Sᵀ chain must stay 32 dependent matrix instructions strictly back to back (anything between two of them costs the accumulator forwarding), but the
+// PV products alternate between TWO accumulators: an instruction between o0's and o1's costs nothing.  So:
+//   * two tile buffers per wave (2 x 16 KB; 128 KB per workgroup): tile t + 1 -- copied two tiles ahead -- is read by ds_reads issued BETWEEN the PV matrix
+//     instructions of tile t (two or three per o0 / o1 pair) INTO THE REGISTERS THOSE INSTRUCTIONS HAVE JUST CONSUMED (the K fragments died with the Sᵀ
+//     chain, a V value dies with its two products: no second register set -- a first form with two sets needed 340 registers and paid for them in
+//     accumulator-file copies), waited for once, after the last of them;
+//   * the copy of tile t + 3 then goes into the buffer tile t + 1 has just left.
+// Everything else (block decode, copy geometry and swizzle, online softmax with deferred rescale, merge through LDS) is the kernel above, line for line.
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 1) void lg_attention_lat_pipe_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld, float* __restrict__ out,
+    int Lq, int Lk, int nqb, const int* __restrict__ qlen, const int* __restrict__ klen, const int* __restrict__ kv_map, int nseq_total) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // NW waves x 2 x AL_WAVE_F floats; the merge needs NW x 32 x 68 floats
+    constexpr int NT_ = 64 * NW;
+    const int Lb = blockIdx.x, xcd = Lb & 7, t_ = Lb >> 3;
+    const int qb = t_ % nqb, unit = (t_ / nqb) * 8 + xcd;
+    if (unit >= 4 * nseq_total) return;
+    const int seq = unit >> 2, head = unit & 3;
+    const int kvseq = kv_map ? kv_map[seq] : seq;
+    const int nq = qlen ? qlen[seq] : Lq;
+    const int nk = klen ? klen[kvseq] : Lk;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    if (qb * 32 >= nq || nk <= 0) {
+        for (int e = tid; e < 32 * 16; e += NT_) {
+            const int row = qb * 32 + (e >> 4);
+            if (row < Lq) *reinterpret_cast<f32x4*>(out + ((size_t)seq * Lq + row) * 256 + head * 64 + (e & 15) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        return;
+    }
+    const int qrow = qb * 32 + j;
+    const size_t qrow_c = (size_t)seq * Lq + (qrow < Lq ? qrow : Lq - 1);
+    constexpr float kScale = 0.125f * 1.44269504088896341f;
+    float qreg[32];
+    {
+        const f32x4* qp4 = reinterpret_cast<const f32x4*>(q + qrow_c * ld + head * 64) + h;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const f32x4 t = qp4[2 * g];
+            qreg[4 * g] = t[0] * kScale; qreg[4 * g + 1] = t[1] * kScale; qreg[4 * g + 2] = t[2] * kScale; qreg[4 * g + 3] = t[3] * kScale;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // from here on the vector-memory counter only sees this wave's tile copies
+
+    const int per = ((nk + NW - 1) / NW + AL_K - 1) / AL_K * AL_K;
+    const int kbeg = wave * per;
+    const int kend = kbeg + per < nk ? kbeg + per : nk;
+    const int ntile = kend > kbeg ? (kend - kbeg + AL_K - 1) / AL_K : 0;
+    const float* kbase = k + (size_t)kvseq * Lk * ld + head * 64;
+    const float* vbase = v + (size_t)kvseq * Lk * ld + head * 64;
+    float* const wl = lds + wave * (2 * AL_WAVE_F);     // buffer b: K tile at wl + b * AL_WAVE_F, V tile behind it
+    const int crow = lane >> 4, cslot = lane & 15;
+    int koff[8], voff[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int row = u * 4 + crow;
+        koff[u] = row * ld + ((cslot ^ (row & 15)) << 2);
+        voff[u] = row * ld + (cslot << 2);
+    }
+    // 16 copy instructions per tile (8 K + 8 V), always: the counted waits below rely on it
+    auto issue = [&](int t, int b) {
+        const int k0 = kbeg + t * AL_K;
+        const float* kb = kbase + (size_t)k0 * ld;
+        const float* vb = vbase + (size_t)k0 * ld;
+        float* Kd = wl + b * AL_WAVE_F;
+        float* Vd = Kd + AL_TILE_F;
+        if (k0 + AL_K <= nk) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) __builtin_amdgcn_global_load_lds((alat_gptr_t)(kb + koff[u]), (alat_lds_ptr_t)(Kd + u * 256), 16, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) __builtin_amdgcn_global_load_lds((alat_gptr_t)(vb + voff[u]), (alat_lds_ptr_t)(Vd + u * 256), 16, 0, 0);
+        } else {   // the sequence's last, partial tile: keys past the end read the last valid row (finite) and are masked in S
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int row = u * 4 + crow;
+                const int rc = k0 + row < nk ? row : nk - 1 - k0;
+                __builtin_amdgcn_global_load_lds((alat_gptr_t)(kb + rc * ld + ((cslot ^ (row & 15)) << 2)), (alat_lds_ptr_t)(Kd + u * 256), 16, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int row = u * 4 + crow;
+                const int rc = k0 + row < nk ? row : nk - 1 - k0;
+                __builtin_amdgcn_global_load_lds((alat_gptr_t)(vb + rc * ld + (cslot << 2)), (alat_lds_ptr_t)(Vd + u * 256), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+    const int jsw = j & 15;
+    f32x4 kf[8];
+    float vf[32];
+    // LDS addresses of this lane's fragments inside a buffer (relative to the buffer's K tile)
+    const float* const ka0 = wl + j * 64;                           // + ((2 g + h) ^ jsw) * 4
+    const float* const va0 = wl + AL_TILE_F + (4 * h) * 64 + j;     // + kr * 64 (+ 32)
+
+    if (ntile > 0) {
+        issue(0, 0);
+        if (ntile > 1) issue(1, 1);
+        if (ntile > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int g = 0; g < 8; ++g) kf[g] = *reinterpret_cast<const f32x4*>(ka0 + (((2 * g + h) ^ jsw) << 2));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kr = (r & 3) + 8 * (r >> 2);
+            vf[r] = va0[kr * 64]; vf[16 + r] = va0[kr * 64 + 32];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (ntile > 2) issue(2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    for (int t = 0; t < ntile; ++t) {
+        const int NXT = (t + 1) & 1;
+        // ---- S^T = K Q^T, 32 dependent matrix instructions back to back
+        f32x16 st;
+        const bool first = t == 0;
+        {
+            const float init = first ? 0.f : -m_run;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = init;
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[g][e], qreg[4 * g + e], st, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int k0 = kbeg + t * AL_K;
+        if (k0 + AL_K > nk) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (key >= nk) st[r] = -INFINITY;
+            }
+        }
+        {
+            float mx = fmaxf(fmaxf(st[0], st[1]), st[2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, st[r]), st[r + 1]);
+            mx = fmaxf(mx, st[15]);
+            if (__any(first || mx > AL_DEFER)) {
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float ref = first ? 0.f : m_run;
+                const float m_new = fmaxf(m_run, mx + ref);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                const float d = ref - m_new;
+                l_run *= alpha;
+                m_run = m_new;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { st[r] += d; o0[r] *= alpha; o1[r] *= alpha; }
+            }
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[r] = __builtin_amdgcn_exp2f(st[r]); ps += st[r]; }
+            l_run += ps;
+        }
+        // ---- O^T += V^T P^T on two alternating accumulators, with tile t + 1's operands read in between
+        const bool nxt = t + 1 < ntile;
+        if (nxt) {
+            // tile t + 1 has landed; the only younger copies are tile t + 2's 16 (requested when tile t's reads had returned)
+            if (t + 2 < ntile) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const float* const ka = ka0 + NXT * AL_WAVE_F;
+            const float* const va = va0 + NXT * AL_WAVE_F;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r], st[r], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[16 + r], st[r], o1, 0, 0, 0);
+                const int kr = (r & 3) + 8 * (r >> 2);
+                vf[r] = va[kr * 64]; vf[16 + r] = va[kr * 64 + 32];           // tile t + 1's values into the registers the two products above have read
+                if (r < 8) kf[r] = *reinterpret_cast<const f32x4*>(ka + (((2 * r + h) ^ jsw) << 2));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads have RETURNED: tile t + 1's buffer may take the copy of tile t + 3
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 3 < ntile) issue(t + 3, NXT);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r], st[r], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[16 + r], st[r], o1, 0, 0, 0);
+            }
+        }
+    }
+    l_run += __shfl_xor(l_run, 32);
+
+    // ---- merge the NW key ranges through LDS (as lg_attention_lat_kernel)
+    __syncthreads();
+    float* const part = lds;
+    {
+        float* pr = part + (wave * 32 + j) * 68;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            *reinterpret_cast<f32x4*>(pr + 8 * rq + 4 * h) = f32x4{o0[4 * rq], o0[4 * rq + 1], o0[4 * rq + 2], o0[4 * rq + 3]};
+            *reinterpret_cast<f32x4*>(pr + 32 + 8 * rq + 4 * h) = f32x4{o1[4 * rq], o1[4 * rq + 1], o1[4 * rq + 2], o1[4 * rq + 3]};
+        }
+        if (h == 0) { pr[64] = m_run; pr[65] = l_run; }
+    }
+    __syncthreads();
+    {
+        constexpr int TPQ = NT_ / 32, DPT = 64 / TPQ;
+        const int qj = tid / TPQ, dq = (tid % TPQ) * DPT;
+        const int row = qb * 32 + qj;
+        float mw[NW], lw[NW], m = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { mw[w] = part[(w * 32 + qj) * 68 + 64]; lw[w] = part[(w * 32 + qj) * 68 + 65]; m = fmaxf(m, mw[w]); }
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        float l = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            if (!(lw[w] > 0.f)) continue;
+            const float wgt = __builtin_amdgcn_exp2f(mw[w] - m);
+            l += lw[w] * wgt;
+            const float* pr = part + (w * 32 + qj) * 68 + dq;
+            a0 += *reinterpret_cast<const f32x4*>(pr) * wgt;
+            if (DPT == 8) a1 += *reinterpret_cast<const f32x4*>(pr + 4) * wgt;
+        }
+        const float inv = (row < nq && l > 0.f) ? 1.0f / l : 0.f;
+        if (row < Lq) {
+            float* op = out + ((size_t)seq * Lq + row) * 256 + head * 64 + dq;
+            *reinterpret_cast<f32x4*>(op) = a0 * inv;
+            if (DPT == 8) *reinterpret_cast<f32x4*>(op + 4) = a1 * inv;
+        }
+    }
+}
+
 #ifdef RFE_TUNING
 extern "C" int rfe_k_dbg_timeline_att(unsigned long long* host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(rfe_dbg_ts_att), (size_t)n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
@@ -362,6 +599,14 @@ bool launch_lg_attention_lat(hipStream_t s, const float* q, const float* k, cons
     if (nw == 8) { RFE_ALAT_GO(8, false); return true; }
 #endif
     if (h2) { RFE_ALAT_GO(4, true); return true; }
+    static const int pipe = tune_int("RFE_ALAT_PIPE", 0);   // round 6: next tile's operands read in the shadow of the PV products (two tile buffers per wave)
+    if (pipe) {
+        constexpr int bytes = 4 * 2 * AL_WAVE_F * 4;         // 128 KB (the merge needs 34.8 KB of it)
+        static bool lp_[64];
+        ensure_dynamic_lds((const void*)lg_attention_lat_pipe_kernel<4>, bytes, lp_);
+        hipLaunchKernelGGL((lg_attention_lat_pipe_kernel<4>), dim3(nqb * units8), dim3(256), bytes, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, nseq);
+        return true;
+    }
     RFE_ALAT_GO(4, false);
 #undef RFE_ALAT_GO
     return true;
