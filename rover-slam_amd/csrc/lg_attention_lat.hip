@@ -18,7 +18,6 @@
 //     written ONCE with 16-byte stores -- no partials in HBM, no second launch.
 // The rotary encoding is NOT applied here: the one-pair qkv projection (gemm_lat.hip, ROPE epilogue) has already rotated q and k.
 // Roofline: fp32 MFMA peak; algorithmic 4 heads * 4 * 64 * sum n_q n_k FLOP.
-#include <type_traits>
 #include "rfe_internal.h"
 #include "h2_split.h"
 
@@ -334,6 +333,7 @@ __global__ __launch_bounds__(64 * NW, 1) void lg_attention_lat_kernel(
 }
 
 
+#ifdef RFE_TUNING   // measured and not adopted (profiles/r06_ab_notes.md 2e): the tuning build keeps it for A/B runs, the product library does not contain it
 // ------------------------------------------------------------------------------------------------------------------------------------------------
 // PIPE form (round 6, fp32): the same tiles, arithmetic and merge with the NEXT tile's operands read from LDS in the shadow of this tile's PV products.
 // In lg_attention_lat_kernel a wave reads the eight K fragments and 32 V values of tile t, waits for them, and only then starts tile t's 64 matrix
@@ -569,6 +569,8 @@ __global__ __launch_bounds__(64 * NW, 1) void lg_attention_lat_pipe_kernel(
     }
 }
 
+#endif
+
 #ifdef RFE_TUNING
 extern "C" int rfe_k_dbg_timeline_att(unsigned long long* host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(rfe_dbg_ts_att), (size_t)n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
@@ -599,6 +601,7 @@ bool launch_lg_attention_lat(hipStream_t s, const float* q, const float* k, cons
     if (nw == 8) { RFE_ALAT_GO(8, false); return true; }
 #endif
     if (h2) { RFE_ALAT_GO(4, true); return true; }
+#ifdef RFE_TUNING
     static const int pipe = tune_int("RFE_ALAT_PIPE", 0);   // round 6: next tile's operands read in the shadow of the PV products (two tile buffers per wave)
     if (pipe) {
         constexpr int bytes = 4 * 2 * AL_WAVE_F * 4;         // 128 KB (the merge needs 34.8 KB of it)
@@ -607,6 +610,7 @@ bool launch_lg_attention_lat(hipStream_t s, const float* q, const float* k, cons
         hipLaunchKernelGGL((lg_attention_lat_pipe_kernel<4>), dim3(nqb * units8), dim3(256), bytes, s, q, k, v, ld, out, Lq, Lk, nqb, qlen, klen, kv_map, nseq);
         return true;
     }
+#endif
     RFE_ALAT_GO(4, false);
 #undef RFE_ALAT_GO
     return true;
