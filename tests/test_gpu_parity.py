@@ -483,6 +483,30 @@ def test_extract_is_repeatable_when_the_heads_overlap(ctx, oracle, B, H, W, K):
         assert first[0][i] == r["n"] and np.array_equal(first[1][i], r["kxy"]) and np.array_equal(first[3][i], r["desc"])
 
 
+@pytest.mark.parametrize("H,W,K,bias", [(120, 160, 128, None), (136, 200, 1024, None), (480, 640, 1024, None), (240, 320, 1024, 9.5), (101, 77, 64, None)])
+def test_fused_detector_tail_equals_the_separate_launches(ctx, H, W, K, bias):
+    """Round 6: calls of up to four frames run the detector tail as sp_tail_lat_kernel + select_rankall_keys_kernel (softmax from the logits, NMS and an UNORDERED
+    candidate list in one launch; rank-determined outputs), larger calls the separate softmax / NMS / count / compact / select launches.  The same frames through both
+    -- five in one call, then the first four, two and one of them -- must give identical bytes per frame: counts, keypoints in order, scores, descriptors.  Sizes that
+    pick each tile height (32 / 40 / 48 rows), a size that is no multiple of 8, a budget above the candidate count of small frames, and the dustbin-biased weights whose
+    candidate count stays BELOW Kmax (row-major order, ranked by pixel index in the fused form)."""
+    from rover_slam_amd import capi
+    if bias is not None:
+        ctx.set_weights(capi.KIND_SUPERPOINT, Wt.make_superpoint(seed=7, dustbin_bias=bias))
+    try:
+        frames, _ = synth.make_frames(5, H, W, seed=H + W)
+        ref = ctx.extract(frames, kmax=K)                                  # 5 frames: the separate launches
+        for nb in (4, 2, 1):
+            got = ctx.extract(frames[:nb], kmax=K)                         # <= 4 frames: the fused tail
+            for a, b in zip(ref, got):
+                assert np.array_equal(a[:nb], b), (nb, a.shape)
+        if bias is not None:
+            assert 0 < int(ref[0].min()) and int(ref[0].max()) < K        # the case really exercises K < Kmax
+    finally:
+        if bias is not None:
+            ctx.set_weights(capi.KIND_SUPERPOINT, Wt.make_superpoint(seed=7))
+
+
 def test_host_graph_option_gives_identical_results(ctx, oracle):
     """RFE_OPT_HOST_GRAPH: the host entries replay a captured hipGraph per call shape (captured on the third call of a shape, four shapes kept; weights, hyper-parameters, options, shape
     and workspace addresses are part of the key).  Same bytes as ordinary launches for extract (u8 / float / binarised) and match, across shape changes,
