@@ -470,6 +470,10 @@ int launch_gemm_nt(hipStream_t s, const GemmArgs& g_in) {
         if (launch_gemm_lat(s, g, nullptr, 0)) return 0;
     }
     const bool res = g.R != nullptr, lna = g.stats_in != nullptr;
+#ifdef RFE_TUNING
+    static const bool ws_on = tune_int("RFE_GEMM_WS", 0) != 0;   // round 6, measured and not adopted: LayerNorm + GELU of the consumer on producer waves (gemm_ws.hip)
+    if (lna && ws_on && res && launch_gemm_ln_ws(s, g)) return 0;
+#endif
     static const bool lni = tune_int("RFE_LN_INTERLEAVE", 1) != 0;   // tuning switch
 
     static const bool kp_on = tune_int("RFE_GEMM_KP", 1) != 0;   // tuning switch: 0 = padded layout / k-ascending order everywhere

@@ -202,6 +202,7 @@ inline void ensure_dynamic_lds(const void* kernel, int bytes, bool* done) {
         if (dev >= 0 && dev < 64) done[dev] = true;
     }
 }
+bool launch_gemm_ln_ws(hipStream_t s, const GemmArgs& g);   // gemm_ws.hip: the LayerNorm-fused consumer with producer / math waves; false = shape not served
 int launch_gemm_h2(hipStream_t s, const GemmArgs& g);   // gemm_h2.hip: split GEMM on the f16 matrix pipe (GemmArgs::Bh / Bl), called by launch_gemm_nt
 void launch_split_f16(hipStream_t s, const float* x, uint16_t* hi, uint16_t* lo, size_t n);
 bool gemm_nt_rope_ok(const GemmArgs& g);                  // may launch_gemm_nt carry GemmArgs::rope_csn for this shape? (set rope_c0 / rope_c1 first)
