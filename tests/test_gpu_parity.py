@@ -507,6 +507,22 @@ def test_fused_detector_tail_equals_the_separate_launches(ctx, H, W, K, bias):
             ctx.set_weights(capi.KIND_SUPERPOINT, Wt.make_superpoint(seed=7))
 
 
+def test_tiny_and_odd_frames_vs_oracle(ctx, oracle):
+    """The reference graph has dynamic axes: any frame of at least 8 x 8 pixels goes.  Frames from ONE cell (8 x 8) up to just past a tile of the fused
+    detector tail (72 x 104 haloed), odd sizes, random noise (tie-rich), batches on both sides of the four-frame switch between the fused tail and the separate
+    launches, budgets of 1, 7 and 4096 keypoints: every output bit for bit."""
+    w = Wt.make_superpoint(seed=7)
+    rng = np.random.default_rng(0)
+    for (H, W) in [(8, 8), (9, 15), (16, 8), (8, 64), (24, 40), (31, 33), (47, 9), (64, 64), (65, 130), (73, 105)]:
+        for B in (1, 4, 5):
+            frames = rng.integers(0, 256, (B, H, W), dtype=np.uint8)
+            for K in (1, 7, 4096):
+                n, kxy, score, desc = ctx.extract(frames, kmax=K)
+                for i in (0, B - 1):
+                    r = oracle.superpoint(w, frames[i], kmax=K)
+                    assert n[i] == r["n"] and np.array_equal(kxy[i], r["kxy"]) and np.array_equal(score[i], r["score"]) and np.array_equal(desc[i], r["desc"]), (H, W, B, K, i)
+
+
 def test_host_graph_option_gives_identical_results(ctx, oracle):
     """RFE_OPT_HOST_GRAPH: the host entries replay a captured hipGraph per call shape (captured on the third call of a shape, four shapes kept; weights, hyper-parameters, options, shape
     and workspace addresses are part of the key).  Same bytes as ordinary launches for extract (u8 / float / binarised) and match, across shape changes,
