@@ -523,6 +523,32 @@ def test_tiny_and_odd_frames_vs_oracle(ctx, oracle):
                     assert n[i] == r["n"] and np.array_equal(kxy[i], r["kxy"]) and np.array_equal(score[i], r["score"]) and np.array_equal(desc[i], r["desc"]), (H, W, B, K, i)
 
 
+@pytest.mark.parametrize("border,always,thr,bias", [(2, 1, 0.0005, None), (0, 0, 0.005, None), (7, 1, 0.0005, 9.5), (4, 1, 0.0005, 9.5)])
+def test_fused_detector_tail_graph_hyper_parameters_vs_oracle(ctx, oracle, border, always, thr, bias):
+    """The graph's constants on the fused tail's side of the switch (published NMS radius 4, <= 4 frames): border width, the unconditional top-k (counts below
+    Kmax then come out in score order instead of row-major -- the ranking kernel's two orders), another detection threshold; against the oracle with the same
+    constants, and the same frames in a five-frame call (separate launches)."""
+    from rover_slam_amd import capi
+    w = Wt.make_superpoint(seed=7, dustbin_bias=bias) if bias is not None else Wt.make_superpoint(seed=7)
+    ctx.set_weights(capi.KIND_SUPERPOINT, w)
+    ctx.set_hparams(sp_nms_radius=4, sp_remove_borders=border, sp_topk_always=always)
+    try:
+        frames, _ = synth.make_frames(5, 136, 200, seed=border * 10 + always)
+        K = 512
+        got = ctx.extract(frames[:3], kmax=K, thr=thr)
+        five = ctx.extract(frames, kmax=K, thr=thr)
+        for a, b in zip(got, five):
+            assert np.array_equal(a, b[:3])
+        for i in range(3):
+            r = oracle.superpoint(w, frames[i], kmax=K, thr=thr, nms_radius=4, border=border, topk_always=bool(always))
+            assert got[0][i] == r["n"] and np.array_equal(got[1][i], r["kxy"]) and np.array_equal(got[2][i], r["score"]) and np.array_equal(got[3][i], r["desc"]), i
+        if bias is not None:
+            assert int(got[0].max()) < K          # the unconditional top-k really had fewer candidates than Kmax to order
+    finally:
+        ctx.set_hparams(sp_nms_radius=4, sp_remove_borders=4, sp_topk_always=0)
+        ctx.set_weights(capi.KIND_SUPERPOINT, Wt.make_superpoint(seed=7))
+
+
 def test_host_graph_option_gives_identical_results(ctx, oracle):
     """RFE_OPT_HOST_GRAPH: the host entries replay a captured hipGraph per call shape (captured on the third call of a shape, four shapes kept; weights, hyper-parameters, options, shape
     and workspace addresses are part of the key).  Same bytes as ordinary launches for extract (u8 / float / binarised) and match, across shape changes,
