@@ -31,7 +31,9 @@ int conv_ck() {
     return ck;
 }
 
-size_t packed_conv3x3_count(int cin, int cout) { return (size_t)cout * cin * 9; }
+// two images of the same weights: the implicit-GEMM tiles' [Cout/64][Cin/CK][CK*9][64] and, behind it (Cin a multiple of 16, Cout of 16), the 16 x 16 x 4 tiles'
+// [Cout/16][Cin/16][9][4][16][4] (see conv3x3_t16d_kernel)
+size_t packed_conv3x3_count(int cin, int cout) { return (size_t)cout * cin * 9 * ((cin % 16 == 0 && cout % 16 == 0) ? 2 : 1); }
 
 // [Cout/64][Cin/CK][CK*9][64] : element (ct, ch, kl, j) = w[ct*64+j][ch*CK + kl/9][(kl%9)/3][kl%3]
 void pack_conv3x3_weights(const float* w, int cin, int cout, std::vector<float>& out) {
@@ -45,6 +47,22 @@ void pack_conv3x3_weights(const float* w, int cin, int cout, std::vector<float>&
                     int co = ct * NT + j, ci = ch * CK + kl / 9, tap = kl % 9;
                     out[(((size_t)ct * nch + ch) * KCH + kl) * NT + j] = w[((size_t)co * cin + ci) * 9 + tap];
                 }
+    if (cin % 16 || cout % 16) return;
+    // the 16 x 16 x 4 tiles (round 6): element (block of 16 output channels b, 16-channel stage st, group g of 16 kappa, lane group q, channel co, step s) =
+    // w[16 b + co][16 st + kap / 9][tap = kap % 9] with kap = 16 g + 4 s + q -- the four weights ONE lane (co, q) feeds to the four consecutive k-steps 4 g .. 4 g + 3
+    // are 16 contiguous bytes, and the 64 lanes of a group read 1 KB in lane order (one conflict-free ds_read_b128 instead of four ds_read_b32).  The order in which
+    // the products are ACCUMULATED does not change: k-steps ascending, kappa = 4 s36 + q inside a step.
+    float* t16 = out.data() + (size_t)cout * cin * 9;
+    const int nst = cin / 16;
+    for (int b = 0; b < cout / 16; ++b)
+        for (int st = 0; st < nst; ++st)
+            for (int g = 0; g < 9; ++g)
+                for (int q = 0; q < 4; ++q)
+                    for (int co = 0; co < 16; ++co)
+                        for (int sq = 0; sq < 4; ++sq) {
+                            const int kap = 16 * g + 4 * sq + q, ci = st * 16 + kap / 9, tap = kap % 9;
+                            t16[((((((size_t)b * nst + st) * 9 + g) * 4 + q) * 16 + co) * 4) + sq] = w[((size_t)(b * 16 + co) * cin + ci) * 9 + tap];
+                        }
 }
 
 // per-lane A offsets for the 9 k-steps of an 18-kappa period (two input channels)
@@ -399,26 +417,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_t16d_kernel(
     for (int nb = 0; nb < NB; ++nb) acc[nb] = *reinterpret_cast<const f32x4*>(bias + co0 + nb * 16 + 4 * q);
     // pixel-operand addressing of the 9 k-steps of a 36-kappa period (4 input channels = granule c4 of the stage): kappa = 4 s + q ->
     // (channel e = kappa / 9 inside the granule, tap) -> haloed pixel p; word = p * 16 + ((c4 ^ swizzle(p)) << 2) + e
-    int pbase[9], pswz[9];
+    // (round 6) all 36 word offsets are formed ONCE: on gfx950 a wave's fp32 matrix instruction keeps its SIMD to itself (tools/kbench/mfma_valu_share.hip: VALU, integer
+    // and LDS instructions of any wave on that SIMD ADD to the matrix time), and the xor / shift / add per pixel read were two vector instructions per 32-cycle matrix instruction
+    int poff[4][9];
 #pragma unroll
     for (int s9 = 0; s9 < 9; ++s9) {
         const int kap = 4 * s9 + q, e = kap / 9, tap = kap % 9;
         const int p = (wave + tap / 3) * T16_IW + px + tap % 3;
-        pbase[s9] = p * T16_CK + e;
-        pswz[s9] = (p >> 2) & 3;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) poff[c4][s9] = p * T16_CK + e + ((c4 ^ ((p >> 2) & 3)) << 2);
     }
     const float* in_b = in + (size_t)b * H * W * CIN;
-    const float* wp_ct = wp + (size_t)(ct / (NT / NC)) * (CIN / 8) * 72 * NT + (ct % (NT / NC)) * NC;
-
-    // weight copies: a row of the stage is NC floats (128 B / 64 B): lane -> row lane / PCS, 16-byte piece lane % PCS; 144 rows = 18 slots of 8 rows (NC = 32) or
-    // 9 slots of 16 rows (NC = 16); wave w issues slots w, w + 4, .. -- WCP each, so that the vector-memory counter advances alike in every wave: a surplus
-    // copy repeats the wave's previous one (same data to the same place)
-    constexpr int PCS = NC / 4, RPS = 64 / PCS, NSLOT = T16D_WROWS / RPS, WCP = (NSLOT + 3) / 4;   // pieces per row, rows per slot, slots, copies per wave
-    int w_off[WCP], w_slot[WCP];
+    // weights: the 16 x 16 x 4 image of the blob (behind the implicit-GEMM image, pack_conv3x3_weights): a stage of a 16-channel block is 9 KB contiguous; one wave
+    // instruction copies 1 KB = one group of 16 kappa; 9 NB slots per stage, wave w issues slots w, w + 4, .. -- WCP each, so that the vector-memory counter advances
+    // alike in every wave: a surplus copy repeats the wave's previous one (same data to the same place)
+    const float* wp_t16 = wp + (size_t)COUT * CIN * 9;
+    constexpr int NSLOT = 9 * NB, WCP = (NSLOT + 3) / 4, BLK_W = 9 * 256;                 // slots, copies per wave, words of one 16-channel block's stage
+    int w_slot[WCP];
+    const float* w_src[WCP];
 #pragma unroll
     for (int u = 0; u < WCP; ++u) {
         w_slot[u] = wave + 4 * u < NSLOT ? wave + 4 * u : wave + 4 * (u - 1);
-        w_off[u] = (w_slot[u] * RPS + lane / PCS) * NT + (lane % PCS) * 4;
+        const int nbk = w_slot[u] / 9, gs = w_slot[u] % 9;
+        w_src[u] = wp_t16 + ((size_t)(ct * NB + nbk) * NST) * BLK_W + gs * 256 + lane * 4;      // + st * BLK_W per stage
     }
     // input copies: lane -> pixel slot * 16 + (lane >> 2), physical granule lane & 3; wave w issues slots w, w + 4 (pixels >= 108: padding)
     const float* i_src[2];
@@ -433,12 +454,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_t16d_kernel(
         i_src[u] = i_img[u] ? in_b + ((size_t)gyy * W + gxx) * CIN + g * 4 : t16d_zero_line + g * 4;
     }
     auto issue = [&](int st) {
-        const float* src = wp_ct + (size_t)st * 2 * 72 * NT;
         float* wdst = lwr + (st % 3) * WST_W;
         float* idst = lin + (st % 3) * IST_W;
 #pragma unroll
         for (int u = 0; u < WCP; ++u)
-            __builtin_amdgcn_global_load_lds((conv_gptr_t)(src + w_off[u]), (conv_lds_ptr_t)(wdst + w_slot[u] * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((conv_gptr_t)(w_src[u] + (size_t)st * BLK_W), (conv_lds_ptr_t)(wdst + w_slot[u] * 256), 16, 0, 0);
 #pragma unroll
         for (int u = 0; u < 2; ++u)
             __builtin_amdgcn_global_load_lds((conv_gptr_t)(i_src[u] + (i_img[u] ? st * T16_CK : 0)), (conv_lds_ptr_t)(idst + (wave + 4 * u) * 256), 16, 0, 0);
@@ -457,15 +477,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_t16d_kernel(
         __builtin_amdgcn_sched_barrier(0);
         if (st + 2 < NST) issue(st + 2);
         const float* li = lin + (st % 3) * IST_W;
-        const float* lw = lwr + (st % 3) * WST_W + px;
+        const float* lw = lwr + (st % 3) * WST_W + (q * 16 + px) * 4;        // this lane's 16 bytes of group g, block nb: + nb * BLK_W + g * 256
+        // 9 groups of 16 kappa = 4 k-steps each; k-step s36 = 4 g + sq covers kappa 4 s36 + q (pixel operand: input channel 4 (s36 / 9) + .., poff[s36 / 9][s36 % 9])
 #pragma unroll
-        for (int c4 = 0; c4 < T16_CK / 4; ++c4) {          // 4 input channels = 36 kappa = 9 k-steps
-            const float* bp = lw + (c4 * 36 + q) * NC;
+        for (int g = 0; g < 9; ++g) {
+            f32x4 wf[NB];
 #pragma unroll
-            for (int s9 = 0; s9 < 9; ++s9) {
-                const float pv = li[pbase[s9] + ((c4 ^ pswz[s9]) << 2)];
+            for (int nb = 0; nb < NB; ++nb) wf[nb] = *reinterpret_cast<const f32x4*>(lw + nb * BLK_W + g * 256);
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bp[4 * s9 * NC + 16 * nb], pv, acc[nb], 0, 0, 0);
+            for (int sq = 0; sq < 4; ++sq) {
+                constexpr int dummy = 0; (void)dummy;
+                const int s36 = 4 * g + sq;
+                const float pv = li[poff[s36 / 9][s36 % 9]];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nb][sq], pv, acc[nb], 0, 0, 0);
             }
         }
     }

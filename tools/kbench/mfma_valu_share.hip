@@ -10,7 +10,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
-template <int KIND>   // 0: v_fma_f32, 1: v_pk_fma_f32, 2: v_exp_f32
+template <int KIND>   // 0: v_fma_f32, 1: v_pk_fma_f32, 2: v_exp_f32, 3: integer (v_xor / v_lshl_add: the address arithmetic of an LDS fragment read), 4: LDS reads
 __global__ __launch_bounds__(512, 1) void share_kernel(float* out, int nm, int nv) {
     const int wave = threadIdx.x >> 6;
     float res = 0.f;
@@ -42,9 +42,30 @@ __global__ __launch_bounds__(512, 1) void share_kernel(float* out, int nm, int n
                 for (int r = 0; r < 2; ++r)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) p[j] = __builtin_elementwise_fma(p[j], f32x2{c, c}, f32x2{d, d});
-            } else {
+            } else if (KIND == 2) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) v[j] = __builtin_amdgcn_exp2f(v[j] * 1e-3f);
+            } else if (KIND == 3) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { unsigned u = __float_as_uint(v[j]); u = ((u ^ (unsigned)it) << 2) + (unsigned)j; v[j] = __uint_as_float(u); }
+            } else if (KIND == 4) {
+                extern __shared__ float sm[];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] += sm[(threadIdx.x * 16 + j * 64 + it) & 8191];
+            } else {
+                // KIND 5: 16 conflict-free ds_read_b32 (lane-linear), KIND 6: 16 ds_read_b128 -- no VALU at all between them, one wait per 16
+                extern __shared__ float sm[];
+                const unsigned addr = (unsigned)(size_t)(sm) + (threadIdx.x & 63) * (KIND == 5 ? 4 : 16);
+                float4 d4;
+                if (KIND == 5) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[j]) : "v"(addr), "n"(j * 256));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d4) : "v"(addr), "n"(j * 1024));
+                    v[0] += d4.x;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         }
 #pragma unroll
@@ -58,9 +79,9 @@ __global__ __launch_bounds__(512, 1) void share_kernel(float* out, int nm, int n
 template <int KIND>
 static double run(float* out, int nm, int nv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 2; ++i) share_kernel<KIND><<<256, 512>>>(out, nm, nv);
+    for (int i = 0; i < 2; ++i) share_kernel<KIND><<<256, 512, 32768>>>(out, nm, nv);
     CK(hipEventRecord(e0));
-    for (int i = 0; i < 5; ++i) share_kernel<KIND><<<256, 512>>>(out, nm, nv);
+    for (int i = 0; i < 5; ++i) share_kernel<KIND><<<256, 512, 32768>>>(out, nm, nv);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     return ms / 5 * 1e3;
@@ -78,5 +99,9 @@ int main() {
     series<0>(o, "v_fma_f32", 32768); series<0>(o, "v_fma_f32", 65536);
     series<1>(o, "v_pk_fma_f32", 32768); series<1>(o, "v_pk_fma_f32", 65536);
     series<2>(o, "v_exp_f32 (+ v_mul)", 16384);
+    series<3>(o, "integer: v_xor + v_lshl_add (2 per count)", 32768);
+    series<4>(o, "ds_read_b32 + v_add_f32 (+ address VALU)", 16384);
+    series<5>(o, "ds_read_b32, conflict-free, no VALU", 65536);
+    series<6>(o, "ds_read_b128, conflict-free, no VALU", 32768);
     return 0;
 }
