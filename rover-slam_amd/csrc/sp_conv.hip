@@ -775,7 +775,7 @@ void launch_conv3x3(hipStream_t s, const float* in, int B, int H, int W, int cin
         // Measured on one box (tools/tune_sweep.py, 200 steps, off / 700 / 1300 / 2500): one 640 x 480 frame 0.630 -> 0.605 ms (conv4a / 4b 28.7 -> 22.3 us,
         // convPa / Da 45 -> 33.7), one pair 2.314 -> 2.276, one 752 x 480 stereo frame 2.517 -> 2.487 (2500: convPa / Da of two 60 x 94 maps too); the
         // 64-channel-input layer (conv3a of one frame, 1200 workgroups) does not gain (36.6 -> 37.2 us) and keeps 32.
-        static const int nc16_thr = tune_int("RFE_CONV_T16_NC16", 2500);   // 0 disables (tuning build A/B)
+        static const int nc16_thr = tune_int("RFE_CONV_T16_NC16", 1000);   // round 6 (b128 weight fragments): convPa / Da of TWO frames (1200 - 1440 workgroups of 32 channels) are better off with 32 (60.2 -> 58.4, 71 -> 69 us), everything smaller with 16   // 0 disables (tuning build A/B)
         if (cin == 128 && (long long)sx * sy * B * (cout / T16_NC) < nc16_thr && cout % 16 == 0) {
             const dim3 g16(conv_grid(sx, sy, B, cout / 16));
             constexpr int b16 = 3 * (T16D_PIX * T16_CK + T16D_WROWS * 16) * 4;        // 51 KB
