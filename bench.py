@@ -441,7 +441,7 @@ def oracle_check_pair(pair_np, wsp, wlg, res, tol):
             "one_sided_borderline": int(only), "match_score_max_dev": float(dev), "match_score_tolerance": tol}
 
 
-def latency_resident(ctx, capi, synth, sharding, torch, dev, frames, steps=50, warmup=5, check=None):
+def latency_resident(ctx, capi, synth, sharding, torch, dev, frames, steps=200, warmup=20, check=None):
     """`latency.resident` of the bench line: BASELINE configs[1] / [2] / [4] -- the shapes the reference itself runs (batch 1,
     src/Extractors/superpoint_onnx.cc:100, src/Matchers/lightglue_onnx.cpp:168-172) -- device-resident, `steps` calls each, no
     per-stage events, wall clock between two device synchronisations.  `frames`: the first two frames of the bench stream (device)."""
@@ -672,7 +672,7 @@ def main():
     ap.add_argument("--no-pool", action="store_true", help="skip the short run through the C-ABI pool (rfe_pool_*, N=1)")
     ap.add_argument("--no-latency", action="store_true",
                     help="skip the `latency` object: BASELINE configs[1] / [2] / [4] device-resident and through the C++ drop-in classes (N=1)")
-    ap.add_argument("--latency-steps", type=int, default=50)
+    ap.add_argument("--latency-steps", type=int, default=200, help="calls per configuration of the `latency` object (after 20 un-timed ones)")
     ap.add_argument("--gather-desc", action="store_true", help="also gather scores and the 256-d descriptors to rank 0")
     ap.add_argument("--lg-fold", type=int, default=None, choices=[0, 1], help="override RFE_OPT_LG_FOLD_WO (default: the library's)")
     ap.add_argument("--lg-fp16x2", type=int, default=0, choices=[0, 1],
